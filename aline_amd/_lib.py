@@ -1,0 +1,132 @@
+"""ctypes binding of libaline_hip.so (the C ABI declared in include/aline_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing, importing this module
+raises, and every op that needs it fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libaline_hip.so")
+
+MAX_LAYERS = 8
+MAX_COMPONENTS = 16
+EMB = {"data": 0, "theta": 1, "mix": 2}
+PREC = {"f32": 0, "fp32": 0, "bf16": 1, "bf16x3": 2}
+SELECT_ARGMAX, SELECT_SAMPLE, SELECT_FORCED = 0, 1, 2
+
+_fp = C.c_void_p  # device pointers travel as plain addresses
+
+
+class AlineModel(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("dim_x", "dim_y", "d", "F", "H", "L", "C", "n_theta",
+                                  "embedding_type", "time_token")]
+        + [("std_min", C.c_float), ("precision", C.c_int32)]
+        + [(n, _fp) for n in ("x_w1", "x_b1", "x_w2", "x_b2", "y_w1", "y_b1", "y_w2", "y_b2",
+                              "theta_tokens")]
+        + [(n, _fp * MAX_LAYERS) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
+                                           "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm1_w",
+                                           "norm1_b", "norm2_w", "norm2_b")]
+        + [(n, _fp) for n in ("acq_w1", "acq_b1", "acq_w2", "acq_b2")]
+        + [(n, _fp * MAX_COMPONENTS) for n in ("gmm_w1", "gmm_b1", "gmm_w2", "gmm_b2")]
+    )
+
+
+class AlineStep(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("B", "n_ctx", "n_query", "n_target_data")]
+        + [(n, _fp) for n in ("context_x", "context_y", "query_x", "target_x", "target_all",
+                              "target_mask", "time_t")]
+        + [("select_mode", C.c_int32)]
+        + [(n, _fp) for n in ("uniform", "forced_idx", "idx", "log_prob", "zt", "post_mean",
+                              "post_std", "post_weight", "postq_mean", "postq_std", "postq_weight",
+                              "target_ll", "embedding", "encoding")]
+    )
+
+
+class AlineRollout(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("B", "P", "n_ctx0", "n_target_data", "T")]
+        + [(n, _fp) for n in ("point_x", "point_y", "role", "target_x", "target_all", "target_mask")]
+        + [("select_mode", C.c_int32)]
+        + [(n, _fp) for n in ("uniform", "forced_idx")]
+        + [("time_token_T", C.c_int32)]
+        + [(n, _fp) for n in ("idx", "slot", "log_prob", "target_ll", "zt", "post_mean", "post_std",
+                              "post_weight")]
+    )
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"aline_amd: HIP library not built ({LIB_PATH} missing). Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C aline_amd/csrc`. "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    MP, SP, RP = C.POINTER(AlineModel), C.POINTER(AlineStep), C.POINTER(AlineRollout)
+    sig = {
+        "aline_abi_version": (C.c_int, []),
+        "aline_error_string": (C.c_char_p, [C.c_int]),
+        "aline_step_workspace_bytes": (C.c_size_t, [MP, SP]),
+        "aline_embed_forward": (C.c_int, [MP, SP, _fp, C.c_size_t, _fp]),
+        "aline_encoder_forward": (C.c_int, [MP, SP, _fp, _fp, C.c_size_t, _fp]),
+        "aline_head_forward": (C.c_int, [MP, SP, _fp, _fp, C.c_size_t, _fp]),
+        "aline_step_forward": (C.c_int, [MP, SP, _fp, C.c_size_t, _fp]),
+        "aline_rollout_workspace_bytes": (C.c_size_t, [MP, RP]),
+        "aline_rollout_init": (C.c_int, [MP, RP, _fp, C.c_size_t, _fp]),
+        "aline_rollout_step": (C.c_int, [MP, RP, C.c_int, _fp, C.c_size_t, _fp]),
+        "aline_rollout_forward": (C.c_int, [MP, RP, _fp, C.c_size_t, _fp]),
+        "aline_rollout_export": (C.c_int, [RP, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+        "aline_compute_ll": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, _fp, _fp]),
+        "aline_eig_location_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_int,
+                                              C.c_int, C.c_float, C.c_float, C.c_float, _fp]),
+        "aline_eig_ces_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_float,
+                                         C.c_float, _fp, _fp]),
+        "aline_eig_finalize_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+        "aline_eig_finalize": (C.c_int, [_fp, C.c_int64, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.aline_abi_version() != 1:
+        raise RuntimeError("aline_amd: libaline_hip.so ABI version mismatch")
+    return lib, sig
+
+
+lib, SIGNATURES = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"aline_amd: {what} failed: {lib.aline_error_string(rc).decode()} ({rc})")
+
+
+def ptr(t):
+    """Device address of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "aline_amd expects contiguous tensors"
+    return t.data_ptr()
+
+
+def f32(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Workspace:
+    """Grow-only device scratch buffer handed to the C ABI (which never allocates)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        return self.buf

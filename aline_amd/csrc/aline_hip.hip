@@ -1,0 +1,556 @@
+// libaline_hip.so -- C ABI (include/aline_hip.h) over the gfx950 kernels.
+// Host side only enqueues kernels on the caller's stream; no allocation, no synchronisation.
+#include "../../include/aline_hip.h"
+#include "common.h"
+#include "gemm.h"
+#include "kernels.h"
+#include "eig.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a = 64) { return (v + a - 1) / a * a; }
+
+#define CHECK_LAUNCH()                                   \
+  do {                                                   \
+    if (hipGetLastError() != hipSuccess) return ALINE_ELAUNCH; \
+  } while (0)
+#define TRY(x)                \
+  do {                        \
+    int _rc = (x);            \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+// Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
+struct Plan {
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, total;
+  int qgmm_chunk;  // episodes per query-GMM chunk
+};
+
+Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool query_gmm) {
+  Plan p{};
+  const size_t N = (size_t)P + n_td + m.n_theta, M = (size_t)B * N, d = m.d, F = m.F;
+  const size_t n_t = (size_t)n_td + m.n_theta;
+  const size_t Cc = (size_t)std::max(m.C, 1);
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
+  p.Ex = take((size_t)B * (P + n_td) * d);
+  p.Ey = take((size_t)B * ey_rows * d);
+  size_t hid = std::max({(size_t)B * (P + n_td) * F, (size_t)B * ey_rows * F, M * F,
+                         (size_t)B * n_t * Cc * F});
+  p.qgmm_chunk = 0;
+  if (query_gmm) {
+    size_t per_ep = (size_t)P * Cc * F;
+    size_t budget = (size_t)64 << 20;  // 64 Mi floats = 256 MiB of hidden activations per chunk
+    p.qgmm_chunk = (int)std::max<size_t>(1, std::min<size_t>(B, budget / per_ep));
+    hid = std::max(hid, per_ep * p.qgmm_chunk);
+  }
+  p.Hid = take(hid);
+  p.X = take(M * d);
+  p.X1 = take(M * d);
+  p.QKV = take(M * 3 * d);
+  p.A = take(M * d);
+  p.Tm = take(M * d);
+  p.Wacq = take(F * d);
+  p.scalar = take(64);
+  p.total = off;
+  return p;
+}
+
+enum { ST_EMBED = 1, ST_ENC = 2, ST_HEAD = 4, ST_ALL = 7 };
+
+// Only the fields (and weight pointers) of the requested stages are checked, so a stand-alone
+// Embedder / Encoder / OutputHead module can call its own entry point with a partial struct.
+int validate_model(const aline_model &m, int stages = ST_ALL) {
+  if (m.d <= 0 || m.F <= 0) return ALINE_EINVAL;
+  if (m.d % 32 || m.F % 32 || m.d > 512) return ALINE_EUNSUPPORTED;
+  if (m.precision < 0 || m.precision > 2) return ALINE_EINVAL;
+  if (m.n_theta < 0) return ALINE_EINVAL;
+  if (m.embedding_type == ALINE_EMB_DATA ? m.n_theta != 0 : m.n_theta <= 0) return ALINE_EINVAL;
+  if (stages & ST_EMBED) {
+    if (m.dim_y < 1 || m.dim_y > 8 || m.dim_x < 1 || m.dim_x > 8) return ALINE_EUNSUPPORTED;
+    if (!m.x_w1 || !m.x_b1 || !m.x_w2 || !m.x_b2 || !m.y_w1 || !m.y_b1 || !m.y_w2 || !m.y_b2)
+      return ALINE_EINVAL;
+    if (m.n_theta > 0 && !m.theta_tokens) return ALINE_EINVAL;
+  }
+  if (stages & ST_ENC) {
+    if (m.H <= 0 || m.L <= 0) return ALINE_EINVAL;
+    if (m.L > ALINE_MAX_LAYERS || m.d % m.H) return ALINE_EUNSUPPORTED;
+    const int hd = m.d / m.H;
+    if (hd != 4 && hd != 8 && hd != 16 && hd != 32 && hd != 64 && hd != 128) return ALINE_EUNSUPPORTED;
+    for (int l = 0; l < m.L; ++l)
+      if (!m.in_proj_w[l] || !m.in_proj_b[l] || !m.out_proj_w[l] || !m.out_proj_b[l] || !m.lin1_w[l] ||
+          !m.lin1_b[l] || !m.lin2_w[l] || !m.lin2_b[l] || !m.norm1_w[l] || !m.norm1_b[l] ||
+          !m.norm2_w[l] || !m.norm2_b[l])
+        return ALINE_EINVAL;
+  }
+  if (stages & ST_HEAD) {
+    if (m.C <= 0) return ALINE_EINVAL;
+    if (m.C > ALINE_MAX_COMPONENTS) return ALINE_EUNSUPPORTED;
+    if (m.dim_y != 1) return ALINE_EUNSUPPORTED;  // GMM head is single-output (model/head.py:113 TODO)
+    if (!m.acq_w1 || !m.acq_b1 || !m.acq_w2 || !m.acq_b2) return ALINE_EINVAL;
+    for (int c = 0; c < m.C; ++c)
+      if (!m.gmm_w1[c] || !m.gmm_b1[c] || !m.gmm_w2[c] || !m.gmm_b2[c]) return ALINE_EINVAL;
+  }
+  return ALINE_OK;
+}
+
+GemmArgs gemm_args(const float *X, int ldx, const float *W, const float *bias, int ldw, float *Y,
+                   int ldy, int M, int N, int K, bool relu) {
+  GemmArgs a{};
+  a.X = X; a.ldx = ldx; a.R_in = 1; a.G_in = 1; a.off_in = 0;
+  a.W[0] = W; a.bias[0] = bias; a.ldw = ldw;
+  a.Y = Y; a.ldy = ldy; a.R_out = 1; a.G_out = 1; a.off_out = 0; a.col_per_group = 0;
+  a.M = M; a.N = N; a.K = K; a.relu = relu ? 1 : 0;
+  return a;
+}
+
+struct Ctx {
+  const aline_model *m;
+  Geo g;
+  Plan pl;
+  float *ws;
+  hipStream_t st;
+  float *at(size_t off) const { return ws + off; }
+};
+
+inline dim3 grid1d(size_t total, int block = 256) { return dim3((unsigned)((total + block - 1) / block)); }
+
+// x/y point embedders -> Ex [B*(P+n_td), d], Ey [B*ey_rows, d]     (model/embedder.py:47-57)
+int do_embed_points(const Ctx &c, Src3 xs, const float *ysrc, int ey_rows) {
+  const aline_model &m = *c.m;
+  const int rows_x = c.g.B * (c.g.P + c.g.n_td);
+  float *hid = c.at(c.pl.Hid);
+  hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_x * m.F), dim3(256), 0, c.st, xs,
+                     c.g.P + c.g.n_td, c.g.B, m.dim_x, m.F, m.x_w1, m.x_b1, hid);
+  CHECK_LAUNCH();
+  TRY(launch_gemm(m.precision, gemm_args(hid, m.F, m.x_w2, m.x_b2, m.F, c.at(c.pl.Ex), m.d, rows_x,
+                                         m.d, m.F, false), 1, c.st));
+  CHECK_LAUNCH();
+  const int rows_y = c.g.B * ey_rows;
+  if (rows_y > 0) {
+    Src3 ys{{ysrc, nullptr, nullptr}, {ey_rows, 0, 0}};
+    hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_y * m.F), dim3(256), 0, c.st, ys,
+                       ey_rows, c.g.B, m.dim_y, m.F, m.y_w1, m.y_b1, hid);
+    CHECK_LAUNCH();
+    TRY(launch_gemm(m.precision, gemm_args(hid, m.F, m.y_w2, m.y_b2, m.F, c.at(c.pl.Ey), m.d, rows_y,
+                                           m.d, m.F, false), 1, c.st));
+    CHECK_LAUNCH();
+  }
+  return ALINE_OK;
+}
+
+int do_assemble(const Ctx &c, int ey_rows, float *X) {
+  const size_t total = (size_t)c.g.B * c.g.N * c.m->d;
+  hipLaunchKernelGGL(assemble_kernel, grid1d(total), dim3(256), 0, c.st, c.g, c.m->d, c.at(c.pl.Ex),
+                     c.at(c.pl.Ey), ey_rows, c.m->theta_tokens, X);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+template <int HD>
+int launch_attention(const Ctx &c, const float *qkv, float *out, int max_keys) {
+  size_t smem = (size_t)max_keys * (2 * HD * sizeof(float) + sizeof(int));
+  if (smem > 160 * 1024 - 1024) return ALINE_EUNSUPPORTED;
+  if (smem > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<HD>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(attention_kernel<HD>, dim3(c.g.B, c.m->H), dim3(256), smem, c.st, c.g, c.m->d,
+                     qkv, out, max_keys);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// Encoder.forward: L post-norm layers (model/encoder.py:128-141)
+int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
+  const aline_model &m = *c.m;
+  const int M = c.g.B * c.g.N, d = m.d, F = m.F;
+  float *X = c.at(c.pl.X), *X1 = c.at(c.pl.X1), *QKV = c.at(c.pl.QKV), *A = c.at(c.pl.A),
+        *Tm = c.at(c.pl.Tm), *Hid = c.at(c.pl.Hid);
+  const float *cur = x_in;
+  const int hd = d / m.H;
+  for (int l = 0; l < m.L; ++l) {
+    TRY(launch_gemm(m.precision, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, 3 * d, M,
+                                           3 * d, d, false), 1, c.st));
+    CHECK_LAUNCH();
+    switch (hd) {
+      case 4: TRY(launch_attention<4>(c, QKV, A, max_keys)); break;
+      case 8: TRY(launch_attention<8>(c, QKV, A, max_keys)); break;
+      case 16: TRY(launch_attention<16>(c, QKV, A, max_keys)); break;
+      case 32: TRY(launch_attention<32>(c, QKV, A, max_keys)); break;
+      case 64: TRY(launch_attention<64>(c, QKV, A, max_keys)); break;
+      case 128: TRY(launch_attention<128>(c, QKV, A, max_keys)); break;
+      default: return ALINE_EUNSUPPORTED;
+    }
+    TRY(launch_gemm(m.precision, gemm_args(A, d, m.out_proj_w[l], m.out_proj_b[l], d, Tm, d, M, d, d,
+                                           false), 1, c.st));
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, c.st, cur, Tm,
+                       m.norm1_w[l], m.norm1_b[l], X1, (long)M, d);
+    CHECK_LAUNCH();
+    TRY(launch_gemm(m.precision, gemm_args(X1, d, m.lin1_w[l], m.lin1_b[l], d, Hid, F, M, F, d, true),
+                    1, c.st));
+    CHECK_LAUNCH();
+    TRY(launch_gemm(m.precision, gemm_args(Hid, F, m.lin2_w[l], m.lin2_b[l], F, Tm, d, M, d, F, false),
+                    1, c.st));
+    CHECK_LAUNCH();
+    float *dst = (l == m.L - 1 && x_out) ? x_out : X;
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, c.st, X1, Tm,
+                       m.norm2_w[l], m.norm2_b[l], dst, (long)M, d);
+    CHECK_LAUNCH();
+    cur = dst;
+  }
+  return ALINE_OK;
+}
+
+struct HeadIO {
+  const float *time_t;
+  const float *target_all;
+  SelectArgs sel;                         // g/F/hid/w2/b2 filled by do_head
+  float *post_mean, *post_std, *post_weight, *target_ll;   // [B*n_t(,C)]
+  float *postq_mean, *postq_std, *postq_weight;            // [B*nq_rows, C]; rows q_off.. of each episode
+  int q_off, q_rows;
+};
+
+// GMM head on `rows_per_ep` token rows starting at `row_off` of every episode in [b0, b0+nb)
+int do_gmm(const Ctx &c, const float *Z, int b0, int nb, int row_off, int rows_per_ep, float *mean,
+           float *sd, float *wgt, const float *value, float *ll) {
+  const aline_model &m = *c.m;
+  const int rows = nb * rows_per_ep;
+  if (rows <= 0) return ALINE_OK;
+  float *hid = c.at(c.pl.Hid);
+  GemmArgs a = gemm_args(Z + (size_t)b0 * c.g.N * m.d, m.d, nullptr, nullptr, m.d, hid, m.C * m.F, rows,
+                         m.F, m.d, true);
+  a.R_in = rows_per_ep; a.G_in = c.g.N; a.off_in = row_off;
+  a.col_per_group = m.F;
+  for (int k = 0; k < m.C; ++k) { a.W[k] = m.gmm_w1[k]; a.bias[k] = m.gmm_b1[k]; }
+  TRY(launch_gemm(m.precision, a, m.C, c.st));
+  CHECK_LAUNCH();
+  GmmFinishArgs f{};
+  f.hid = hid; f.rows = rows; f.C = m.C; f.F = m.F; f.std_min = m.std_min;
+  for (int k = 0; k < m.C; ++k) { f.w2[k] = m.gmm_w2[k]; f.b2[k] = m.gmm_b2[k]; }
+  const size_t o = (size_t)b0 * rows_per_ep;
+  f.mean = mean ? mean + o * m.C : nullptr;
+  f.std = sd ? sd + o * m.C : nullptr;
+  f.weight = wgt ? wgt + o * m.C : nullptr;
+  f.R_out = 1; f.G_out = 1; f.off_out = 0;
+  f.value = value ? value + o : nullptr;
+  f.ll = (ll && value) ? ll + o : nullptr;
+  hipLaunchKernelGGL(gmm_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, c.st, f);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// OutputHead.forward (model/head.py:319-393)
+int do_head(const Ctx &c, const float *Z, HeadIO io) {
+  const aline_model &m = *c.m;
+  const Geo &g = c.g;
+  const int n_t = g.n_td + g.n_th;
+  // acquisition MLP first layer on the P point rows of every episode
+  const float *w1 = m.acq_w1;
+  int ldw = m.d;
+  if (m.time_token) {
+    if (!io.time_t) return ALINE_EINVAL;
+    hipLaunchKernelGGL(pack_cols_kernel, grid1d((size_t)m.F * m.d), dim3(256), 0, c.st, m.acq_w1,
+                       m.d + 1, m.F, m.d, c.at(c.pl.Wacq));
+    CHECK_LAUNCH();
+    w1 = c.at(c.pl.Wacq);
+  }
+  float *hid = c.at(c.pl.Hid);
+  GemmArgs a = gemm_args(Z, m.d, w1, m.acq_b1, ldw, hid, m.F, g.B * g.P, m.F, m.d, true);
+  a.R_in = g.P; a.G_in = g.N; a.off_in = 0;
+  if (m.time_token) { a.tscalar = io.time_t; a.tcol = m.acq_w1 + m.d; a.tcol_stride = m.d + 1; }
+  TRY(launch_gemm(m.precision, a, 1, c.st));
+  CHECK_LAUNCH();
+  io.sel.g = g; io.sel.F = m.F; io.sel.hid = hid; io.sel.w2 = m.acq_w2; io.sel.b2 = m.acq_b2;
+  if (g.P > 1024) return ALINE_EUNSUPPORTED;
+  hipLaunchKernelGGL(acq_select_kernel, dim3(g.B), dim3(256), (size_t)g.P * 8, c.st, io.sel);
+  CHECK_LAUNCH();
+  // posterior over the targets (+ compute_ll)
+  if (io.post_mean || io.post_std || io.post_weight || io.target_ll)
+    TRY(do_gmm(c, Z, 0, g.B, g.P + 0, n_t, io.post_mean, io.post_std, io.post_weight, io.target_all,
+               io.target_ll));
+  // posterior_out_query (head.py:366): chunked over episodes to bound the hidden activations
+  if (io.postq_mean || io.postq_std || io.postq_weight) {
+    if (c.pl.qgmm_chunk <= 0) return ALINE_EWORKSPACE;
+    for (int b0 = 0; b0 < g.B; b0 += c.pl.qgmm_chunk) {
+      int nb = std::min(c.pl.qgmm_chunk, g.B - b0);
+      TRY(do_gmm(c, Z, b0, nb, io.q_off, io.q_rows, io.postq_mean, io.postq_std, io.postq_weight,
+                 nullptr, nullptr));
+    }
+  }
+  return ALINE_OK;
+}
+
+int step_geo(const aline_model &m, const aline_step &s, Geo &g) {
+  if (s.B <= 0 || s.n_ctx < 1 || s.n_query < 1 || s.n_target_data < 0) return ALINE_EINVAL;
+  if (m.embedding_type == ALINE_EMB_THETA && s.n_target_data != 0) return ALINE_EINVAL;
+  g.B = s.B; g.P = s.n_ctx + s.n_query; g.n_td = s.n_target_data; g.n_th = m.n_theta;
+  g.N = g.P + g.n_td + g.n_th; g.n_ctx = s.n_ctx; g.role = nullptr; g.tmask = s.target_mask;
+  return ALINE_OK;
+}
+
+bool wants_query_gmm(const aline_step &s) { return s.postq_mean || s.postq_std || s.postq_weight; }
+
+int step_ctx(const aline_model *m, const aline_step *s, void *ws, size_t ws_bytes, void *stream,
+             Ctx &c, int stages) {
+  if (!m || !s || !ws) return ALINE_EINVAL;
+  TRY(validate_model(*m, stages));
+  TRY(step_geo(*m, *s, c.g));
+  c.m = m;
+  c.pl = make_plan(*m, s->B, c.g.P, c.g.n_td, s->n_ctx, wants_query_gmm(*s));
+  if (ws_bytes < c.pl.total * sizeof(float)) return ALINE_EWORKSPACE;
+  c.ws = static_cast<float *>(ws);
+  c.st = static_cast<hipStream_t>(stream);
+  return ALINE_OK;
+}
+
+int step_embed(const Ctx &c, const aline_step &s, float *X) {
+  if (!s.context_x || !s.context_y || !s.query_x) return ALINE_EINVAL;
+  if (c.g.n_td > 0 && !s.target_x) return ALINE_EINVAL;
+  Src3 xs{{s.context_x, s.query_x, s.target_x}, {s.n_ctx, s.n_query, c.g.n_td}};
+  TRY(do_embed_points(c, xs, s.context_y, s.n_ctx));
+  return do_assemble(c, s.n_ctx, X);
+}
+
+HeadIO step_head_io(const aline_step &s, int n_ctx) {
+  HeadIO io{};
+  io.time_t = s.time_t;
+  io.target_all = s.target_all;
+  io.sel.mode = s.select_mode;
+  io.sel.uniform = s.uniform;
+  io.sel.forced = s.forced_idx; io.sel.forced_stride = 1;
+  io.sel.idx = s.idx; io.sel.idx_stride = 1;
+  io.sel.slot = nullptr; io.sel.slot_stride = 0;
+  io.sel.log_prob = s.log_prob; io.sel.lp_stride = 1;
+  io.sel.zt = s.zt; io.sel.zt_stride = s.n_query; io.sel.zt_width = s.n_query;
+  io.sel.role_out = nullptr;
+  io.post_mean = s.post_mean; io.post_std = s.post_std; io.post_weight = s.post_weight;
+  io.target_ll = s.target_ll;
+  io.postq_mean = s.postq_mean; io.postq_std = s.postq_std; io.postq_weight = s.postq_weight;
+  io.q_off = n_ctx; io.q_rows = s.n_query;
+  return io;
+}
+
+int check_select(int mode, const float *uniform, const int64_t *forced) {
+  if (mode == ALINE_SELECT_SAMPLE && !uniform) return ALINE_EINVAL;
+  if (mode == ALINE_SELECT_FORCED && !forced) return ALINE_EINVAL;
+  if (mode < 0 || mode > 2) return ALINE_EINVAL;
+  return ALINE_OK;
+}
+
+__global__ void set_scalar_kernel(float *p, float v) { p[0] = v; }
+
+}  // namespace
+
+extern "C" {
+
+int aline_abi_version(void) { return ALINE_ABI_VERSION; }
+
+const char *aline_error_string(int code) {
+  switch (code) {
+    case ALINE_OK: return "ok";
+    case ALINE_EINVAL: return "invalid argument";
+    case ALINE_EUNSUPPORTED: return "unsupported shape/configuration";
+    case ALINE_EWORKSPACE: return "workspace too small";
+    case ALINE_ELAUNCH: return "kernel launch failed";
+  }
+  return "unknown error";
+}
+
+size_t aline_step_workspace_bytes(const aline_model *m, const aline_step *s) {
+  if (!m || !s || validate_model(*m, 0) != 0) return 0;
+  Geo g;
+  if (step_geo(*m, *s, g) != 0) return 0;
+  return make_plan(*m, s->B, g.P, g.n_td, s->n_ctx, wants_query_gmm(*s)).total * sizeof(float);
+}
+
+int aline_embed_forward(const aline_model *m, const aline_step *s, void *ws, size_t ws_bytes,
+                        void *stream) {
+  Ctx c;
+  TRY(step_ctx(m, s, ws, ws_bytes, stream, c, ST_EMBED));
+  if (!s->embedding) return ALINE_EINVAL;
+  return step_embed(c, *s, s->embedding);
+}
+
+int aline_encoder_forward(const aline_model *m, const aline_step *s, const float *x_in, void *ws,
+                          size_t ws_bytes, void *stream) {
+  Ctx c;
+  TRY(step_ctx(m, s, ws, ws_bytes, stream, c, ST_ENC));
+  if (!x_in || !s->encoding) return ALINE_EINVAL;
+  return do_encoder(c, x_in, s->encoding, c.g.n_ctx + c.g.n_td + c.g.n_th);
+}
+
+int aline_head_forward(const aline_model *m, const aline_step *s, const float *z, void *ws,
+                       size_t ws_bytes, void *stream) {
+  Ctx c;
+  TRY(step_ctx(m, s, ws, ws_bytes, stream, c, ST_HEAD));
+  if (!z) return ALINE_EINVAL;
+  TRY(check_select(s->select_mode, s->uniform, s->forced_idx));
+  return do_head(c, z, step_head_io(*s, s->n_ctx));
+}
+
+int aline_step_forward(const aline_model *m, const aline_step *s, void *ws, size_t ws_bytes,
+                       void *stream) {
+  Ctx c;
+  TRY(step_ctx(m, s, ws, ws_bytes, stream, c, ST_ALL));
+  TRY(check_select(s->select_mode, s->uniform, s->forced_idx));
+  float *X0 = s->embedding ? s->embedding : c.at(c.pl.X);
+  TRY(step_embed(c, *s, X0));
+  TRY(do_encoder(c, X0, s->encoding, c.g.n_ctx + c.g.n_td + c.g.n_th));
+  const float *Z = s->encoding ? s->encoding : c.at(c.pl.X);
+  return do_head(c, Z, step_head_io(*s, s->n_ctx));
+}
+
+// ---- rollout (static slots) --------------------------------------------------------------------
+static int rollout_ctx(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
+                       void *stream, Ctx &c) {
+  if (!m || !r || !ws) return ALINE_EINVAL;
+  TRY(validate_model(*m));
+  if (r->B <= 0 || r->P < 2 || r->n_ctx0 < 1 || r->n_ctx0 >= r->P || r->T < 1 ||
+      r->n_ctx0 + r->T > r->P || !r->role || !r->point_x || !r->point_y)
+    return ALINE_EINVAL;
+  if (m->embedding_type == ALINE_EMB_THETA && r->n_target_data != 0) return ALINE_EINVAL;
+  if (r->n_target_data > 0 && !r->target_x) return ALINE_EINVAL;
+  c.g.B = r->B; c.g.P = r->P; c.g.n_td = r->n_target_data; c.g.n_th = m->n_theta;
+  c.g.N = c.g.P + c.g.n_td + c.g.n_th; c.g.n_ctx = r->n_ctx0; c.g.role = r->role;
+  c.g.tmask = r->target_mask;
+  c.m = m;
+  c.pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false);
+  if (ws_bytes < c.pl.total * sizeof(float)) return ALINE_EWORKSPACE;
+  c.ws = static_cast<float *>(ws);
+  c.st = static_cast<hipStream_t>(stream);
+  return ALINE_OK;
+}
+
+size_t aline_rollout_workspace_bytes(const aline_model *m, const aline_rollout *r) {
+  if (!m || !r || validate_model(*m, 0) != 0) return 0;
+  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false).total * sizeof(float);
+}
+
+int aline_rollout_init(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
+                       void *stream) {
+  Ctx c;
+  TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
+  hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B,
+                     r->P, r->n_ctx0);
+  CHECK_LAUNCH();
+  // x- and y-embeddings of every slot are step-invariant: compute them once per rollout
+  Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
+  return do_embed_points(c, xs, r->point_y, r->P);
+}
+
+int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void *ws, size_t ws_bytes,
+                       void *stream) {
+  Ctx c;
+  TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
+  if (t < 0 || t >= r->T) return ALINE_EINVAL;
+  TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
+  const int n_t = c.g.n_td + c.g.n_th;
+  c.g.n_ctx = r->n_ctx0 + t;
+  float *X = c.at(c.pl.X);
+  TRY(do_assemble(c, r->P, X));
+  TRY(do_encoder(c, X, nullptr, r->n_ctx0 + t + n_t));
+  HeadIO io{};
+  if (m->time_token) {
+    float *sc = c.at(c.pl.scalar);
+    const int TT = r->time_token_T > 0 ? r->time_token_T : r->T;
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, c.st, sc, (float)t / (float)TT);
+    CHECK_LAUNCH();
+    io.time_t = sc;
+  }
+  io.target_all = r->target_all;
+  io.sel.mode = r->select_mode;
+  io.sel.uniform = r->uniform ? r->uniform + (size_t)t * r->B : nullptr;
+  io.sel.forced = r->forced_idx ? r->forced_idx + t : nullptr; io.sel.forced_stride = r->T;
+  io.sel.idx = r->idx ? r->idx + t : nullptr; io.sel.idx_stride = r->T;
+  io.sel.slot = r->slot ? r->slot + t : nullptr; io.sel.slot_stride = r->T;
+  io.sel.log_prob = r->log_prob ? r->log_prob + t : nullptr; io.sel.lp_stride = r->T;
+  const int zw = r->P - r->n_ctx0;
+  io.sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; io.sel.zt_stride = zw; io.sel.zt_width = zw;
+  io.sel.role_out = r->role;
+  const size_t po = (size_t)t * r->B * n_t;
+  io.post_mean = r->post_mean ? r->post_mean + po * m->C : nullptr;
+  io.post_std = r->post_std ? r->post_std + po * m->C : nullptr;
+  io.post_weight = r->post_weight ? r->post_weight + po * m->C : nullptr;
+  io.target_ll = r->target_ll ? r->target_ll + po : nullptr;
+  return do_head(c, X, io);
+}
+
+int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
+                          void *stream) {
+  TRY(aline_rollout_init(m, r, ws, ws_bytes, stream));
+  for (int t = 0; t < r->T; ++t) TRY(aline_rollout_step(m, r, t, ws, ws_bytes, stream));
+  return ALINE_OK;
+}
+
+int aline_rollout_export(const aline_rollout *r, int n_ctx, float *context_x, float *context_y,
+                         float *query_x, float *query_y, int dim_x, int dim_y, void *stream) {
+  if (!r || !r->role || !context_x || !context_y || n_ctx < 1 || n_ctx > r->P) return ALINE_EINVAL;
+  hipLaunchKernelGGL(rollout_export_kernel, dim3(r->B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     r->role, r->point_x, r->point_y, r->B, r->P, n_ctx, dim_x, dim_y, context_x,
+                     context_y, query_x, query_y);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// ---- objectives ---------------------------------------------------------------------------------
+int aline_compute_ll(const float *value, const float *means, const float *stds, const float *weights,
+                     int64_t rows, int C, float *out, void *stream) {
+  if (!value || !means || !stds || !weights || !out || rows <= 0 || C <= 0) return ALINE_EINVAL;
+  hipLaunchKernelGGL(compute_ll_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), value, means, stds, weights, (long)rows, C, out);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+int aline_eig_location_step(const float *theta, const float *xi, const float *y, float *S, int64_t L1,
+                            int B, int K, int D, float noise_scale, float base_signal,
+                            float max_signal, void *stream) {
+  if (!theta || !xi || !y || !S || L1 < 2 || B <= 0 || K <= 0 || D <= 0 || D > 8) return ALINE_EINVAL;
+  const size_t total = (size_t)L1 * B;
+  unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(eig_location_step_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), theta, xi, y, S, (long)L1, B, K, D, noise_scale,
+                     base_signal, max_signal);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+int aline_eig_ces_step(const float *theta, const float *xi, const float *y, float *S, int64_t L1, int B,
+                       float noise_scale, float epsilon, int32_t *nan_flag, void *stream) {
+  if (!theta || !xi || !y || !S || L1 < 2 || B <= 0) return ALINE_EINVAL;
+  const size_t total = (size_t)L1 * B;
+  unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(eig_ces_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     theta, xi, y, S, (long)L1, B, noise_scale, epsilon, nan_flag);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+static const long kEigChunk = 4096;
+
+size_t aline_eig_finalize_workspace_bytes(int64_t L1, int B) {
+  long nchunk = (L1 - 1 + kEigChunk - 1) / kEigChunk;
+  return (size_t)std::max<long>(nchunk, 1) * B * 2 * sizeof(float);
+}
+
+int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc, void *ws,
+                       size_t ws_bytes, void *stream) {
+  if (!S || L1 < 2 || B <= 0 || !ws) return ALINE_EINVAL;
+  if (ws_bytes < aline_eig_finalize_workspace_bytes(L1, B)) return ALINE_EWORKSPACE;
+  const int nchunk = (int)((L1 - 1 + kEigChunk - 1) / kEigChunk);
+  float *part = static_cast<float *>(ws);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(eig_lse_partial_kernel, dim3(nchunk, (B + 63) / 64), dim3(256), 0, st, S, (long)L1,
+                     B, kEigChunk, part);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(eig_lse_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, st, S, part, nchunk,
+                     (long)L1, B, pce, nmc);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of libaline_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define WAVE 64  // CDNA wavefront width (hard-coded: no wave-size macro on gfx950)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// fp32 -> bf16 round-to-nearest-even (finite inputs; NaN propagation is not needed here because
+// every consumer accumulates in fp32 and NaNs in activations already mean a failed step).
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// split a = hi + lo (+ O(2^-17 |a|)) with hi, lo bf16  -- operand form of ALINE_PREC_BF16X3
+__device__ __forceinline__ void split_bf16(float a, unsigned short &hi, unsigned short &lo) {
+  hi = f2bf(a);
+  lo = f2bf(a - bf2f(hi));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) {
+  // torch.nn.functional.softplus(beta=1, threshold=20)
+  return x > 20.f ? x : log1pf(expf(x));
+}

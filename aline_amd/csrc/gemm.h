@@ -1,0 +1,211 @@
+// Token-wise linear layers:  Y[m, n] = act( sum_k X[m, k] * W[n, k] + bias[n] (+ t * wcol[n]) )
+//
+// "NT" GEMM on the matrix cores: both operands are K-contiguous, which is exactly PyTorch's
+// nn.Linear layout ([out, in] row-major), so weights are consumed where the optimiser keeps them.
+// One workgroup = 4 waves (256 threads) computes a BM x BN tile with 16x16 MFMA fragments;
+// K is walked in steps of 32 through LDS.  Three arithmetic policies (include/aline_hip.h):
+//   F32    v_mfma_f32_16x16x4_f32   (exact fp32, 8 MFMAs per 32-deep step)
+//   BF16   v_mfma_f32_16x16x32_bf16 (1 MFMA per step)
+//   BF16X3 split operands hi+lo, 3 MFMAs per step (hi*hi + hi*lo + lo*hi), ~2^-16 relative error
+// Row maps let a launch read/write a sub-range of each episode's token rows (e.g. only the
+// target rows) without a gather pass:  row(m) = (m / R) * G + off + (m % R).
+// blockIdx.z selects a weight group (the C independent GMM heads run as one grouped launch).
+#pragma once
+#include "common.h"
+
+#define GEMM_MAX_GROUPS 16
+
+struct GemmArgs {
+  const float *X; int ldx; int R_in, G_in, off_in;
+  const float *W[GEMM_MAX_GROUPS]; const float *bias[GEMM_MAX_GROUPS]; int ldw;
+  float *Y; int ldy; int R_out, G_out, off_out; int col_per_group;
+  int M, N, K; int relu;
+  const float *tscalar; const float *tcol; int tcol_stride;  // optional rank-1 term (time token)
+};
+
+constexpr int GEMM_BK = 32;
+
+template <int PREC> struct LdsTile;  // storage of a [ROWS x 32] operand tile in LDS
+template <> struct LdsTile<0> { static constexpr int LD = 34; using T = float; static constexpr int PLANES = 1; };
+template <> struct LdsTile<1> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 1; };
+template <> struct LdsTile<2> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 2; };
+
+// store 4 consecutive k-values of one tile row
+template <int PREC>
+__device__ __forceinline__ void lds_store4(typename LdsTile<PREC>::T *base, int plane_elems, int row,
+                                           int k, float4 v) {
+  constexpr int LD = LdsTile<PREC>::LD;
+  if constexpr (PREC == 0) {
+    float *p = base + row * LD + k;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+  } else if constexpr (PREC == 1) {
+    u16x4 h = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+    *reinterpret_cast<u16x4 *>(base + row * LD + k) = h;
+  } else {
+    u16x4 h, l;
+    unsigned short a, b;
+    split_bf16(v.x, a, b); h[0] = a; l[0] = b;
+    split_bf16(v.y, a, b); h[1] = a; l[1] = b;
+    split_bf16(v.z, a, b); h[2] = a; l[2] = b;
+    split_bf16(v.w, a, b); h[3] = a; l[3] = b;
+    *reinterpret_cast<u16x4 *>(base + row * LD + k) = h;
+    *reinterpret_cast<u16x4 *>(base + plane_elems + row * LD + k) = l;
+  }
+}
+
+template <int PREC, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+  using LT = LdsTile<PREC>;
+  using T = typename LT::T;
+  constexpr int LD = LT::LD;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int A_ELEMS = BM * LD, B_ELEMS = BN * LD;
+  __shared__ __attribute__((aligned(16))) T smem[(A_ELEMS + B_ELEMS) * LT::PLANES];
+  T *As = smem;
+  T *Bs = smem + A_ELEMS * LT::PLANES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, grp = blockIdx.z;
+  const float *__restrict__ W = a.W[grp];
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-thread staging coordinates: 8 float4 per 32-wide row
+  constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
+  const float *arow[A_IT];
+  bool aok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int idx = tid + i * 256, row = idx >> 3;
+    int m = m0 + row;
+    aok[i] = m < a.M;
+    int mm = aok[i] ? m : 0;
+    long src = (long)(mm / a.R_in) * a.G_in + a.off_in + (mm % a.R_in);
+    arow[i] = a.X + src * a.ldx + (idx & 7) * 4;
+  }
+
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int k0 = 0; k0 < a.K; k0 += GEMM_BK) {
+    float4 av[A_IT], bv[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      av[i] = aok[i] ? *reinterpret_cast<const float4 *>(arow[i] + k0) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int idx = tid + i * 256, row = idx >> 3;
+      bv[i] = *reinterpret_cast<const float4 *>(W + (long)(n0 + row) * a.ldw + k0 + (idx & 7) * 4);
+    }
+    __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int idx = tid + i * 256;
+      lds_store4<PREC>(As, A_ELEMS, idx >> 3, (idx & 7) * 4, av[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int idx = tid + i * 256;
+      lds_store4<PREC>(Bs, B_ELEMS, idx >> 3, (idx & 7) * 4, bv[i]);
+    }
+    __syncthreads();
+
+    if constexpr (PREC == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = As[(wm * WM + i * 16 + fr) * LD + ks * 4 + fg];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = Bs[(wn * WN + j * 16 + fr) * LD + ks * 4 + fg];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      bf16x8 ah[TM], bh[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        ah[i] = *reinterpret_cast<const bf16x8 *>(As + (wm * WM + i * 16 + fr) * LD + fg * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bh[j] = *reinterpret_cast<const bf16x8 *>(Bs + (wn * WN + j * 16 + fr) * LD + fg * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      if constexpr (PREC == 2) {
+        bf16x8 al[TM], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          al[i] = *reinterpret_cast<const bf16x8 *>(As + A_ELEMS + (wm * WM + i * 16 + fr) * LD + fg * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bl[j] = *reinterpret_cast<const bf16x8 *>(Bs + B_ELEMS + (wn * WN + j * 16 + fr) * LD + fg * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // epilogue: C/D fragment layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  const float *bias = a.bias[grp];
+  const float tsc = a.tscalar ? a.tscalar[0] : 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + fr;
+    float add = bias ? bias[n] : 0.f;
+    if (a.tscalar) add += tsc * a.tcol[(long)n * a.tcol_stride];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * WM + i * 16 + fg * 4 + r;
+        if (m < a.M) {
+          float v = acc[i][j][r] + add;
+          if (a.relu) v = fmaxf(v, 0.f);
+          long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
+          a.Y[dst * a.ldy + grp * a.col_per_group + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int PREC>
+static int launch_gemm_prec(const GemmArgs &a, int groups, hipStream_t st) {
+  if (a.K % GEMM_BK != 0 || a.N % 32 != 0 || a.M <= 0) return -2;
+  dim3 block(256);
+  if (a.N % 128 == 0) {
+    dim3 grid((a.M + 127) / 128, a.N / 128, groups);
+    hipLaunchKernelGGL((gemm_nt_kernel<PREC, 128, 128, 2, 2>), grid, block, 0, st, a);
+  } else if (a.N % 64 == 0) {
+    dim3 grid((a.M + 127) / 128, a.N / 64, groups);
+    hipLaunchKernelGGL((gemm_nt_kernel<PREC, 128, 64, 4, 1>), grid, block, 0, st, a);
+  } else {
+    dim3 grid((a.M + 127) / 128, a.N / 32, groups);
+    hipLaunchKernelGGL((gemm_nt_kernel<PREC, 128, 32, 4, 1>), grid, block, 0, st, a);
+  }
+  return 0;
+}
+
+static int launch_gemm(int prec, const GemmArgs &a, int groups, hipStream_t st) {
+  switch (prec) {
+    case 0: return launch_gemm_prec<0>(a, groups, st);
+    case 1: return launch_gemm_prec<1>(a, groups, st);
+    case 2: return launch_gemm_prec<2>(a, groups, st);
+  }
+  return -1;
+}

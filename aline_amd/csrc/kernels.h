@@ -1,0 +1,439 @@
+// Non-GEMM kernels of one design step: point-embedder first layer, token assembly, masked
+// set-attention, residual+LayerNorm, acquisition softmax + design selection (+ role update),
+// GMM head epilogue (+ log-likelihood).  All fp32.
+#pragma once
+#include "common.h"
+
+// Token geometry of one step.  Per episode the rows are
+//   [ P candidate points | n_td target-data rows | n_th theta-token rows ]   (N rows)
+// A point is a context point when is_ctx(b, p); otherwise it is a (remaining) query.
+// Step API: the first n_ctx points are the context (role == nullptr).  Rollout API: role[b, p] > 0.
+struct Geo {
+  int B, P, n_td, n_th, N;
+  int n_ctx;             // static context count (step API) / current count (rollout, informational)
+  const int *role;       // [B, P] or nullptr
+  const uint8_t *tmask;  // [n_td + n_th] or nullptr (= every target is visible to the queries)
+};
+
+__device__ __forceinline__ bool is_ctx(const Geo &g, int b, int p) {
+  return g.role ? g.role[(long)b * g.P + p] > 0 : p < g.n_ctx;
+}
+
+// ---- G1a: first layer of the point embedder (model/embedder.py:47-57), K = dim_x / dim_y is
+// tiny so this is FMA work:  hid[r, f] = relu(b1[f] + sum_k in[r, k] * w1[f, k]).
+// Rows come from up to three source tensors laid end to end per episode (ctx | query | target_x).
+struct Src3 { const float *p[3]; int n[3]; };
+__global__ void embed_hidden_kernel(Src3 src, int rows_per_ep, int B, int K, int F,
+                                    const float *__restrict__ w1, const float *__restrict__ b1,
+                                    float *__restrict__ hid) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * rows_per_ep * F;
+  if (i >= total) return;
+  int f = i % F;
+  long r = i / F;
+  int b = r / rows_per_ep, p = r % rows_per_ep;
+  const float *x;
+  if (p < src.n[0]) x = src.p[0] + ((long)b * src.n[0] + p) * K;
+  else if (p < src.n[0] + src.n[1]) x = src.p[1] + ((long)b * src.n[1] + (p - src.n[0])) * K;
+  else x = src.p[2] + ((long)b * src.n[2] + (p - src.n[0] - src.n[1])) * K;
+  float acc = b1[f];
+  for (int k = 0; k < K; ++k) acc = fmaf(x[k], w1[f * K + k], acc);
+  hid[i] = fmaxf(acc, 0.f);
+}
+
+// ---- G1b: token assembly (embedder.py:156-166 / :196-212):
+// X[b, row] = Ex[b, row] (+ Ey[b, p] on context rows); theta rows = theta_tokens.
+__global__ void assemble_kernel(Geo g, int d, const float *__restrict__ Ex, const float *__restrict__ Ey,
+                                int ey_rows, const float *__restrict__ theta_tokens,
+                                float *__restrict__ X) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)g.B * g.N * d;
+  if (i >= total) return;
+  int c = i % d;
+  long r = i / d;
+  int b = r / g.N, row = r % g.N;
+  float v;
+  if (row < g.P + g.n_td) {
+    v = Ex[((long)b * (g.P + g.n_td) + row) * d + c];
+    if (row < g.P && is_ctx(g, b, row)) v += Ey[((long)b * ey_rows + row) * d + c];
+  } else {
+    v = theta_tokens[(row - g.P - g.n_td) * d + c];
+  }
+  X[i] = v;
+}
+
+// ---- G2-G4: masked set-attention (model/encoder.py:8-46 and :83-126 without materialising the
+// [N, N] mask).  Keys = context rows, plus (for query rows only) the selected target rows.
+// One workgroup per (episode, head): K_h, V_h of the key rows are staged in LDS once, every
+// thread then owns token rows and runs an online softmax over the keys.
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const float *__restrict__ QKV,
+                                                        float *__restrict__ Aout, int max_keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *Ks = reinterpret_cast<float *>(smem_raw);          // [max_keys][HD]
+  float *Vs = Ks + (size_t)max_keys * HD;                   // [max_keys][HD]
+  int *keyrow = reinterpret_cast<int *>(Vs + (size_t)max_keys * HD);   // [max_keys]
+  __shared__ int wave_cnt[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_t = g.n_td + g.n_th;
+  // ordered compaction of the key rows: context points in slot order, then selected targets
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < g.N; c0 += 256) {
+    int row = c0 + tid;
+    bool key = false;
+    if (row < g.P) key = is_ctx(g, b, row);
+    unsigned long long bal = __ballot(key);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (key) keyrow[off + __popcll(bal & ((1ull << lane) - 1ull))] = row;
+    __syncthreads();
+    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int n_ck = s_base;   // context keys
+  __syncthreads();
+  if (tid == 0) {
+    int n = n_ck;
+    for (int j = 0; j < n_t; ++j)
+      if (!g.tmask || g.tmask[j]) keyrow[n++] = g.P + j;
+    s_base = n;
+  }
+  __syncthreads();
+  const int n_ak = s_base;   // all keys (queries see these)
+  const long ep = (long)b * g.N;
+  for (int i = tid; i < n_ak * HD; i += 256) {
+    int j = i / HD, c = i % HD;
+    const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
+    Ks[j * HD + c] = src[d];
+    Vs[j * HD + c] = src[2 * d];
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)HD);
+  for (int row = tid; row < g.N; row += 256) {
+    const bool isq = row < g.P && !is_ctx(g, b, row);
+    const int nk = isq ? n_ak : n_ck;
+    float q[HD], o[HD];
+    const float *qp = QKV + (ep + row) * 3 * d + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { q[c] = qp[c] * scale; o[c] = 0.f; }
+    float mx = -INFINITY, l = 0.f;
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j * HD + c], s);
+      float mn = fmaxf(mx, s);
+      float corr = __expf(mx - mn), p = __expf(s - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(p, Vs[j * HD + c], o[c] * corr);
+      mx = mn;
+    }
+    float inv = 1.f / l;
+    float *op = Aout + (ep + row) * d + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) op[c] = o[c] * inv;
+  }
+}
+
+// ---- G5/G6 epilogue: out = LayerNorm(a + b) * w + bias  (post-norm, eps 1e-5).  One wave / row.
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ a,
+                                                            const float *__restrict__ b2,
+                                                            const float *__restrict__ w,
+                                                            const float *__restrict__ bias,
+                                                            float *__restrict__ out, long rows, int d) {
+  const int lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *pa = a + row * d, *pb = b2 + row * d;
+  float v[8];  // d <= 512
+  float s = 0.f;
+  int n = 0;
+  for (int c = lane; c < d; c += 64, ++n) { v[n] = pa[c] + pb[c]; s += v[n]; }
+  const float mean = wave_sum(s) / d;
+  float ss = 0.f;
+  for (int i = 0; i < n; ++i) { float t = v[i] - mean; ss += t * t; }
+  const float rstd = rsqrtf(wave_sum(ss) / d + 1e-5f);
+  n = 0;
+  for (int c = lane; c < d; c += 64, ++n) out[row * d + c] = (v[n] - mean) * rstd * w[c] + bias[c];
+}
+
+// ---- G7/G8 (+G11): acquisition softmax over the remaining queries, design selection, and (rollout
+// API) the role update that replaces Task.update_batch (tasks/base_task.py:133-154).
+// hid [B*P, F] = relu(z_q W1^T + b1) from the GEMM; logits = hid . w2 + b2 (model/head.py:27-33).
+// One workgroup per episode.  zt / idx use the reference's *compacted* query numbering
+// (order-preserving boolean-mask compaction, base_task.py:114-117).
+struct SelectArgs {
+  Geo g;
+  int F;
+  const float *hid, *w2, *b2;
+  int mode;                      // ALINE_SELECT_*
+  const float *uniform;          // [B]
+  const int64_t *forced; int forced_stride;   // forced[b * stride]
+  int64_t *idx; int idx_stride;  // idx[b * stride]
+  int *slot; int slot_stride;    // chosen slot (may be null)
+  float *log_prob; int lp_stride;
+  float *zt; int zt_stride;      // zt[b * stride + i], zero padded up to zt_width
+  int zt_width;
+  int *role_out;                 // rollout: role[b, chosen] = n_ctx_now + 1
+};
+
+__global__ __launch_bounds__(256) void acq_select_kernel(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *logit = reinterpret_cast<float *>(smem_raw);   // [P]
+  int *qslot = reinterpret_cast<int *>(logit + a.g.P);  // [P] compacted -> slot
+  __shared__ float red[4];
+  __shared__ int wave_cnt[4];
+  __shared__ int s_base, s_choice;
+  __shared__ float s_val;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = a.g.P;
+  // logits: one wave per row, lanes over F
+  for (int p = wave; p < P; p += 4) {
+    const float *hp = a.hid + ((long)b * P + p) * a.F;
+    float s = 0.f;
+    for (int f = lane; f < a.F; f += 64) s = fmaf(hp[f], a.w2[f], s);
+    s = wave_sum(s);
+    if (lane == 0) logit[p] = s + a.b2[0];
+  }
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  // ordered compaction of the remaining queries
+  for (int c0 = 0; c0 < P; c0 += 256) {
+    int p = c0 + tid;
+    bool isq = p < P && !is_ctx(a.g, b, p);
+    unsigned long long bal = __ballot(isq);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (isq) qslot[off + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+    __syncthreads();
+    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int nq = s_base;
+  // softmax over the nq remaining queries (nn.Softmax(dim=-1), head.py:32)
+  float mx = -INFINITY;
+  for (int i = tid; i < nq; i += 256) mx = fmaxf(mx, logit[qslot[i]]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = tid; i < nq; i += 256) sum += __expf(logit[qslot[i]] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.f / sum;
+  __syncthreads();
+  // probabilities back into logit[] (compacted order) and out to zt
+  float *prob = logit;  // reuse: write compacted probs after everyone has read their logits
+  float pv[4];          // P <= 1024
+  int cnt = 0;
+  for (int i = tid; i < nq; i += 256) pv[cnt++] = __expf(logit[qslot[i]] - mx) * inv;
+  __syncthreads();
+  cnt = 0;
+  for (int i = tid; i < nq; i += 256) prob[i] = pv[cnt++];
+  __syncthreads();
+  if (a.zt)
+    for (int i = tid; i < a.zt_width; i += 256)
+      a.zt[(long)b * a.zt_stride + i] = i < nq ? prob[i] : 0.f;
+  // selection (single wave: nq <= 1024 keeps this short and deterministic)
+  if (wave == 0) {
+    int choice = 0;
+    float val = 0.f;
+    if (a.mode == 0) {          // argmax, first maximal index (torch.max semantics)
+      float best = -1.f; int bi = 0;
+      for (int i = lane; i < nq; i += 64) if (prob[i] > best) { best = prob[i]; bi = i; }
+      for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      choice = bi; val = best;
+    } else if (a.mode == 2) {
+      choice = (int)a.forced[(long)b * a.forced_stride];
+      choice = min(max(choice, 0), nq - 1);
+      val = prob[choice];
+    } else {                    // inverse CDF of Categorical(probs = zt / sum zt)
+      float tot = 0.f;
+      for (int i = lane; i < nq; i += 64) tot += prob[i];
+      tot = wave_sum(tot);
+      const float u = a.uniform[b] * tot;
+      // serial scan by chunks of 64 with a wave prefix sum
+      float run = 0.f; int found = nq - 1; bool done = false;
+      for (int c0 = 0; c0 < nq && !done; c0 += 64) {
+        int i = c0 + lane;
+        float v = i < nq ? prob[i] : 0.f, incl = v;
+        for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        bool hit = i < nq && (run + incl) > u;
+        unsigned long long bal = __ballot(hit);
+        if (bal) { found = c0 + __ffsll((long long)bal) - 1; done = true; }
+        run += __shfl(incl, 63, 64);
+      }
+      choice = found; val = prob[choice];
+      // Categorical(probs).log_prob uses probs / probs.sum() clamped to [eps, 1-eps]
+      val = val / tot;
+    }
+    if (a.mode == 2) {
+      float tot = 0.f;
+      for (int i = lane; i < nq; i += 64) tot += prob[i];
+      tot = wave_sum(tot);
+      val = val / tot;
+    }
+    if (lane == 0) { s_choice = choice; s_val = val; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int choice = s_choice;
+    float v = s_val;
+    if (a.mode != 0) v = fminf(fmaxf(v, 1.1920929e-07f), 1.f - 1.1920929e-07f);
+    if (a.idx) a.idx[(long)b * a.idx_stride] = choice;
+    if (a.log_prob) a.log_prob[(long)b * a.lp_stride] = logf(v);
+    const int sl = qslot[choice];
+    if (a.slot) a.slot[(long)b * a.slot_stride] = sl;
+    if (a.role_out) a.role_out[(long)b * P + sl] = (P - nq) + 1;
+  }
+}
+
+// ---- G9/G10 epilogue: second layer of the C GMM heads + parameter maps + optional log-lik.
+// hid [rows, C*F] (grouped GEMM output, ReLU applied).  Output raw[c][j] = hid_c . w2_c[j] + b2_c[j];
+// after the reference's stack/movedim/flatten/chunk (head.py:264-265) with dim_y == 1:
+// mean_c = raw[c][0], std_c = softplus(raw[c][1]) + std_min, weight = softmax_c(raw[c][2]).
+// One wave per row.
+struct GmmFinishArgs {
+  const float *hid; long rows; int C, F;
+  const float *w2[16]; const float *b2[16];
+  float std_min;
+  float *mean, *std, *weight;            // [rows, C] (row-mapped)
+  int R_out, G_out, off_out;             // output row map (rows per episode etc.)
+  const float *value; float *ll;         // optional compute_ll, same row map
+};
+
+__global__ __launch_bounds__(256) void gmm_finish_kernel(GmmFinishArgs a) {
+  const int lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;   // lane c holds component c's three outputs
+  for (int c = 0; c < a.C; ++c) {
+    const float *hp = a.hid + (row * a.C + c) * a.F;
+    const float *w = a.w2[c];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int f = lane; f < a.F; f += 64) {
+      float hv = hp[f];
+      s0 = fmaf(hv, w[f], s0);
+      s1 = fmaf(hv, w[a.F + f], s1);
+      s2 = fmaf(hv, w[2 * a.F + f], s2);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == c) { raw0 = s0 + a.b2[c][0]; raw1 = s1 + a.b2[c][1]; raw2 = s2 + a.b2[c][2]; }
+  }
+  const bool act = lane < a.C;
+  float mean = raw0, sd = softplus_f(raw1) + a.std_min;
+  float mx = wave_max(act ? raw2 : -INFINITY);
+  float e = act ? __expf(raw2 - mx) : 0.f;
+  float wgt = e / wave_sum(e);
+  long orow = (row / a.R_out) * a.G_out + a.off_out + (row % a.R_out);
+  if (act) {
+    if (a.mean) a.mean[orow * a.C + lane] = mean;
+    if (a.std) a.std[orow * a.C + lane] = sd;
+    if (a.weight) a.weight[orow * a.C + lane] = wgt;
+  }
+  if (a.ll) {
+    // compute_ll (utils/eval.py:200-207): logsumexp_c( Normal(mean, sd).log_prob(v) + log w )
+    float v = a.value[orow];
+    float z = (v - mean) / sd;
+    float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
+    float m2 = wave_max(lp);
+    float se = wave_sum(act ? __expf(lp - m2) : 0.f);
+    if (lane == 0) a.ll[orow] = m2 + logf(se);
+  }
+}
+
+// compute_ll on caller-provided GMM parameters (utils/eval.py:200-207).  One wave per row.
+__global__ __launch_bounds__(256) void compute_ll_kernel(const float *__restrict__ value,
+                                                         const float *__restrict__ means,
+                                                         const float *__restrict__ stds,
+                                                         const float *__restrict__ weights, long rows,
+                                                         int C, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float m2 = -INFINITY, se = 0.f;
+  const float v = value[row];
+  float lp = -INFINITY;
+  // C <= 64 in practice; loop for generality with an online logsumexp across chunks
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    int c = c0 + lane;
+    lp = -INFINITY;
+    if (c < C) {
+      float mu = means[row * C + c], sd = stds[row * C + c], w = weights[row * C + c];
+      float z = (v - mu) / sd;
+      lp = -0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(w);
+    }
+    float cm = wave_max(lp);
+    float mn = fmaxf(m2, cm);
+    float cs = wave_sum(c < C ? __expf(lp - mn) : 0.f);
+    se = se * __expf(m2 - mn) + cs;
+    m2 = mn;
+  }
+  if (lane == 0) out[row] = m2 + logf(se);
+}
+
+// rollout helpers -------------------------------------------------------------------------------
+__global__ void role_init_kernel(int *role, int B, int P, int n_ctx0) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * P) return;
+  int p = i % P;
+  role[i] = p < n_ctx0 ? p + 1 : 0;
+}
+
+// Task.update_batch view of the static-slot state (tasks/base_task.py:133-154): context in order of
+// entry, queries in slot order.  One workgroup per episode.
+__global__ __launch_bounds__(256) void rollout_export_kernel(const int *role, const float *px,
+                                                             const float *py, int B, int P, int n_ctx,
+                                                             int dx, int dy, float *cx, float *cy,
+                                                             float *qx, float *qy) {
+  __shared__ int wave_cnt[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const int nq = P - n_ctx;
+  for (int c0 = 0; c0 < P; c0 += 256) {
+    int p = c0 + tid;
+    int r = p < P ? role[(long)b * P + p] : -1;
+    if (r > 0 && r <= n_ctx) {
+      for (int k = 0; k < dx; ++k) cx[((long)b * n_ctx + r - 1) * dx + k] = px[((long)b * P + p) * dx + k];
+      for (int k = 0; k < dy; ++k) cy[((long)b * n_ctx + r - 1) * dy + k] = py[((long)b * P + p) * dy + k];
+    }
+    bool isq = r == 0;
+    unsigned long long bal = __ballot(isq);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (isq) {
+      int i = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (i < nq) {
+        if (qx) for (int k = 0; k < dx; ++k) qx[((long)b * nq + i) * dx + k] = px[((long)b * P + p) * dx + k];
+        if (qy) for (int k = 0; k < dy; ++k) qy[((long)b * nq + i) * dy + k] = py[((long)b * P + p) * dy + k];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+// strided 2-D copy (packs the first `cols` columns of a [rows, ld] matrix)
+__global__ void pack_cols_kernel(const float *src, int ld, int rows, int cols, float *dst) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  dst[i] = src[(i / cols) * ld + (i % cols)];
+}

@@ -1,0 +1,152 @@
+"""T-step acquisition loop (reference train_aline.py:80-110 / utils/eval.py:24-30) on the
+shape-static slot layout of the C ABI (`aline_rollout_*`): the whole loop -- forward, design
+selection, context/query update, GMM log-likelihood -- stays on the device with no host sync, and
+can be captured in one HIP graph."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .model import _native
+
+
+class Rollout:
+    """One batch of episodes rolled out for T design steps.
+
+    select: 'argmax' (eval, head.py:355-358), 'sample' (train, head.py:350-354; randoms from
+    `uniform` [T, B] or torch.rand), or 'forced' with `forced_idx` [B, T] (teacher forcing).
+    """
+
+    def __init__(self, model, batch, T, select="argmax", forced_idx=None, uniform=None,
+                 time_token_T=0, keep_zt=False, keep_posterior=True):
+        self.model = model
+        self.m = model.model_struct()
+        g = _native._get
+        cx, cy = _lib.f32(g(batch, "context_x")), _lib.f32(g(batch, "context_y"))
+        qx, qy = _lib.f32(g(batch, "query_x")), _lib.f32(g(batch, "query_y"))
+        if not cx.is_cuda:
+            raise RuntimeError("aline_amd: batch tensors must live on the GPU (no CPU fallback)")
+        dev = self.device = cx.device
+        B, n_c0, n_q0 = cx.shape[0], cx.shape[1], qx.shape[1]
+        self.B, self.n_c0, self.n_q0, self.T = B, n_c0, n_q0, T
+        self.P = P = n_c0 + n_q0
+        self.px = torch.cat([cx, qx], dim=1).contiguous()
+        self.py = torch.cat([cy, qy], dim=1).contiguous()
+        ta = g(batch, "target_all")
+        self.n_t = n_t = ta.shape[1]
+        self.target_all = _lib.f32(ta.reshape(B, n_t))
+        n_td = n_t - self.m.n_theta
+        tx = g(batch, "target_x")
+        self.tx = _lib.f32(tx) if (tx is not None and n_td > 0) else None
+        tm = g(batch, "target_mask")
+        self.tmask = None if tm is None else tm.to(dev, torch.uint8).contiguous()
+        C_ = self.m.C
+        self.role = torch.empty(B, P, dtype=torch.int32, device=dev)
+        self.idx = torch.empty(B, T, dtype=torch.int64, device=dev)
+        self.slot = torch.empty(B, T, dtype=torch.int32, device=dev)
+        self.log_prob = torch.empty(B, T, device=dev)
+        self.target_ll = torch.empty(T, B, n_t, device=dev)
+        self.zt = torch.empty(T, B, n_q0, device=dev) if keep_zt else None
+        if keep_posterior:
+            self.post_mean = torch.empty(T, B, n_t, C_, device=dev)
+            self.post_std = torch.empty_like(self.post_mean)
+            self.post_weight = torch.empty_like(self.post_mean)
+        else:
+            self.post_mean = self.post_std = self.post_weight = None
+        r = self.r = _lib.AlineRollout()
+        r.B, r.P, r.n_ctx0, r.n_target_data, r.T = B, P, n_c0, n_td, T
+        r.point_x, r.point_y, r.role = self.px.data_ptr(), self.py.data_ptr(), self.role.data_ptr()
+        r.target_x = _lib.ptr(self.tx)
+        r.target_all = self.target_all.data_ptr()
+        r.target_mask = _lib.ptr(self.tmask)
+        r.select_mode = {"argmax": _lib.SELECT_ARGMAX, "sample": _lib.SELECT_SAMPLE,
+                         "forced": _lib.SELECT_FORCED}[select]
+        self.uniform = self.forced = None
+        if select == "sample":
+            self.uniform = (uniform if uniform is not None else torch.rand(T, B, device=dev))
+            self.uniform = self.uniform.to(dev, torch.float32).contiguous()
+            r.uniform = self.uniform.data_ptr()
+        if select == "forced":
+            self.forced = forced_idx.to(dev, torch.int64).contiguous()
+            assert self.forced.shape == (B, T)
+            r.forced_idx = self.forced.data_ptr()
+        r.time_token_T = time_token_T
+        r.idx, r.slot, r.log_prob = self.idx.data_ptr(), self.slot.data_ptr(), self.log_prob.data_ptr()
+        r.target_ll = self.target_ll.data_ptr()
+        r.zt = _lib.ptr(self.zt)
+        r.post_mean, r.post_std, r.post_weight = (_lib.ptr(self.post_mean), _lib.ptr(self.post_std),
+                                                  _lib.ptr(self.post_weight))
+        nbytes = _lib.lib.aline_rollout_workspace_bytes(C.byref(self.m), C.byref(r))
+        if nbytes == 0:
+            raise RuntimeError("aline_amd: unsupported model/batch configuration")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._graph = None
+
+    # ------------------------------------------------------------------------------------------
+    def refresh_uniform(self):
+        if self.uniform is not None:
+            self.uniform.uniform_()
+
+    def _enqueue(self):
+        st = _lib.stream_ptr(self.device)
+        _lib.check(_lib.lib.aline_rollout_forward(C.byref(self.m), C.byref(self.r), self.ws.data_ptr(),
+                                                  self.ws.numel(), st), "rollout_forward")
+
+    def run(self):
+        """init + T steps enqueued on the current stream (no host synchronisation)."""
+        self._enqueue()
+        return self
+
+    def capture(self):
+        """Capture init + T steps into one HIP graph (hipGraph through torch's stream capture:
+        the C ABI allocates nothing and only enqueues on the capturing stream)."""
+        self._enqueue()                       # warm-up outside capture (function attributes etc.)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue()
+        self._graph = g
+        return self
+
+    def replay(self):
+        self._graph.replay()
+        return self
+
+    def step(self, t):
+        st = _lib.stream_ptr(self.device)
+        if t == 0:
+            _lib.check(_lib.lib.aline_rollout_init(C.byref(self.m), C.byref(self.r), self.ws.data_ptr(),
+                                                   self.ws.numel(), st), "rollout_init")
+        _lib.check(_lib.lib.aline_rollout_step(C.byref(self.m), C.byref(self.r), t, self.ws.data_ptr(),
+                                               self.ws.numel(), st), "rollout_step")
+
+    def export_context(self, n_ctx=None):
+        """context_x / context_y in order of acquisition, as Task.update_batch would have built them
+        (tasks/base_task.py:133-154)."""
+        n_ctx = self.n_c0 + self.T if n_ctx is None else n_ctx
+        dx, dy = self.px.shape[-1], self.py.shape[-1]
+        cx = torch.empty(self.B, n_ctx, dx, device=self.device)
+        cy = torch.empty(self.B, n_ctx, dy, device=self.device)
+        _lib.check(_lib.lib.aline_rollout_export(C.byref(self.r), n_ctx, cx.data_ptr(), cy.data_ptr(),
+                                                 None, None, dx, dy, _lib.stream_ptr(self.device)),
+                   "rollout_export")
+        return cx, cy
+
+    # train_aline.py:97-110 reductions on the per-step log-likelihoods (tiny, torch on device)
+    def nlls(self, embedding_type, mask_type="all"):
+        ll = self.target_ll                                      # [T, B, n_t]
+        n_th = self.m.n_theta
+        if self.tmask is not None:
+            sel = torch.where(self.tmask.bool())[0]
+            masked = ll[:, :, sel]
+        else:
+            masked = ll
+        if embedding_type == "mix" and mask_type == "all":
+            nll_q = -(masked[..., :-n_th].mean(-1) + masked[..., -n_th:].mean(-1))
+        else:
+            nll_q = -masked.mean(-1)
+        if embedding_type == "mix":
+            nll = -(ll[..., :-n_th].mean(-1) + ll[..., -n_th:].mean(-1))
+        else:
+            nll = -ll.mean(-1)
+        return nll_q.t(), nll.t()                                # [B, T]

@@ -1,0 +1,61 @@
+"""Mirror of the reference's utils/eval.py for the hot path: compute_ll (:200-207), get_traces
+(:8-39) and compute_EIG_from_history (:42-80), all on the HIP kernels."""
+import math
+
+import torch
+
+from .. import _lib
+from ..loss.eig import EIGStepLoss
+
+
+def compute_ll(value, means, stds, weights):
+    """GMM log-likelihood logsumexp_c(Normal(mu_c, sd_c).log_prob(v) + log w_c)  (eval.py:200-207).
+    value [B, n_t, 1] (or [B, n_t]) against [B, n_t, C] -> [B, n_t]."""
+    C_ = means.shape[-1]
+    lead = means.shape[:-1]
+    v = _lib.f32(value).expand(*lead, 1) if value.dim() == means.dim() else _lib.f32(value)
+    v = v.reshape(-1).contiguous()
+    m, s, w = (_lib.f32(t).reshape(-1, C_) for t in (means, stds, weights))
+    out = torch.empty(v.shape[0], dtype=torch.float32, device=m.device)
+    _lib.check(_lib.lib.aline_compute_ll(v.data_ptr(), m.data_ptr(), s.data_ptr(), w.data_ptr(),
+                                         v.shape[0], C_, out.data_ptr(), _lib.stream_ptr(m.device)),
+               "compute_ll")
+    return out.reshape(lead)
+
+
+@torch.no_grad()
+def get_traces(model, experiment, T=30, batch_size=40, time_token=False):
+    """Eval-mode rollout (eval.py:8-39) on the static-slot rollout API: returns theta_0, designs x
+    [B, n_ctx0+T, dx] (unnormalised) and outcomes y in order of acquisition."""
+    from ..rollout import Rollout
+    model.eval()
+    theta_shape = experiment.sample_theta((batch_size)).shape
+    batch = experiment.sample_batch(batch_size)
+    ro = Rollout(model, batch, T, select="argmax", time_token_T=T if time_token else 0)
+    ro.run()
+    cx, cy = ro.export_context()
+    theta_0 = batch.target_theta.reshape(*theta_shape)
+    return theta_0, experiment.unnormalise_design(cx), cy
+
+
+@torch.no_grad()
+def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=40, stepwise=False):
+    """sPCE / sNMC bounds from a design history (eval.py:42-80)."""
+    T = x.shape[1]
+    criterion = EIGStepLoss(L, batch_size, experiment, reduction="none", device=x.device)
+    thetas = experiment.sample_theta((L, batch_size))
+    thetas = torch.concat([theta_0.unsqueeze(0), thetas], dim=0).contiguous()
+    pce_l, nmc_l = [], []
+    for t in range(T):
+        last = t == T - 1
+        if stepwise or last:
+            pce, nmc = criterion(y[:, t], x[:, t], thetas)
+            pce_l.append(pce)
+            nmc_l.append(nmc)
+        else:
+            criterion.step(y[:, t], x[:, t], thetas)   # eval.py:73-74 recomputes the LSE; only the last is used
+    if stepwise:
+        pce, nmc = torch.stack(pce_l, dim=-1), torch.stack(nmc_l, dim=-1)
+    else:
+        pce, nmc = pce_l[-1], nmc_l[-1]
+    return math.log(L + 1) - pce, math.log(L) - nmc

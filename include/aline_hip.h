@@ -1,0 +1,184 @@
+/* aline_hip.h -- C ABI of the MI355X-native ALINE hot path (libaline_hip.so).
+ *
+ * Drop-in boundary: the reference has no FFI; the seam is the three nn.Modules hydra instantiates
+ * (config/embedder|encoder|head/NAME.yaml -> train_aline.py:246-249) and the calls
+ * `model.forward(batch)` (train_aline.py:84, utils/eval.py:28), `compute_ll` (train_aline.py:92),
+ * `Task.update_batch` (train_aline.py:88) and `EIGStepLoss` (utils/eval.py:56-74).  Every entry
+ * point below names the reference function it replaces.  Plain pointers and sizes only:
+ *   - all tensors are device pointers to contiguous row-major fp32 (int64 for indices,
+ *     int32 for roles, uint8 for masks) unless stated otherwise;
+ *   - weights are read in PyTorch's own layout ([out, in] row-major) -- the caller repacks nothing;
+ *   - no allocation inside: the caller passes a workspace (size from *_workspace_bytes), so every
+ *     call is legal inside hipGraph capture;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work, never synchronise;
+ *   - return 0 on success, a negative ALINE_E* code otherwise; nothing throws across the ABI;
+ *   - re-entrant, no mutable global state.
+ */
+#ifndef ALINE_HIP_H
+#define ALINE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALINE_ABI_VERSION 1
+#define ALINE_MAX_LAYERS 8
+#define ALINE_MAX_COMPONENTS 16
+
+enum { ALINE_OK = 0, ALINE_EINVAL = -1, ALINE_EUNSUPPORTED = -2, ALINE_EWORKSPACE = -3,
+       ALINE_ELAUNCH = -4 };
+
+/* embedding_type of model/embedder.py:24 */
+enum { ALINE_EMB_DATA = 0, ALINE_EMB_THETA = 1, ALINE_EMB_MIX = 2 };
+
+/* arithmetic of the matrix products (accumulation, LayerNorm, softmax, log-likelihoods are
+ * always fp32):  F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the reference-precision mode;
+ * BF16 = one bf16 MFMA pass; BF16X3 = split-bf16 (hi*hi + hi*lo + lo*hi), ~fp32 accuracy at
+ * 3 bf16 MFMA passes. */
+enum { ALINE_PREC_F32 = 0, ALINE_PREC_BF16 = 1, ALINE_PREC_BF16X3 = 2 };
+
+/* design selection of model/head.py:350-358 */
+enum { ALINE_SELECT_ARGMAX = 0,   /* eval: max -> log            (head.py:355-358) */
+       ALINE_SELECT_SAMPLE = 1,   /* train: inverse-CDF sample of Categorical(zt) from uniform[b] */
+       ALINE_SELECT_FORCED = 2 }; /* teacher forcing: idx given, log_prob = Categorical.log_prob */
+
+/* Model hyper-parameters + weight pointers, keyed exactly like the reference state_dict
+ * (SURVEY.md 8-b.6).  Mirrors the constructor kwargs of Embedder (model/embedder.py:17-26),
+ * Encoder (model/encoder.py:56-63) and OutputHead (model/head.py:275-287). */
+typedef struct aline_model {
+  int32_t dim_x, dim_y, d, F, H, L, C;
+  int32_t n_theta;          /* n_target_theta: number of learnable theta tokens (0 in data mode) */
+  int32_t embedding_type;   /* ALINE_EMB_* */
+  int32_t time_token;       /* head.py:24-25: acquisition MLP input is d+1 wide */
+  float std_min;            /* head.py:176 */
+  int32_t precision;        /* ALINE_PREC_* */
+  /* embedder.{x,y}_embedder.{0,2}.{weight,bias}, embedder.theta_tokens */
+  const float *x_w1, *x_b1, *x_w2, *x_b2;
+  const float *y_w1, *y_b1, *y_w2, *y_b2;
+  const float *theta_tokens;                       /* [n_theta, d] or NULL */
+  /* encoder.encoder.layers.{l}.* */
+  const float *in_proj_w[ALINE_MAX_LAYERS], *in_proj_b[ALINE_MAX_LAYERS];     /* [3d,d],[3d] */
+  const float *out_proj_w[ALINE_MAX_LAYERS], *out_proj_b[ALINE_MAX_LAYERS];   /* [d,d],[d]  */
+  const float *lin1_w[ALINE_MAX_LAYERS], *lin1_b[ALINE_MAX_LAYERS];           /* [F,d],[F]  */
+  const float *lin2_w[ALINE_MAX_LAYERS], *lin2_b[ALINE_MAX_LAYERS];           /* [d,F],[d]  */
+  const float *norm1_w[ALINE_MAX_LAYERS], *norm1_b[ALINE_MAX_LAYERS];
+  const float *norm2_w[ALINE_MAX_LAYERS], *norm2_b[ALINE_MAX_LAYERS];
+  /* head.acquisition_head.predictor.{0,2}.* */
+  const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;  /* [F,d(+1)],[F],[1,F],[1] */
+  /* head.target_head.heads.{c}.{0,2}.* */
+  const float *gmm_w1[ALINE_MAX_COMPONENTS], *gmm_b1[ALINE_MAX_COMPONENTS];   /* [F,d],[F] */
+  const float *gmm_w2[ALINE_MAX_COMPONENTS], *gmm_b2[ALINE_MAX_COMPONENTS];   /* [3,F],[3] */
+} aline_model;
+
+/* One design step in the reference's own (shape-changing) batch layout: the AttrDict batch of
+ * SURVEY.md 8-b.4.  Token order is context | query | target data | theta (model/embedder.py). */
+typedef struct aline_step {
+  int32_t B, n_ctx, n_query, n_target_data;     /* n_t = n_target_data + model.n_theta */
+  const float *context_x, *context_y;           /* [B,n_ctx,dx], [B,n_ctx,dy] */
+  const float *query_x;                         /* [B,n_query,dx] */
+  const float *target_x;                        /* [B,n_target_data,dx] or NULL */
+  const float *target_all;                      /* [B,n_t] values for compute_ll, or NULL */
+  const uint8_t *target_mask;                   /* [n_t] (encoder.py:110) or NULL = all */
+  const float *time_t;                          /* device scalar batch.t, or NULL */
+  int32_t select_mode;                          /* ALINE_SELECT_* */
+  const float *uniform;                         /* [B] in [0,1) for SAMPLE */
+  const int64_t *forced_idx;                    /* [B] for FORCED */
+  /* outputs (any may be NULL to skip) -- the AttrDict of model/head.py:384-392 */
+  int64_t *idx;                                 /* [B,1]  design_out.idx (index into query list) */
+  float *log_prob;                              /* [B]    design_out.log_prob */
+  float *zt;                                    /* [B,n_query] design_out.zt */
+  float *post_mean, *post_std, *post_weight;    /* [B,n_t,C]   posterior_out.* */
+  float *postq_mean, *postq_std, *postq_weight; /* [B,n_query,C] posterior_out_query.* */
+  float *target_ll;                             /* [B,n_t] compute_ll (utils/eval.py:200-207) */
+  float *embedding;                             /* [B,N,d] Embedder.forward output */
+  float *encoding;                              /* [B,N,d] Encoder.forward output */
+} aline_step;
+
+/* Whole T-step acquisition loop (train_aline.py:80-110 / utils/eval.py:24-30) on a shape-static
+ * layout: all P = n_ctx0 + n_query0 candidate points stay in fixed slots, `role[b,p]` is 0 for a
+ * remaining query and k>0 for the k-th context point (order of entry), so one step is
+ * hipGraph-capturable.  Equivalent to the reference up to summation order because there are no
+ * positional encodings and the mask depends only on the token's role (encoder.py:83-126). */
+typedef struct aline_rollout {
+  int32_t B, P, n_ctx0, n_target_data, T;
+  const float *point_x, *point_y;               /* [B,P,dx], [B,P,dy]: ctx0 first, then queries */
+  int32_t *role;                                /* [B,P] in/out; NULL-initialised by aline_rollout_init */
+  const float *target_x;                        /* [B,n_target_data,dx] or NULL */
+  const float *target_all;                      /* [B,n_t] */
+  const uint8_t *target_mask;                   /* [n_t] or NULL */
+  int32_t select_mode;
+  const float *uniform;                         /* [T,B] */
+  const int64_t *forced_idx;                    /* [B,T] index into the compacted query list */
+  int32_t time_token_T;                         /* t/T is fed when model.time_token */
+  /* outputs */
+  int64_t *idx;                                 /* [B,T] compacted index (reference convention) */
+  int32_t *slot;                                /* [B,T] chosen slot p */
+  float *log_prob;                              /* [B,T] */
+  float *target_ll;                             /* [T,B,n_t] */
+  float *zt;                                    /* [T,B,P - n_ctx0] zero padded, or NULL */
+  float *post_mean, *post_std, *post_weight;    /* [T,B,n_t,C] or NULL */
+} aline_rollout;
+
+/* ABI / build info. */
+int aline_abi_version(void);
+const char *aline_error_string(int code);
+
+/* --- Aline.forward (model/base.py:32-50) and its three stages ------------------------------ */
+size_t aline_step_workspace_bytes(const aline_model *m, const aline_step *s);
+/* Embedder.forward (model/embedder.py:67-95): writes s->embedding. */
+int aline_embed_forward(const aline_model *m, const aline_step *s, void *ws, size_t ws_bytes,
+                        void *stream);
+/* Encoder.forward (model/encoder.py:128-141): x_in [B,N,d] -> s->encoding. */
+int aline_encoder_forward(const aline_model *m, const aline_step *s, const float *x_in, void *ws,
+                          size_t ws_bytes, void *stream);
+/* OutputHead.forward (model/head.py:319-393) on z [B,N,d]. */
+int aline_head_forward(const aline_model *m, const aline_step *s, const float *z, void *ws,
+                       size_t ws_bytes, void *stream);
+/* embedder -> encoder -> head in one call. */
+int aline_step_forward(const aline_model *m, const aline_step *s, void *ws, size_t ws_bytes,
+                       void *stream);
+
+/* --- T-step loop on the static-slot layout -------------------------------------------------- */
+size_t aline_rollout_workspace_bytes(const aline_model *m, const aline_rollout *r);
+/* role <- initial ctx/query; caches the step-invariant point embeddings (x- and y-embedder of
+ * every slot, model/embedder.py:47-57) in the workspace: the same `ws` must be passed to the steps. */
+int aline_rollout_init(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
+                       void *stream);
+int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void *ws,
+                       size_t ws_bytes, void *stream);             /* forward + select + update */
+int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
+                          void *stream);                            /* init + T steps */
+/* Task.update_batch equivalent for callers that want the reference layout back
+ * (tasks/base_task.py:133-154): context_x/y [B,n_ctx0+T,*] in order of entry, query remainder. */
+int aline_rollout_export(const aline_rollout *r, int n_ctx, float *context_x, float *context_y,
+                         float *query_x, float *query_y, int dim_x, int dim_y, void *stream);
+
+/* --- objectives ----------------------------------------------------------------------------- */
+/* compute_ll (utils/eval.py:200-207): value [rows], means/stds/weights [rows,C] -> out [rows]. */
+int aline_compute_ll(const float *value, const float *means, const float *stds,
+                     const float *weights, int64_t rows, int C, float *out, void *stream);
+
+/* EIGStepLoss.step (loss/eig.py:174-193) with HiddenLocation.log_likelihood
+ * (tasks/location_finding.py:110-164):  S[l,b] += log N(y[b]; log(base + sum_k 1/(m+|xi_b-th_lbk|^2)), noise)
+ * theta [L1,B,K,D], xi [B,D], y [B], S [L1,B] in/out. */
+int aline_eig_location_step(const float *theta, const float *xi, const float *y, float *S,
+                            int64_t L1, int B, int K, int D, float noise_scale, float base_signal,
+                            float max_signal, void *stream);
+/* same with CESTask.log_likelihood (tasks/ces.py:169-210) and CensoredSigmoidNormal.log_prob
+ * (distributions/censored_sigmoid_normal.py:47-86): theta [L1,B,5], xi [B,6], y [B].
+ * nan_flag (device int, may be NULL) is set instead of raising (csn.py:83-84). */
+int aline_eig_ces_step(const float *theta, const float *xi, const float *y, float *S, int64_t L1,
+                       int B, float noise_scale, float epsilon, int32_t *nan_flag, void *stream);
+/* EIGStepLoss.forward (loss/eig.py:195-209) + the bounds of utils/eval.py:77-78:
+ * pce[b] = log(L+1) - (LSE_{l>=0} S - S[0]),  nmc[b] = log L - (LSE_{l>=1} S - S[0]). */
+size_t aline_eig_finalize_workspace_bytes(int64_t L1, int B);
+int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc, void *ws,
+                       size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALINE_HIP_H */
