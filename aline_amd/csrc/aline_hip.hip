@@ -243,11 +243,10 @@ int do_gmm(const Ctx &c, const float *Z, int b0, int nb, int row_off, int rows_p
   return ALINE_OK;
 }
 
-// OutputHead.forward (model/head.py:319-393)
-int do_head(const Ctx &c, const float *Z, HeadIO io) {
+// AcquisitionHead + design selection (model/head.py:27-33, :347-362)
+int do_acquisition(const Ctx &c, const float *Z, HeadIO io) {
   const aline_model &m = *c.m;
   const Geo &g = c.g;
-  const int n_t = g.n_td + g.n_th;
   // acquisition MLP first layer on the P point rows of every episode
   const float *w1 = m.acq_w1;
   int ldw = m.d;
@@ -268,6 +267,16 @@ int do_head(const Ctx &c, const float *Z, HeadIO io) {
   if (g.P > 1024) return ALINE_EUNSUPPORTED;
   hipLaunchKernelGGL(acq_select_kernel, dim3(g.B), dim3(256), (size_t)g.P * 8, c.st, io.sel);
   CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// OutputHead.forward (model/head.py:319-393)
+int do_head(const Ctx &c, const float *Z, HeadIO io) {
+  const aline_model &m = *c.m;
+  const Geo &g = c.g;
+  const int n_t = g.n_td + g.n_th;
+  const bool want_sel = io.sel.idx || io.sel.log_prob || io.sel.zt || io.sel.slot || io.sel.role_out;
+  if (want_sel) TRY(do_acquisition(c, Z, io));
   // posterior over the targets (+ compute_ll)
   if (io.post_mean || io.post_std || io.post_weight || io.target_ll)
     TRY(do_gmm(c, Z, 0, g.B, g.P + 0, n_t, io.post_mean, io.post_std, io.post_weight, io.target_all,
@@ -388,7 +397,7 @@ int aline_head_forward(const aline_model *m, const aline_step *s, const float *z
   Ctx c;
   TRY(step_ctx(m, s, ws, ws_bytes, stream, c, ST_HEAD));
   if (!z) return ALINE_EINVAL;
-  TRY(check_select(s->select_mode, s->uniform, s->forced_idx));
+  if (s->idx || s->log_prob || s->zt) TRY(check_select(s->select_mode, s->uniform, s->forced_idx));
   return do_head(c, z, step_head_io(*s, s->n_ctx));
 }
 

@@ -46,6 +46,22 @@ def algorithmic_flops_per_episode(dx, dy, d, F, H, L, C, n_c0, n_q0, n_td, n_th,
     return total
 
 
+def host_cores():
+    """Threads this process may really use: min(affinity, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("ALINE_CPU_THREADS", "16"))))
+
+
 def build_model(args, device):
     from aline_amd import Aline, Embedder, Encoder, OutputHead
     torch.manual_seed(args.seed)
@@ -60,12 +76,9 @@ def cpu_baseline(args, model):
     bounded sample of the same workload: `cpu_batch` episodes, full T, eval-mode forward."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import aline_oracle as orc
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
     sd = orc.cast_state_dict(model.state_dict())
     cfg = dict(embedding_type="theta", n_head=args.heads, num_layers=args.layers, num_components=10,
                std_min=1e-4, n_target_theta=2)
@@ -81,7 +94,12 @@ def cpu_baseline(args, model):
 
     with torch.no_grad():
         orc.rollout(sd, make(4), cfg, 2, with_query_gmm=True)          # warm-up
-        B = args.cpu_batch
+        t0 = time.perf_counter()
+        orc.rollout(sd, make(16), cfg, args.T, with_query_gmm=True)    # calibration
+        cal = time.perf_counter() - t0
+        # bounded sample: about 15 s of CPU work, at most --cpu-batch episodes
+        B = int(max(16, min(args.cpu_batch, 16 * 15.0 / max(cal, 1e-3))))
+        log(f"cpu baseline calibration: 16 episodes in {cal:.2f} s -> timing {B} episodes")
         t0 = time.perf_counter()
         orc.rollout(sd, make(B), cfg, args.T, with_query_gmm=True)
         dt = time.perf_counter() - t0
@@ -89,6 +107,10 @@ def cpu_baseline(args, model):
             "kind": "port",
             "sample": f"{B} episodes x T={args.T} x n_query={args.n_query}, fp32 torch-CPU oracle, "
                       f"eval forward incl. posterior_out_query, {dt:.1f} s"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -105,7 +127,7 @@ def main():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16", "bf16x3"])
     ap.add_argument("--graph", type=int, default=1, help="replay the rollout from one HIP graph")
-    ap.add_argument("--cpu-batch", type=int, default=192)
+    ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
     args = ap.parse_args()
@@ -125,14 +147,20 @@ def main():
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
 
+    log(f"rank {rank}/{world}: building model d={args.d_model} F={args.d_ff} prec={args.precision}")
     model = build_model(args, device)
     model.train()                       # train-time path: designs are sampled (head.py:350-354)
     torch.manual_seed(args.seed + rank)             # every rank rolls out its own episodes
     task = HiddenLocation(n_query_init=args.n_query, device=device)
     batch = task.sample_batch(args.batch)
     ro = Rollout(model, batch, args.T, select="sample", keep_zt=False, keep_posterior=True)
+    log("rollout object built; first (eager) rollout ...")
+    ro.run()
+    torch.cuda.synchronize(device)
+    log("eager rollout done")
     if args.graph:
         ro.capture()
+        log("graph captured")
     run = ro.replay if args.graph else ro.run
 
     def barrier():
@@ -144,6 +172,7 @@ def main():
         ro.refresh_uniform()
         run()
     barrier()
+    log("warm-up done; timing ...")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -185,8 +214,10 @@ def main():
                      "kernel": "whole rollout graph (all kernels of T steps; per-kernel split in profiles/)",
                      "algorithmic_flops_per_episode": fl_ep, "device_ms_per_rollout": dev_ms / args.steps},
     }
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms per rollout")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, model)
+        log("cpu baseline done")
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
