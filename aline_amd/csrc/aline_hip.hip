@@ -5,9 +5,11 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "eig.h"
+#include "fused_rollout.h"
 
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -25,7 +27,7 @@ inline size_t align_up(size_t v, size_t a = 64) { return (v + a - 1) / a * a; }
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -55,6 +57,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   p.Tm = take(M * d);
   p.Wacq = take(F * d);
   p.scalar = take(64);
+  p.Wpack = take((size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS);
   p.total = off;
   return p;
 }
@@ -488,8 +491,62 @@ int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void
   return do_head(c, X, io);
 }
 
+// The fused per-episode kernel (fused_rollout.h) covers the small-width theta-mode models.
+static bool fused_eligible(const aline_model &m, const aline_rollout &r) {
+  if (getenv("ALINE_DISABLE_FUSED")) return false;
+  if (m.precision != ALINE_PREC_F32) return false;
+  if (m.d != fused::D || m.F != fused::F || m.H != fused::H || m.time_token) return false;
+  if (m.embedding_type != ALINE_EMB_THETA || r.n_target_data != 0) return false;
+  if (m.n_theta < 1 || m.n_theta > fused::MAXNT || r.P + m.n_theta > fused::MAXROWS) return false;
+  if (r.n_ctx0 + r.T - 1 + m.n_theta > fused::NKMAX) return false;
+  return true;
+}
+
+static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
+                         void *stream) {
+  Ctx c;
+  TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
+  TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
+  // step-invariant point embeddings (x- and y-embedder of every slot)
+  Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
+  TRY(do_embed_points(c, xs, r->point_y, r->P));
+  fused::PackArgs pa{};
+  pa.L = m->L;
+  for (int l = 0; l < m->L; ++l) {
+    pa.in_proj_w[l] = m->in_proj_w[l]; pa.in_proj_b[l] = m->in_proj_b[l];
+    pa.out_proj_w[l] = m->out_proj_w[l]; pa.out_proj_b[l] = m->out_proj_b[l];
+    pa.lin1_w[l] = m->lin1_w[l]; pa.lin1_b[l] = m->lin1_b[l];
+    pa.lin2_w[l] = m->lin2_w[l]; pa.lin2_b[l] = m->lin2_b[l];
+    pa.n1w[l] = m->norm1_w[l]; pa.n1b[l] = m->norm1_b[l];
+    pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
+  }
+  pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
+  pa.out = c.at(c.pl.Wpack);
+  hipLaunchKernelGGL(fused::pack_weights_kernel, dim3(64), dim3(256), 0, c.st, pa);
+  CHECK_LAUNCH();
+  fused::RolloutArgs a{};
+  a.B = r->B; a.P = r->P; a.n_ctx0 = r->n_ctx0; a.n_th = m->n_theta; a.T = r->T; a.L = m->L; a.C = m->C;
+  a.wpack = c.at(c.pl.Wpack); a.Ex = c.at(c.pl.Ex); a.Ey = c.at(c.pl.Ey);
+  a.theta_tokens = m->theta_tokens; a.tmask = r->target_mask; a.target_all = r->target_all;
+  for (int k = 0; k < m->C; ++k) {
+    a.gmm_w1[k] = m->gmm_w1[k]; a.gmm_b1[k] = m->gmm_b1[k];
+    a.gmm_w2[k] = m->gmm_w2[k]; a.gmm_b2[k] = m->gmm_b2[k];
+  }
+  a.std_min = m->std_min; a.mode = r->select_mode; a.uniform = r->uniform; a.forced = r->forced_idx;
+  a.role = r->role; a.idx = r->idx; a.slot = r->slot; a.log_prob = r->log_prob;
+  a.target_ll = r->target_ll; a.zt = r->zt;
+  a.post_mean = r->post_mean; a.post_std = r->post_std; a.post_weight = r->post_weight;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::LDS_BYTES);
+  hipLaunchKernelGGL(fused::rollout_f32_kernel, dim3(r->B), dim3(256), fused::LDS_BYTES, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
 int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
                           void *stream) {
+  if (m && r && validate_model(*m) == 0 && fused_eligible(*m, *r))
+    return rollout_fused(m, r, ws, ws_bytes, stream);
   TRY(aline_rollout_init(m, r, ws, ws_bytes, stream));
   for (int t = 0; t < r->T; ++t) TRY(aline_rollout_step(m, r, t, ws, ws_bytes, stream));
   return ALINE_OK;
