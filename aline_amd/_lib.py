@@ -86,6 +86,7 @@ def _load():
         "aline_eig_ces_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_float,
                                          C.c_float, _fp, _fp]),
         "aline_eig_finalize_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+        "aline_debug_stamps_offset": (C.c_size_t, [MP, RP]),
         "aline_eig_finalize": (C.c_int, [_fp, C.c_int64, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     }
     for name, (res, args) in sig.items():

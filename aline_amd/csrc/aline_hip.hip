@@ -27,7 +27,7 @@ inline size_t align_up(size_t v, size_t a = 64) { return (v + a - 1) / a * a; }
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -58,6 +58,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   p.Wacq = take(F * d);
   p.scalar = take(64);
   p.Wpack = take((size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS);
+  p.Stamps = take(512);   // diagnostic stamps of the fused kernel (8 x 16 x u64)
   p.total = off;
   return p;
 }
@@ -536,9 +537,19 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   a.role = r->role; a.idx = r->idx; a.slot = r->slot; a.log_prob = r->log_prob;
   a.target_ll = r->target_ll; a.zt = r->zt;
   a.post_mean = r->post_mean; a.post_std = r->post_std; a.post_weight = r->post_weight;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::LDS_BYTES);
-  hipLaunchKernelGGL(fused::rollout_f32_kernel, dim3(r->B), dim3(256), fused::LDS_BYTES, c.st, a);
+  a.stagger_sleeps = getenv("ALINE_FUSED_STAGGER") ? atoi(getenv("ALINE_FUSED_STAGGER")) : 16;
+  // ALINE_FUSED_STAMPS=1 selects the diagnostic (s_memtime-stamped) instantiation; the stamps land
+  // in the tail of the workspace scalar block and are never read by product code.
+  if (getenv("ALINE_FUSED_STAMPS")) {
+    a.stamps = reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::LDS_BYTES);
+    hipLaunchKernelGGL(fused::rollout_f32_kernel<true>, dim3(r->B), dim3(256), fused::LDS_BYTES, c.st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::LDS_BYTES);
+    hipLaunchKernelGGL(fused::rollout_f32_kernel<false>, dim3(r->B), dim3(256), fused::LDS_BYTES, c.st, a);
+  }
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -620,3 +631,9 @@ int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc
 }
 
 }  // extern "C"
+
+// Diagnostic only: byte offset of the stamp block inside a rollout workspace (tools/stamps.py).
+extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_rollout *r) {
+  if (!m || !r) return 0;
+  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false).Stamps * sizeof(float);
+}

@@ -58,7 +58,8 @@ __device__ __forceinline__ float frag_elem(const float *W, int K, int mt, int kb
 
 __global__ void pack_weights_kernel(PackArgs a) {
   const int total = a.L * LAYER_FLOATS + HEAD_FLOATS;
-  const float qscale = rsqrtf((float)HD);
+  // 1/sqrt(hd) and log2(e) folded into Wq, bq: the kernel's softmax is exp2(s - max)
+  const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     float v = 0.f;
     if (i < a.L * LAYER_FLOATS) {
@@ -123,16 +124,20 @@ __device__ __forceinline__ void mma_half(f32x4 &acc, const f32x4 &A, const f32x4
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], B[j], acc, 0, 0, 0);
 }
 
-// reduce over the 4 lane groups (lanes l, l^16, l^32, l^48 hold the same token)
+// reduce over the 4 lane groups (lanes l, l^16, l^32, l^48 hold the same token) with the gfx950
+// row/half swaps (VALU, no LDS crossbar): v_permlane16_swap(x, x) leaves {x0,x0,x2,x2} and
+// {x1,x1,x3,x3} (rows of 16 lanes), v_permlane32_swap(x, x) leaves {lo,lo} and {hi,hi}.
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float group_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 // LayerNorm over the 32 features of each token (eps 1e-5, biased variance): x <- LN(x) * w + b
@@ -157,6 +162,258 @@ __device__ __forceinline__ void layer_norm(f32x4 (&x)[2], const float *w, const 
   }
 }
 
+
+#define MFMA4(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0)
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+// One encoder layer for NT (1 or 2) token tiles of one wave (x[tile][acc tile]).  Independent
+// accumulators (2 acc tiles x NT tiles) are interleaved MFMA by MFMA so that a 16x16x4 fp32 MFMA
+// (32-cycle issue, 40-cycle dependent latency) never waits for its own accumulator; with NT = 2 every
+// weight / K / V fragment read from LDS feeds both tiles.  nv[t]: keys visible to this lane's token.
+template <int NT>
+__device__ __forceinline__ void layer_tiles(f32x4 (&x)[NT][2], const float *Wl, const float *prm,
+                                            const float *Kb, const float *Vb, int lane, int g,
+                                            const int (&nv)[NT], bool two_kt) {
+  // ---- q = Wq x + bq (scaled) ------------------------------------------------------------------------
+  f32x4 q[NT][2];
+  {
+    const Frag w0 = ld_frag(Wl + FQ * FRAG, lane), w1 = ld_frag(Wl + (FQ + 1) * FRAG, lane);
+    const f32x4 b0 = ld4(prm + PB_Q + 4 * g), b1 = ld4(prm + PB_Q + 16 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { q[t][0] = b0; q[t][1] = b1; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(q[t][0], w0.lo[j], x[t][0][j]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(q[t][1], w1.lo[j], x[t][0][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(q[t][0], w0.hi[j], x[t][1][j]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(q[t][1], w1.hi[j], x[t][1][j]);
+    }
+  }
+  // ---- S^T = Kblk q for the 4 heads (only the head's 16-channel sub-plane is non-zero) ----------------
+  f32x4 s[NT][H][2];
+  {
+    f32x4 kf[H][2];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      kf[h][0] = ld4(Kb + (h * 2 + 0) * 256 + lane * 4);
+      kf[h][1] = two_kt ? ld4(Kb + (h * 2 + 1) * 256 + lane * 4) : zero4();
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { s[t][h][0] = zero4(); s[t][h][1] = zero4(); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(s[t][h][0], kf[h][0][j], q[t][h >> 1][j]);
+    if (two_kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) MFMA4(s[t][h][1], kf[h][1][j], q[t][h >> 1][j]);
+    }
+  }
+  // ---- masked softmax over the key axis (registers x lane groups); p stays unnormalised ---------------
+  float inv[NT][H];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    bool ok[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ok[kt][r] = (16 * kt + 4 * g + r) < nv[t];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[t][h][kt][r] = ok[kt][r] ? s[t][h][kt][r] : -INFINITY;
+          mx = fmaxf(mx, s[t][h][kt][r]);
+        }
+      mx = group_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[t][h][kt][r] = __builtin_amdgcn_exp2f(s[t][h][kt][r] - mx);
+          sum += s[t][h][kt][r];
+        }
+      inv[t][h] = __builtin_amdgcn_rcpf(group_sum(sum));
+    }
+  }
+  // ---- O^T = Vblk P^T (head h feeds the 8 channels of acc tile h>>1), then normalise ------------------
+  f32x4 o[NT][2];
+  {
+    f32x4 vf[H][2];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float *vp = Vb + ((h >> 1) * 2 + (h & 1)) * FRAG;
+      vf[h][0] = ld4(vp + lane * 4);
+      vf[h][1] = two_kt ? ld4(vp + 256 + lane * 4) : zero4();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { o[t][0] = zero4(); o[t][1] = zero4(); }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(o[t][0], vf[e][0][j], s[t][e][0][j]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(o[t][1], vf[2 + e][0][j], s[t][2 + e][0][j]);
+      }
+    if (two_kt) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) MFMA4(o[t][0], vf[e][1][j], s[t][e][1][j]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) MFMA4(o[t][1], vf[2 + e][1][j], s[t][2 + e][1][j]);
+        }
+    }
+    // rows 4g+r of acc tile mt belong to head 2 mt + (g >> 1)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float f = (g >> 1) ? inv[t][2 * mt + 1] : inv[t][2 * mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][mt][r] *= f;
+      }
+  }
+  // ---- x1 = LN1(x + Wo o + bo) ---------------------------------------------------------------------------
+  f32x4 x1[NT][2];
+  {
+    const Frag w0 = ld_frag(Wl + FO * FRAG, lane), w1 = ld_frag(Wl + (FO + 1) * FRAG, lane);
+    const f32x4 b0 = ld4(prm + PB_O + 4 * g), b1 = ld4(prm + PB_O + 16 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { x1[t][0] = b0 + x[t][0]; x1[t][1] = b1 + x[t][1]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(x1[t][0], w0.lo[j], o[t][0][j]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(x1[t][1], w1.lo[j], o[t][0][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(x1[t][0], w0.hi[j], o[t][1][j]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(x1[t][1], w1.hi[j], o[t][1][j]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) layer_norm(x1[t], prm + PLN1W, prm + PLN1B, g);
+  // ---- x = LN2(x1 + W2 relu(W1 x1 + b1) + b2), hidden streamed in 32-wide chunks ----------------------------
+  {
+    const f32x4 b0 = ld4(prm + PB_2 + 4 * g), b1 = ld4(prm + PB_2 + 16 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { x[t][0] = b0 + x1[t][0]; x[t][1] = b1 + x1[t][1]; }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const Frag u0 = ld_frag(Wl + (F1 + 2 * kb) * FRAG, lane), u1 = ld_frag(Wl + (F1 + 2 * kb + 1) * FRAG, lane);
+      const f32x4 hb0 = ld4(prm + PB_1 + 32 * kb + 4 * g), hb1 = ld4(prm + PB_1 + 32 * kb + 16 + 4 * g);
+      f32x4 hd[NT][2];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { hd[t][0] = hb0; hd[t][1] = hb1; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.lo[j], x1[t][0][j]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.lo[j], x1[t][0][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.hi[j], x1[t][1][j]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.hi[j], x1[t][1][j]);
+      }
+      const Frag d0 = ld_frag(Wl + (F2 + kb) * FRAG, lane), d1 = ld_frag(Wl + (F2 + 4 + kb) * FRAG, lane);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hd[t][mt][r] = fmaxf(hd[t][mt][r], 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(x[t][0], d0.lo[j], hd[t][0][j]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(x[t][1], d1.lo[j], hd[t][0][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(x[t][0], d0.hi[j], hd[t][1][j]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) MFMA4(x[t][1], d1.hi[j], hd[t][1][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) layer_norm(x[t], prm + PLN2W, prm + PLN2B, g);
+}
+
+// acquisition MLP (model/head.py:27-33) for NT tiles: logit = w2 . relu(W1 z + b1) + b2
+template <int NT>
+__device__ __forceinline__ void acq_tiles(const f32x4 (&z)[NT][2], const float *Wl, int lane, int g,
+                                          float (&lg)[NT]) {
+  const float *hb1 = Wl + 8 * FRAG, *hw2 = hb1 + 128, *hb2 = hw2 + 128;
+  float p[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) p[t] = 0.f;
+#pragma unroll
+  for (int mp = 0; mp < 4; ++mp) {
+    const Frag u0 = ld_frag(Wl + (2 * mp) * FRAG, lane), u1 = ld_frag(Wl + (2 * mp + 1) * FRAG, lane);
+    const f32x4 hb0 = ld4(hb1 + 32 * mp + 4 * g), hbb = ld4(hb1 + 32 * mp + 16 + 4 * g);
+    const f32x4 w20 = ld4(hw2 + 32 * mp + 4 * g), w21 = ld4(hw2 + 32 * mp + 16 + 4 * g);
+    f32x4 hd[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { hd[t][0] = hb0; hd[t][1] = hbb; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.lo[j], z[t][0][j]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.lo[j], z[t][0][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.hi[j], z[t][1][j]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.hi[j], z[t][1][j]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[t] = fmaf(fmaxf(hd[t][0][r], 0.f), w20[r], p[t]);
+        p[t] = fmaf(fmaxf(hd[t][1][r], 0.f), w21[r], p[t]);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) lg[t] = group_sum(p[t]) + hb2[0];
+}
+
 struct RolloutArgs {
   int B, P, n_ctx0, n_th, T, L, C;
   const float *wpack;           // packed layer + head images
@@ -174,14 +431,15 @@ struct RolloutArgs {
   float *target_ll;                                   // [T, B, n_th]
   float *zt;                                          // [T, B, P - n_ctx0] or null
   float *post_mean, *post_std, *post_weight;          // [T, B, n_th, C] or null
+  int stagger_sleeps;           // s_sleep(127) iterations (8128 cycles each) for odd residency slots
+  unsigned long long *stamps;   // diagnostic build only: per-phase cycle sums [8 waves x 16]
 };
 
 // LDS carve (floats).  Everything lives in one dynamic array (16-byte aligned carve offsets).
 constexpr int L_W = 0;                               // layer image / head image
 constexpr int L_KB = L_W + LAYER_FLOATS;             // Kblk: 8 fragments x 256 floats (one sub-plane each)
 constexpr int L_VB = L_KB + 8 * 256;                 // Vblk: 4 fragments x 512 floats
-constexpr int L_E = L_VB + 4 * FRAG;                 // E [MAXROWS][ES]
-constexpr int L_XK = L_E + MAXROWS * ES;             // Xk [NKMAX][ES]
+constexpr int L_XK = L_VB + 4 * FRAG;                // Xk [NKMAX][ES]
 constexpr int L_ZT = L_XK + NKMAX * ES;              // Zt [MAXNT][ES]
 constexpr int L_LOGIT = L_ZT + MAXNT * ES;           // logits / probs [MAXROWS]
 constexpr int L_RAW = L_LOGIT + MAXROWS;             // GMM raw outputs [MAXNT][16][4]
@@ -189,9 +447,22 @@ constexpr int L_INT = L_RAW + MAXNT * 16 * 4;        // ints: role[MAXROWS], kid
 constexpr int L_TOTAL = L_INT + 3 * MAXROWS + 16;
 constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 4;
 
-__global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
+// Diagnostic stamps (template STAMP = true builds only; never in the shipped instantiation): wave w
+// of workgroup 0 accumulates s_memtime deltas per phase into a.stamps[w * 16 + phase].
+#define STAMP_PHASE(ph)                                                           \
+  if constexpr (STAMP) {                                                          \
+    unsigned long long _t;                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");    \
+    if (blockIdx.x == 0 && lane == 0) a.stamps[wave * 16 + (ph)] += _t - t_prev;  \
+    t_prev = _t;                                                                  \
+  }
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void rollout_f32_kernel(RolloutArgs a) {
+  unsigned long long t_prev = 0;
+  if constexpr (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory"); }
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *Wl = lds + L_W, *Kb = lds + L_KB, *Vb = lds + L_VB, *E = lds + L_E, *Xk = lds + L_XK,
+  float *Wl = lds + L_W, *Kb = lds + L_KB, *Vb = lds + L_VB, *Xk = lds + L_XK,
         *Zt = lds + L_ZT, *logit = lds + L_LOGIT, *raw = lds + L_RAW;
   int *role = reinterpret_cast<int *>(lds + L_INT);
   int *kidx = role + MAXROWS, *qslot = kidx + MAXROWS, *misc = qslot + MAXROWS;
@@ -202,22 +473,27 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
   const int P = a.P, n_th = a.n_th, N = P + n_th;
   const int ntiles = (N + 15) >> 4;
   const int zw = P - a.n_ctx0;
+  // Balanced contiguous tile ranges: wave wv owns tiles [t0, t0 + tcnt), tcnt = ntiles/4 (+1 for the
+  // first ntiles%4 waves).  The waves that own the extra tile rotate with the workgroup (and with its
+  // residency slot) so that co-resident workgroups do not stack their heavy waves on one SIMD.
+  const int wv = (wave + blockIdx.x + (blockIdx.x >> 8)) & 3;
+  const int tcnt = ntiles / 4 + (wv < (ntiles & 3) ? 1 : 0);
+  const int t0 = wv * (ntiles / 4) + min(wv, ntiles & 3);
 
-  // ---- episode state: roles, E = Ex (+ Ey on context rows), theta-token rows ---------------------
+  // ---- episode state: roles.  The step-invariant embeddings stay in HBM/L2 (Ex, Ey: 26 KB per
+  // episode and step): X^(0)[row] = Ex[row] (+ Ey[row] once the point has joined the context).
   for (int r = tid; r < MAXROWS; r += 256) role[r] = r < P ? (r < a.n_ctx0 ? r + 1 : 0) : -1;
-  for (int i = tid; i < MAXROWS * 8; i += 256) {          // 8 float4 per row
-    const int r = i >> 3, c4 = (i & 7) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < P) {
-      v = ld4(a.Ex + ((long)b * P + r) * D + c4);
-      if (r < a.n_ctx0) { f32x4 y = ld4(a.Ey + ((long)b * P + r) * D + c4); v += y; }
-    } else if (r < N) {
-      v = ld4(a.theta_tokens + (r - P) * D + c4);
-    }
-    *reinterpret_cast<f32x4 *>(E + r * ES + c4) = v;
-  }
   for (int i = tid; i < NKMAX * ES; i += 256) Xk[i] = 0.f;
   __syncthreads();
+
+  // Two workgroups share a CU (and its matrix pipes).  They run the same program, so without help
+  // they would sit in the MFMA-free phases (selection, GMM, weight streaming) at the same time.
+  // Workgroups of the second residency slot (dispatch is round-robin over 256 CUs) start half a
+  // step late, so one workgroup's MFMA-dense layer passes cover the other's scalar phases.  Speed
+  // only: nothing depends on the placement.
+  if (a.stagger_sleeps > 0 && ((blockIdx.x >> 8) & 1)) {
+    for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   for (int t = 0; t < a.T; ++t) {
     // ---- key list: context slots in slot order, then the selected targets ----------------------
@@ -245,21 +521,33 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
       __syncthreads();
     }
     const int n_ck = misc[0], n_ak = misc[1];
+    STAMP_PHASE(0)   // key list
 
     // ---- X^(0): token tiles of this wave from E (tile ti = wave + 4 i) ----------------------------
-    f32x4 x[4][2];
+    f32x4 x[4][2];   // [local tile][acc tile]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = 16 * (wave + 4 * i) + tok;
-      x[i][0] = ld4(E + row * ES + 4 * g);
-      x[i][1] = ld4(E + row * ES + 16 + 4 * g);
-      const int k = kidx[row];
-      if (k >= 0) {
-        *reinterpret_cast<f32x4 *>(Xk + k * ES + 4 * g) = x[i][0];
-        *reinterpret_cast<f32x4 *>(Xk + k * ES + 16 + 4 * g) = x[i][1];
+      const int row = 16 * (t0 + i) + tok;
+      f32x4 v0 = zero4(), v1 = zero4();
+      if (i < tcnt && row < N) {
+        const float *src = row < P ? a.Ex + ((long)b * P + row) * D : a.theta_tokens + (long)(row - P) * D;
+        v0 = ld4(src + 4 * g);
+        v1 = ld4(src + 16 + 4 * g);
+        if (row < P && role[row] > 0) {
+          const float *ey = a.Ey + ((long)b * P + row) * D;
+          v0 += ld4(ey + 4 * g);
+          v1 += ld4(ey + 16 + 4 * g);
+        }
+        const int k = kidx[row];
+        if (k >= 0) {
+          *reinterpret_cast<f32x4 *>(Xk + k * ES + 4 * g) = v0;
+          *reinterpret_cast<f32x4 *>(Xk + k * ES + 16 + 4 * g) = v1;
+        }
       }
+      x[i][0] = v0;
+      x[i][1] = v1;
     }
-
+    STAMP_PHASE(1)   // x0 load
     for (int l = 0; l < a.L; ++l) {
       // ---- stream layer l's packed image into LDS ------------------------------------------------
       {
@@ -268,6 +556,7 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
         for (int i = tid; i < LAYER_FLOATS / 4; i += 256) dst[i] = src[i];
       }
       __syncthreads();   // weights + Xk visible
+      STAMP_PHASE(2)   // weight stream + barrier
       const float *prm = Wl + NFRAG_LAYER * FRAG;
 
       // ---- pre-pass: K^T (waves 0,1) and V (waves 2,3) of key tile kt = wave & 1 ------------------
@@ -312,101 +601,51 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
         }
       }
       __syncthreads();   // K/V fragments visible
+      STAMP_PHASE(3)   // pre-pass + barrier
 
-      // ---- main pass over this wave's token tiles --------------------------------------------------
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ti = wave + 4 * i;
-        if (ti < ntiles) {
-          const int row = 16 * ti + tok;
-          const bool isq = row < P && role[row] == 0;
-          const int nvalid = isq ? n_ak : n_ck;
-          const Frag xf = {x[i][0], x[i][1]};
-          // q = (Wq x + bq) / sqrt(hd)  (scale folded into the packed weights)
-          f32x4 q[2], o[2];
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            q[mt] = ld4(prm + PB_Q + 16 * mt + 4 * g);
-            mma_block(q[mt], ld_frag(Wl + (FQ + mt) * FRAG, lane), xf);
-            o[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // ---- main pass: local tiles (0,1) as a pair, then (2,3) as a pair or tile 2 alone ------------
+      {
+        const bool two_kt = n_ak > 16;
+        const bool publish = l + 1 < a.L;
+        auto nvis = [&](int row) { return (row < P && role[row] == 0) ? n_ak : n_ck; };
+        auto pub = [&](int row, const f32x4 &v0, const f32x4 &v1) {
+          const int k = (publish && row < N) ? kidx[row] : -1;
+          if (k >= 0) {
+            *reinterpret_cast<f32x4 *>(Xk + k * ES + 4 * g) = v0;
+            *reinterpret_cast<f32x4 *>(Xk + k * ES + 16 + 4 * g) = v1;
           }
-#pragma unroll
-          for (int h = 0; h < H; ++h) {
-            f32x4 s[2];
-            s[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            s[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            mma_half(s[0], ld4(Kb + (h * 2 + 0) * 256 + lane * 4), q[h >> 1]);
-            if (n_ak > 16) mma_half(s[1], ld4(Kb + (h * 2 + 1) * 256 + lane * 4), q[h >> 1]);
-            // masked softmax over the key axis (registers x lane groups)
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int key = 16 * kt + 4 * g + r;
-                s[kt][r] = key < nvalid ? s[kt][r] : -INFINITY;
-                mx = fmaxf(mx, s[kt][r]);
-              }
-            mx = group_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mx); sum += s[kt][r]; }
-            const float inv = 1.f / group_sum(sum);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-            // O^T[c, tok] += Vblk[c, key] P^T[key, tok] for the 8 channels of head h
-            const float *vf = Vb + ((h >> 1) * 2 + (h & 1)) * FRAG;
-            mma_half(o[h >> 1], ld4(vf + lane * 4), s[0]);
-            if (n_ak > 16) mma_half(o[h >> 1], ld4(vf + 256 + lane * 4), s[1]);
-          }
-          // x1 = LN1(x + Wo o + bo)
-          f32x4 x1[2];
-          {
-            const Frag of = {o[0], o[1]};
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-              x1[mt] = ld4(prm + PB_O + 16 * mt + 4 * g) + x[i][mt];
-              mma_block(x1[mt], ld_frag(Wl + (FO + mt) * FRAG, lane), of);
-            }
-          }
-          layer_norm(x1, prm + PLN1W, prm + PLN1B, g);
-          // x = LN2(x1 + W2 relu(W1 x1 + b1) + b2), hidden streamed in 32-wide chunks
-          {
-            const Frag x1f = {x1[0], x1[1]};
-            f32x4 y[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) y[mt] = ld4(prm + PB_2 + 16 * mt + 4 * g) + x1[mt];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-              Frag hf;
-              hf.lo = ld4(prm + PB_1 + 32 * kb + 4 * g);
-              hf.hi = ld4(prm + PB_1 + 32 * kb + 16 + 4 * g);
-              mma_block(hf.lo, ld_frag(Wl + (F1 + 2 * kb) * FRAG, lane), x1f);
-              mma_block(hf.hi, ld_frag(Wl + (F1 + 2 * kb + 1) * FRAG, lane), x1f);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { hf.lo[r] = fmaxf(hf.lo[r], 0.f); hf.hi[r] = fmaxf(hf.hi[r], 0.f); }
-#pragma unroll
-              for (int mt = 0; mt < 2; ++mt) mma_block(y[mt], ld_frag(Wl + (F2 + mt * 4 + kb) * FRAG, lane), hf);
-            }
-            layer_norm(y, prm + PLN2W, prm + PLN2B, g);
-            x[i][0] = y[0];
-            x[i][1] = y[1];
-          }
-          // key rows publish x^(l+1) for the next layer's pre-pass
-          if (l + 1 < a.L) {
-            const int k = kidx[row];
-            if (k >= 0) {
-              *reinterpret_cast<f32x4 *>(Xk + k * ES + 4 * g) = x[i][0];
-              *reinterpret_cast<f32x4 *>(Xk + k * ES + 16 + 4 * g) = x[i][1];
-            }
-          }
+        };
+        const int rowb = 16 * t0 + tok;
+        if (tcnt >= 2) {
+          f32x4 xp[2][2] = {{x[0][0], x[0][1]}, {x[1][0], x[1][1]}};
+          const int nv[2] = {nvis(rowb), nvis(rowb + 16)};
+          layer_tiles<2>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
+          pub(rowb, xp[0][0], xp[0][1]); pub(rowb + 16, xp[1][0], xp[1][1]);
+          x[0][0] = xp[0][0]; x[0][1] = xp[0][1]; x[1][0] = xp[1][0]; x[1][1] = xp[1][1];
+        } else if (tcnt == 1) {
+          f32x4 xp[1][2] = {{x[0][0], x[0][1]}};
+          const int nv[1] = {nvis(rowb)};
+          layer_tiles<1>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
+          pub(rowb, xp[0][0], xp[0][1]);
+          x[0][0] = xp[0][0]; x[0][1] = xp[0][1];
+        }
+        if (tcnt == 4) {
+          f32x4 xp[2][2] = {{x[2][0], x[2][1]}, {x[3][0], x[3][1]}};
+          const int nv[2] = {nvis(rowb + 32), nvis(rowb + 48)};
+          layer_tiles<2>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
+          pub(rowb + 32, xp[0][0], xp[0][1]); pub(rowb + 48, xp[1][0], xp[1][1]);
+          x[2][0] = xp[0][0]; x[2][1] = xp[0][1]; x[3][0] = xp[1][0]; x[3][1] = xp[1][1];
+        } else if (tcnt == 3) {
+          f32x4 xp[1][2] = {{x[2][0], x[2][1]}};
+          const int nv[1] = {nvis(rowb + 32)};
+          layer_tiles<1>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
+          pub(rowb + 32, xp[0][0], xp[0][1]);
+          x[2][0] = xp[0][0]; x[2][1] = xp[0][1];
         }
       }
+      STAMP_PHASE(4)   // main pass (this wave's tiles)
       __syncthreads();   // everyone done with this layer's weights / K / V
+      STAMP_PHASE(5)   // wait for the slowest wave
     }
 
     // ---- acquisition head (model/head.py:27-33) on every tile; z of the target rows -> Zt --------
@@ -416,33 +655,42 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
       for (int i = tid; i < HEAD_FLOATS / 4; i += 256) dst[i] = src[i];
     }
     __syncthreads();
+    STAMP_PHASE(6)   // head image stream
     {
-      const float *hb1 = Wl + 8 * FRAG, *hw2 = hb1 + 128, *hb2 = hw2 + 128;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ti = wave + 4 * i;
-        if (ti < ntiles) {
-          const int row = 16 * ti + tok;
-          const Frag zf = {x[i][0], x[i][1]};
-          float part = 0.f;
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt) {
-            f32x4 hdn = ld4(hb1 + 16 * mt + 4 * g);
-            mma_block(hdn, ld_frag(Wl + mt * FRAG, lane), zf);
-            const f32x4 w2 = ld4(hw2 + 16 * mt + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part = fmaf(fmaxf(hdn[r], 0.f), w2[r], part);
-          }
-          part = group_sum(part) + hb2[0];
-          if (g == 0) logit[row] = part;
-          if (row >= P && row < N) {
-            *reinterpret_cast<f32x4 *>(Zt + (row - P) * ES + 4 * g) = x[i][0];
-            *reinterpret_cast<f32x4 *>(Zt + (row - P) * ES + 16 + 4 * g) = x[i][1];
-          }
+      auto emit = [&](int row, float lgt, const f32x4 &v0, const f32x4 &v1) {
+        if (g == 0 && row < MAXROWS) logit[row] = lgt;
+        if (row >= P && row < N) {
+          *reinterpret_cast<f32x4 *>(Zt + (row - P) * ES + 4 * g) = v0;
+          *reinterpret_cast<f32x4 *>(Zt + (row - P) * ES + 16 + 4 * g) = v1;
         }
+      };
+      const int rowb = 16 * t0 + tok;
+      if (tcnt >= 2) {
+        const f32x4 zp[2][2] = {{x[0][0], x[0][1]}, {x[1][0], x[1][1]}};
+        float lg[2];
+        acq_tiles<2>(zp, Wl, lane, g, lg);
+        emit(rowb, lg[0], zp[0][0], zp[0][1]); emit(rowb + 16, lg[1], zp[1][0], zp[1][1]);
+      } else if (tcnt == 1) {
+        const f32x4 zp[1][2] = {{x[0][0], x[0][1]}};
+        float lg[1];
+        acq_tiles<1>(zp, Wl, lane, g, lg);
+        emit(rowb, lg[0], zp[0][0], zp[0][1]);
+      }
+      if (tcnt == 4) {
+        const f32x4 zp[2][2] = {{x[2][0], x[2][1]}, {x[3][0], x[3][1]}};
+        float lg[2];
+        acq_tiles<2>(zp, Wl, lane, g, lg);
+        emit(rowb + 32, lg[0], zp[0][0], zp[0][1]); emit(rowb + 48, lg[1], zp[1][0], zp[1][1]);
+      } else if (tcnt == 3) {
+        const f32x4 zp[1][2] = {{x[2][0], x[2][1]}};
+        float lg[1];
+        acq_tiles<1>(zp, Wl, lane, g, lg);
+        emit(rowb + 32, lg[0], zp[0][0], zp[0][1]);
       }
     }
+    STAMP_PHASE(7)   // acquisition MLP
     __syncthreads();
+    STAMP_PHASE(8)   // barrier after acquisition
 
     if (wave == 0) {
       // ---- softmax over the remaining queries + design selection (model/head.py:347-362) ---------
@@ -522,8 +770,7 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
         if (a.log_prob) a.log_prob[o] = logf(val);
         role[sl] = order;
       }
-      // the chosen point joins the context: E[slot] += y-embedding (embedder.py:156)
-      if (lane < D) E[sl * ES + lane] += a.Ey[((long)b * P + sl) * D + lane];
+      // the chosen point joins the context: from the next step on its row adds Ey (embedder.py:156)
     } else {
       // ---- GMM heads on the target rows (model/head.py:172-177), fp32 FMA: n_t rows are few -----
       for (int c = wave - 1; c < a.C; c += 3) {
@@ -554,7 +801,9 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
         }
       }
     }
+    STAMP_PHASE(9)   // selection (wave 0) / GMM heads (waves 1-3)
     __syncthreads();
+    STAMP_PHASE(10)  // barrier after selection / GMM
 
     // ---- GMM parameter maps + compute_ll (head.py:176-177, utils/eval.py:200-207) -------------------
     if (wave == 1) {
@@ -585,6 +834,7 @@ __global__ __launch_bounds__(256, 1) void rollout_f32_kernel(RolloutArgs a) {
     }
     // (the barrier at the top of the next step's key-list build orders role / E updates)
     __syncthreads();
+    STAMP_PHASE(11)  // GMM epilogue + barrier
   }
   for (int r = tid; r < P; r += 256) a.role[(long)b * P + r] = role[r];
 }

@@ -178,6 +178,11 @@ size_t aline_eig_finalize_workspace_bytes(int64_t L1, int B);
 int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc, void *ws,
                        size_t ws_bytes, void *stream);
 
+/* --- diagnostics ----------------------------------------------------------------------------- */
+/* Byte offset, inside a rollout workspace, of the per-phase cycle stamps the fused rollout kernel
+ * writes when the process runs with ALINE_FUSED_STAMPS=1 (diagnostic instantiation only). */
+size_t aline_debug_stamps_offset(const aline_model *m, const aline_rollout *r);
+
 #ifdef __cplusplus
 }
 #endif
