@@ -25,13 +25,15 @@ inline size_t align_up(size_t v, size_t a = 64) { return (v + a - 1) / a * a; }
     if (_rc != 0) return _rc; \
   } while (0)
 
+constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidden = rows x C*F floats)
+
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
-Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool query_gmm) {
+Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool query_gmm, int T = 0) {
   Plan p{};
   const size_t N = (size_t)P + n_td + m.n_theta, M = (size_t)B * N, d = m.d, F = m.F;
   const size_t n_t = (size_t)n_td + m.n_theta;
@@ -49,6 +51,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
     p.qgmm_chunk = (int)std::max<size_t>(1, std::min<size_t>(B, budget / per_ep));
     hid = std::max(hid, per_ep * p.qgmm_chunk);
   }
+  if (T > 0) hid = std::max(hid, std::min((size_t)T * B * n_t, kGmmChunkRows) * Cc * F);
   p.Hid = take(hid);
   p.X = take(M * d);
   p.X1 = take(M * d);
@@ -59,6 +62,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   p.scalar = take(64);
   p.Wpack = take((size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS);
   p.Stamps = take(512);   // diagnostic stamps of the fused kernel (8 x 16 x u64)
+  p.Ztg = take((size_t)T * B * n_t * d);   // fused rollout: target-row encodings of all steps
   p.total = off;
   return p;
 }
@@ -242,6 +246,30 @@ int do_gmm(const Ctx &c, const float *Z, int b0, int nb, int row_off, int rows_p
   f.R_out = 1; f.G_out = 1; f.off_out = 0;
   f.value = value ? value + o : nullptr;
   f.ll = (ll && value) ? ll + o : nullptr;
+  hipLaunchKernelGGL(gmm_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, c.st, f);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// GMM head on a dense [rows, d] matrix of token encodings; `value` (if any) is indexed modulo
+// value_mod (the same targets are scored at every step of a rollout).
+int do_gmm_rows(const Ctx &c, const float *Zrows, int rows, float *mean, float *sd, float *wgt,
+                const float *value, float *ll, long row0, long value_mod) {
+  const aline_model &m = *c.m;
+  if (rows <= 0) return ALINE_OK;
+  float *hid = c.at(c.pl.Hid);
+  GemmArgs a = gemm_args(Zrows, m.d, nullptr, nullptr, m.d, hid, m.C * m.F, rows, m.F, m.d, true);
+  a.col_per_group = m.F;
+  for (int k = 0; k < m.C; ++k) { a.W[k] = m.gmm_w1[k]; a.bias[k] = m.gmm_b1[k]; }
+  TRY(launch_gemm(m.precision, a, m.C, c.st));
+  CHECK_LAUNCH();
+  GmmFinishArgs f{};
+  f.hid = hid; f.rows = rows; f.C = m.C; f.F = m.F; f.std_min = m.std_min;
+  for (int k = 0; k < m.C; ++k) { f.w2[k] = m.gmm_w2[k]; f.b2[k] = m.gmm_b2[k]; }
+  f.mean = mean; f.std = sd; f.weight = wgt;
+  f.R_out = 1; f.G_out = 1; f.off_out = 0;
+  f.value = value; f.ll = (ll && value) ? ll : nullptr;
+  f.value_row0 = row0; f.value_mod = value_mod;
   hipLaunchKernelGGL(gmm_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, c.st, f);
   CHECK_LAUNCH();
   return ALINE_OK;
@@ -431,7 +459,7 @@ static int rollout_ctx(const aline_model *m, const aline_rollout *r, void *ws, s
   c.g.N = c.g.P + c.g.n_td + c.g.n_th; c.g.n_ctx = r->n_ctx0; c.g.role = r->role;
   c.g.tmask = r->target_mask;
   c.m = m;
-  c.pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false);
+  c.pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T);
   if (ws_bytes < c.pl.total * sizeof(float)) return ALINE_EWORKSPACE;
   c.ws = static_cast<float *>(ws);
   c.st = static_cast<hipStream_t>(stream);
@@ -440,7 +468,7 @@ static int rollout_ctx(const aline_model *m, const aline_rollout *r, void *ws, s
 
 size_t aline_rollout_workspace_bytes(const aline_model *m, const aline_rollout *r) {
   if (!m || !r || validate_model(*m, 0) != 0) return 0;
-  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false).total * sizeof(float);
+  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).total * sizeof(float);
 }
 
 int aline_rollout_init(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
@@ -498,7 +526,7 @@ static bool fused_eligible(const aline_model &m, const aline_rollout &r) {
   if (m.precision != ALINE_PREC_F32) return false;
   if (m.d != fused::D || m.F != fused::F || m.H != fused::H || m.time_token) return false;
   if (m.embedding_type != ALINE_EMB_THETA || r.n_target_data != 0) return false;
-  if (m.n_theta < 1 || m.n_theta > fused::MAXNT || r.P + m.n_theta > fused::MAXROWS) return false;
+  if (m.n_theta < 1 || m.n_theta > fused::MAXNT || r.P + m.n_theta > 16 * fused::WPE * fused::MAXT) return false;
   if (r.n_ctx0 + r.T - 1 + m.n_theta > fused::NKMAX) return false;
   return true;
 }
@@ -537,20 +565,31 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   a.role = r->role; a.idx = r->idx; a.slot = r->slot; a.log_prob = r->log_prob;
   a.target_ll = r->target_ll; a.zt = r->zt;
   a.post_mean = r->post_mean; a.post_std = r->post_std; a.post_weight = r->post_weight;
-  a.stagger_sleeps = getenv("ALINE_FUSED_STAGGER") ? atoi(getenv("ALINE_FUSED_STAGGER")) : 16;
+  a.ztg = c.at(c.pl.Ztg);
   // ALINE_FUSED_STAMPS=1 selects the diagnostic (s_memtime-stamped) instantiation; the stamps land
   // in the tail of the workspace scalar block and are never read by product code.
   if (getenv("ALINE_FUSED_STAMPS")) {
     a.stamps = reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::LDS_BYTES);
-    hipLaunchKernelGGL(fused::rollout_f32_kernel<true>, dim3(r->B), dim3(256), fused::LDS_BYTES, c.st, a);
+    hipLaunchKernelGGL(fused::rollout_f32_kernel<true>, dim3((r->B + fused::EPW - 1) / fused::EPW), dim3(fused::NTHREADS), fused::LDS_BYTES, c.st, a);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::LDS_BYTES);
-    hipLaunchKernelGGL(fused::rollout_f32_kernel<false>, dim3(r->B), dim3(256), fused::LDS_BYTES, c.st, a);
+    hipLaunchKernelGGL(fused::rollout_f32_kernel<false>, dim3((r->B + fused::EPW - 1) / fused::EPW), dim3(fused::NTHREADS), fused::LDS_BYTES, c.st, a);
   }
   CHECK_LAUNCH();
+  // GMM posterior + compute_ll of all T steps on the saved target-row encodings [T*B*n_t, d]
+  if (r->post_mean || r->post_std || r->post_weight || r->target_ll) {
+    const long rows = (long)r->T * r->B * m->n_theta;
+    for (long r0 = 0; r0 < rows; r0 += (long)kGmmChunkRows) {
+      const int nr = (int)std::min<long>(kGmmChunkRows, rows - r0);
+      TRY(do_gmm_rows(c, c.at(c.pl.Ztg) + r0 * m->d, nr, r->post_mean ? r->post_mean + r0 * m->C : nullptr,
+                      r->post_std ? r->post_std + r0 * m->C : nullptr,
+                      r->post_weight ? r->post_weight + r0 * m->C : nullptr, r->target_all,
+                      r->target_ll ? r->target_ll + r0 : nullptr, r0, (long)r->B * m->n_theta));
+    }
+  }
   return ALINE_OK;
 }
 
@@ -635,5 +674,5 @@ int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc
 // Diagnostic only: byte offset of the stamp block inside a rollout workspace (tools/stamps.py).
 extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return 0;
-  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false).Stamps * sizeof(float);
+  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).Stamps * sizeof(float);
 }

@@ -431,20 +431,50 @@ struct RolloutArgs {
   float *target_ll;                                   // [T, B, n_th]
   float *zt;                                          // [T, B, P - n_ctx0] or null
   float *post_mean, *post_std, *post_weight;          // [T, B, n_th, C] or null
-  int stagger_sleeps;           // s_sleep(127) iterations (8128 cycles each) for odd residency slots
+  float *ztg;                   // [T, B, n_th, 32] encoder outputs of the target rows (GMM runs after the loop)
   unsigned long long *stamps;   // diagnostic build only: per-phase cycle sums [8 waves x 16]
 };
 
-// LDS carve (floats).  Everything lives in one dynamic array (16-byte aligned carve offsets).
-constexpr int L_W = 0;                               // layer image / head image
-constexpr int L_KB = L_W + LAYER_FLOATS;             // Kblk: 8 fragments x 256 floats (one sub-plane each)
-constexpr int L_VB = L_KB + 8 * 256;                 // Vblk: 4 fragments x 512 floats
-constexpr int L_XK = L_VB + 4 * FRAG;                // Xk [NKMAX][ES]
-constexpr int L_ZT = L_XK + NKMAX * ES;              // Zt [MAXNT][ES]
-constexpr int L_LOGIT = L_ZT + MAXNT * ES;           // logits / probs [MAXROWS]
-constexpr int L_RAW = L_LOGIT + MAXROWS;             // GMM raw outputs [MAXNT][16][4]
-constexpr int L_INT = L_RAW + MAXNT * 16 * 4;        // ints: role[MAXROWS], kidx[MAXROWS], qslot[MAXROWS], misc[16]
-constexpr int L_TOTAL = L_INT + 3 * MAXROWS + 16;
+// ---- wave-wide reductions on the VALU (DPP row ops + row/half swaps), no LDS crossbar -------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wsum(float v) {     // every lane gets the 64-lane sum
+  v += dpp_f<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);    // row_half_mirror
+  v += dpp_f<0x140>(v);    // row_mirror  -> 16-lane row sums
+  return group_sum(v);     // across the four rows
+}
+__device__ __forceinline__ float wmax(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return group_max(v);
+}
+
+// Workgroup geometry: 12 waves = 4 episode lanes x 3 waves.  Wave w serves episode lane e = w & 3 as
+// its sub-wave j = w >> 2, so the three waves of an episode share one SIMD (waves i, i + 4, i + 8) and
+// every SIMD carries one whole episode: ntiles tiles split 5/4/4 -> 13 tiles per SIMD, balanced.
+// With B = 1000 episodes this is 250 workgroups: the whole batch is resident at once on 256 CUs.
+constexpr int EPW = 4, WPE = 3, NTHREADS = EPW * WPE * 64, ETH = WPE * 64;
+constexpr int MAXT = 5;   // tiles per wave (at most 15 tiles / 3 waves: N <= 240 rows)
+
+// LDS carve (floats).  One dynamic array, 16-byte aligned offsets.
+//   [0, LAYER_FLOATS)                 current layer image / head image (shared by the 4 episodes)
+//   per episode (EP_FLOATS each):
+//     KB  8 fragments x 256           K head-block fragments of the current layer
+//     VB  4 fragments x 512           V head-block fragments
+//         (head phase reuses KB: logits[256])
+//     XK  [NKMAX][ES]                 inputs of the key rows for the next pre-pass
+//     INT role u8[256] | kidx i8[256] | qslot u8[256] | misc int[16]
+constexpr int EP_KB = 0, EP_VB = EP_KB + 8 * 256, EP_XK = EP_VB + 4 * FRAG, EP_INT = EP_XK + NKMAX * ES;
+constexpr int EP_FLOATS = EP_INT + (3 * MAXROWS) / 4 + 16;
+constexpr int HP_LOGIT = 0, HP_ZT = HP_LOGIT + MAXROWS, HP_RAW = HP_ZT + MAXNT * ES;   // inside KB
+static_assert(HP_RAW + MAXNT * 16 * 4 <= 8 * 256, "head-phase scratch must fit in the K fragment area");
+constexpr int L_TOTAL = LAYER_FLOATS + EPW * EP_FLOATS;
 constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 4;
 
 // Diagnostic stamps (template STAMP = true builds only; never in the shipped instantiation): wave w
@@ -458,82 +488,85 @@ constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 4;
   }
 
 template <bool STAMP>
-__global__ __launch_bounds__(256, 2) void rollout_f32_kernel(RolloutArgs a) {
+__global__ __launch_bounds__(NTHREADS, 3) void rollout_f32_kernel(RolloutArgs a) {
   unsigned long long t_prev = 0;
   if constexpr (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory"); }
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *Wl = lds + L_W, *Kb = lds + L_KB, *Vb = lds + L_VB, *Xk = lds + L_XK,
-        *Zt = lds + L_ZT, *logit = lds + L_LOGIT, *raw = lds + L_RAW;
-  int *role = reinterpret_cast<int *>(lds + L_INT);
-  int *kidx = role + MAXROWS, *qslot = kidx + MAXROWS, *misc = qslot + MAXROWS;
-  // misc: 0 n_ck, 1 n_ak, 2.. wave counts
-
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e = wave & 3, j = wave >> 2, tid3 = j * 64 + lane;
   const int tok = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x * EPW + e;
+  const bool valid = b < a.B;
+
+  float *Wl = lds;
+  float *ep = lds + LAYER_FLOATS + e * EP_FLOATS;
+  float *Kb = ep + EP_KB, *Vb = ep + EP_VB, *Xk = ep + EP_XK;
+  float *logit = Kb + HP_LOGIT;
+  unsigned char *role = reinterpret_cast<unsigned char *>(ep + EP_INT);   // 0 query, k>0 k-th context, 255 n/a
+  signed char *kidx = reinterpret_cast<signed char *>(role + MAXROWS);
+  unsigned char *qslot = role + 2 * MAXROWS;
+  int *misc = reinterpret_cast<int *>(role + 3 * MAXROWS);
+  float *fmisc = reinterpret_cast<float *>(misc + 8);
+  // misc: 0 n_ck, 1 n_ak, 2..4 per-wave counts, 5 nq, 6 choice;  fmisc: 0..2 per-wave partials, 3 total
+
   const int P = a.P, n_th = a.n_th, N = P + n_th;
   const int ntiles = (N + 15) >> 4;
   const int zw = P - a.n_ctx0;
-  // Balanced contiguous tile ranges: wave wv owns tiles [t0, t0 + tcnt), tcnt = ntiles/4 (+1 for the
-  // first ntiles%4 waves).  The waves that own the extra tile rotate with the workgroup (and with its
-  // residency slot) so that co-resident workgroups do not stack their heavy waves on one SIMD.
-  const int wv = (wave + blockIdx.x + (blockIdx.x >> 8)) & 3;
-  const int tcnt = ntiles / 4 + (wv < (ntiles & 3) ? 1 : 0);
-  const int t0 = wv * (ntiles / 4) + min(wv, ntiles & 3);
+  const int tcnt = ntiles / WPE + (j < (ntiles % WPE) ? 1 : 0);
+  const int t0 = j * (ntiles / WPE) + min(j, ntiles % WPE);
 
   // ---- episode state: roles.  The step-invariant embeddings stay in HBM/L2 (Ex, Ey: 26 KB per
   // episode and step): X^(0)[row] = Ex[row] (+ Ey[row] once the point has joined the context).
-  for (int r = tid; r < MAXROWS; r += 256) role[r] = r < P ? (r < a.n_ctx0 ? r + 1 : 0) : -1;
-  for (int i = tid; i < NKMAX * ES; i += 256) Xk[i] = 0.f;
+  for (int r = tid3; r < MAXROWS; r += ETH) role[r] = r < P ? (r < a.n_ctx0 ? r + 1 : 0) : 255;
+  for (int i = tid3; i < NKMAX * ES; i += ETH) Xk[i] = 0.f;
   __syncthreads();
-
-  // Two workgroups share a CU (and its matrix pipes).  They run the same program, so without help
-  // they would sit in the MFMA-free phases (selection, GMM, weight streaming) at the same time.
-  // Workgroups of the second residency slot (dispatch is round-robin over 256 CUs) start half a
-  // step late, so one workgroup's MFMA-dense layer passes cover the other's scalar phases.  Speed
-  // only: nothing depends on the placement.
-  if (a.stagger_sleeps > 0 && ((blockIdx.x >> 8) & 1)) {
-    for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   for (int t = 0; t < a.T; ++t) {
     // ---- key list: context slots in slot order, then the selected targets ----------------------
+    // rows tid3 and tid3 + 192; chunks in row order: (j=0,p=0) (1,0) (2,0) (0,1)
     {
-      const int r = tid;                                   // MAXROWS == blockDim
-      const bool ck = r < P && role[r] > 0;
-      const unsigned long long bal = __ballot(ck);
-      if (lane == 0) misc[2 + wave] = __popcll(bal);
+      const int r0 = tid3, r1 = tid3 + ETH;
+      const bool c0 = r0 < P && role[r0] != 0 && role[r0] != 255;
+      const bool c1 = r1 < P && role[r1] != 0 && role[r1] != 255;
+      const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1);
+      if (lane == 0) { misc[2 + j] = __popcll(b0); if (j == 0) misc[5] = __popcll(b1); }
       __syncthreads();
-      int off = 0;
-      for (int w = 0; w < wave; ++w) off += misc[2 + w];
-      const int nck = misc[2] + misc[3] + misc[4] + misc[5];
-      int k = ck ? off + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
-      if (r >= P && r < N) {
+      const int cnt0 = misc[2], cnt1 = misc[3], cnt2 = misc[4], cnt3 = misc[5];
+      const int nck = cnt0 + cnt1 + cnt2 + cnt3;
+      const int off0 = j == 0 ? 0 : (j == 1 ? cnt0 : cnt0 + cnt1);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      int k0 = c0 ? off0 + __popcll(b0 & below) : -1;
+      int k1 = c1 ? cnt0 + cnt1 + cnt2 + __popcll(b1 & below) : -1;
+      auto target_key = [&](int r) {
         int nsel = 0, mine = -1;
-        for (int j = 0; j < n_th; ++j) {
-          const bool sel = !a.tmask || a.tmask[j];
-          if (j == r - P && sel) mine = nsel;
+        for (int q = 0; q < n_th; ++q) {
+          const bool sel = !a.tmask || a.tmask[q];
+          if (q == r - P && sel) mine = nsel;
           nsel += sel ? 1 : 0;
         }
-        if (mine >= 0) k = nck + mine;
         if (r == P) { misc[0] = nck; misc[1] = nck + nsel; }
-      }
-      kidx[r] = k;
+        return mine >= 0 ? nck + mine : -1;
+      };
+      if (r0 >= P && r0 < N) k0 = target_key(r0);
+      if (r1 >= P && r1 < N) k1 = target_key(r1);
+      if (r0 < MAXROWS) kidx[r0] = (signed char)k0;
+      if (r1 < MAXROWS) kidx[r1] = (signed char)k1;
       __syncthreads();
     }
     const int n_ck = misc[0], n_ak = misc[1];
     STAMP_PHASE(0)   // key list
 
-    // ---- X^(0): token tiles of this wave from E (tile ti = wave + 4 i) ----------------------------
-    f32x4 x[4][2];   // [local tile][acc tile]
+    // ---- X^(0): this wave's token tiles --------------------------------------------------------------
+    f32x4 x[MAXT][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MAXT; ++i) {
       const int row = 16 * (t0 + i) + tok;
       f32x4 v0 = zero4(), v1 = zero4();
-      if (i < tcnt && row < N) {
+      if (valid && i < tcnt && row < N) {
         const float *src = row < P ? a.Ex + ((long)b * P + row) * D : a.theta_tokens + (long)(row - P) * D;
         v0 = ld4(src + 4 * g);
         v1 = ld4(src + 16 + 4 * g);
-        if (row < P && role[row] > 0) {
+        if (row < P && role[row] != 0) {
           const float *ey = a.Ey + ((long)b * P + row) * D;
           v0 += ld4(ey + 4 * g);
           v1 += ld4(ey + 16 + 4 * g);
@@ -548,26 +581,32 @@ __global__ __launch_bounds__(256, 2) void rollout_f32_kernel(RolloutArgs a) {
       x[i][1] = v1;
     }
     STAMP_PHASE(1)   // x0 load
+
     for (int l = 0; l < a.L; ++l) {
-      // ---- stream layer l's packed image into LDS ------------------------------------------------
+      // ---- stream layer l's packed image into LDS (all 768 threads) ------------------------------
       {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (long)l * LAYER_FLOATS);
         f32x4 *dst = reinterpret_cast<f32x4 *>(Wl);
-        for (int i = tid; i < LAYER_FLOATS / 4; i += 256) dst[i] = src[i];
+        f32x4 buf[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const int q = tid + i * NTHREADS; if (q < LAYER_FLOATS / 4) buf[i] = src[q]; }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const int q = tid + i * NTHREADS; if (q < LAYER_FLOATS / 4) dst[q] = buf[i]; }
       }
       __syncthreads();   // weights + Xk visible
       STAMP_PHASE(2)   // weight stream + barrier
       const float *prm = Wl + NFRAG_LAYER * FRAG;
 
-      // ---- pre-pass: K^T (waves 0,1) and V (waves 2,3) of key tile kt = wave & 1 ------------------
-      {
-        const int kt = wave & 1;
-        if (kt == 0 || n_ak > 16) {
+      // ---- pre-pass: K^T / V of the key tiles.  items: 0 K kt0, 1 V kt0, 2 K kt1, 3 V kt1 ------------
+      if (valid) {
+        const int nitems = n_ak > 16 ? 4 : 2;
+        for (int it = j; it < nitems; it += WPE) {
+          const int kt = it >> 1;
           const int key = 16 * kt + tok;
           Frag xf;
           xf.lo = ld4(Xk + key * ES + 4 * g);
           xf.hi = ld4(Xk + key * ES + 16 + 4 * g);
-          if (wave < 2) {
+          if ((it & 1) == 0) {
             // K^T[c, key] = Wk x_key + bk : rows = channels
             f32x4 kacc[2];
 #pragma unroll
@@ -578,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void rollout_f32_kernel(RolloutArgs a) {
             // head-block fragments: head h uses sub-plane h>>1, lanes with (g>>1) == (h&1)
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-              f32x4 v = ((g >> 1) == (h & 1)) ? kacc[h >> 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+              f32x4 v = ((g >> 1) == (h & 1)) ? kacc[h >> 1] : zero4();
               *reinterpret_cast<f32x4 *>(Kb + (h * 2 + kt) * 256 + lane * 4) = v;
             }
           } else {
@@ -593,9 +632,9 @@ __global__ __launch_bounds__(256, 2) void rollout_f32_kernel(RolloutArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                f32x4 v = ((tok >> 3) == e) ? vacc[nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(Vb + (nt * 2 + e) * FRAG + kt * 256 + lane * 4) = v;
+              for (int hh = 0; hh < 2; ++hh) {
+                f32x4 v = ((tok >> 3) == hh) ? vacc[nt] : zero4();
+                *reinterpret_cast<f32x4 *>(Vb + (nt * 2 + hh) * FRAG + kt * 256 + lane * 4) = v;
               }
           }
         }
@@ -603,44 +642,27 @@ __global__ __launch_bounds__(256, 2) void rollout_f32_kernel(RolloutArgs a) {
       __syncthreads();   // K/V fragments visible
       STAMP_PHASE(3)   // pre-pass + barrier
 
-      // ---- main pass: local tiles (0,1) as a pair, then (2,3) as a pair or tile 2 alone ------------
+      // ---- main pass: this wave's tiles, one at a time (registers rotate so that every index is static)
       {
         const bool two_kt = n_ak > 16;
         const bool publish = l + 1 < a.L;
-        auto nvis = [&](int row) { return (row < P && role[row] == 0) ? n_ak : n_ck; };
-        auto pub = [&](int row, const f32x4 &v0, const f32x4 &v1) {
-          const int k = (publish && row < N) ? kidx[row] : -1;
-          if (k >= 0) {
-            *reinterpret_cast<f32x4 *>(Xk + k * ES + 4 * g) = v0;
-            *reinterpret_cast<f32x4 *>(Xk + k * ES + 16 + 4 * g) = v1;
-          }
-        };
-        const int rowb = 16 * t0 + tok;
-        if (tcnt >= 2) {
-          f32x4 xp[2][2] = {{x[0][0], x[0][1]}, {x[1][0], x[1][1]}};
-          const int nv[2] = {nvis(rowb), nvis(rowb + 16)};
-          layer_tiles<2>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
-          pub(rowb, xp[0][0], xp[0][1]); pub(rowb + 16, xp[1][0], xp[1][1]);
-          x[0][0] = xp[0][0]; x[0][1] = xp[0][1]; x[1][0] = xp[1][0]; x[1][1] = xp[1][1];
-        } else if (tcnt == 1) {
+#pragma unroll 1
+        for (int it = 0; it < MAXT; ++it) {
           f32x4 xp[1][2] = {{x[0][0], x[0][1]}};
-          const int nv[1] = {nvis(rowb)};
-          layer_tiles<1>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
-          pub(rowb, xp[0][0], xp[0][1]);
-          x[0][0] = xp[0][0]; x[0][1] = xp[0][1];
-        }
-        if (tcnt == 4) {
-          f32x4 xp[2][2] = {{x[2][0], x[2][1]}, {x[3][0], x[3][1]}};
-          const int nv[2] = {nvis(rowb + 32), nvis(rowb + 48)};
-          layer_tiles<2>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
-          pub(rowb + 32, xp[0][0], xp[0][1]); pub(rowb + 48, xp[1][0], xp[1][1]);
-          x[2][0] = xp[0][0]; x[2][1] = xp[0][1]; x[3][0] = xp[1][0]; x[3][1] = xp[1][1];
-        } else if (tcnt == 3) {
-          f32x4 xp[1][2] = {{x[2][0], x[2][1]}};
-          const int nv[1] = {nvis(rowb + 32)};
-          layer_tiles<1>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
-          pub(rowb + 32, xp[0][0], xp[0][1]);
-          x[2][0] = xp[0][0]; x[2][1] = xp[0][1];
+          if (valid && it < tcnt) {
+            const int row = 16 * (t0 + it) + tok;
+            const int nv[1] = {(row < P && role[row] == 0) ? n_ak : n_ck};
+            layer_tiles<1>(xp, Wl, prm, Kb, Vb, lane, g, nv, two_kt);
+            const int k = (publish && row < N) ? kidx[row] : -1;
+            if (k >= 0) {   // key rows publish x^(l+1) for the next layer's pre-pass
+              *reinterpret_cast<f32x4 *>(Xk + k * ES + 4 * g) = xp[0][0];
+              *reinterpret_cast<f32x4 *>(Xk + k * ES + 16 + 4 * g) = xp[0][1];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i + 1 < MAXT; ++i) { x[i][0] = x[i + 1][0]; x[i][1] = x[i + 1][1]; }
+          x[MAXT - 1][0] = xp[0][0];
+          x[MAXT - 1][1] = xp[0][1];
         }
       }
       STAMP_PHASE(4)   // main pass (this wave's tiles)
@@ -652,191 +674,139 @@ __global__ __launch_bounds__(256, 2) void rollout_f32_kernel(RolloutArgs a) {
     {
       const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (long)a.L * LAYER_FLOATS);
       f32x4 *dst = reinterpret_cast<f32x4 *>(Wl);
-      for (int i = tid; i < HEAD_FLOATS / 4; i += 256) dst[i] = src[i];
+      for (int i = tid; i < HEAD_FLOATS / 4; i += NTHREADS) dst[i] = src[i];
     }
     __syncthreads();
     STAMP_PHASE(6)   // head image stream
-    {
-      auto emit = [&](int row, float lgt, const f32x4 &v0, const f32x4 &v1) {
-        if (g == 0 && row < MAXROWS) logit[row] = lgt;
+#pragma unroll 1
+    for (int it = 0; it < MAXT; ++it) {
+      const f32x4 zp[1][2] = {{x[0][0], x[0][1]}};
+      if (valid && it < tcnt) {
+        const int row = 16 * (t0 + it) + tok;
+        float lg[1];
+        acq_tiles<1>(zp, Wl, lane, g, lg);
+        if (g == 0 && row < MAXROWS) logit[row] = lg[0];
         if (row >= P && row < N) {
-          *reinterpret_cast<f32x4 *>(Zt + (row - P) * ES + 4 * g) = v0;
-          *reinterpret_cast<f32x4 *>(Zt + (row - P) * ES + 16 + 4 * g) = v1;
+          float *zo = a.ztg + (((long)t * a.B + b) * n_th + (row - P)) * D;
+          *reinterpret_cast<f32x4 *>(zo + 4 * g) = zp[0][0];
+          *reinterpret_cast<f32x4 *>(zo + 16 + 4 * g) = zp[0][1];
         }
-      };
-      const int rowb = 16 * t0 + tok;
-      if (tcnt >= 2) {
-        const f32x4 zp[2][2] = {{x[0][0], x[0][1]}, {x[1][0], x[1][1]}};
-        float lg[2];
-        acq_tiles<2>(zp, Wl, lane, g, lg);
-        emit(rowb, lg[0], zp[0][0], zp[0][1]); emit(rowb + 16, lg[1], zp[1][0], zp[1][1]);
-      } else if (tcnt == 1) {
-        const f32x4 zp[1][2] = {{x[0][0], x[0][1]}};
-        float lg[1];
-        acq_tiles<1>(zp, Wl, lane, g, lg);
-        emit(rowb, lg[0], zp[0][0], zp[0][1]);
       }
-      if (tcnt == 4) {
-        const f32x4 zp[2][2] = {{x[2][0], x[2][1]}, {x[3][0], x[3][1]}};
-        float lg[2];
-        acq_tiles<2>(zp, Wl, lane, g, lg);
-        emit(rowb + 32, lg[0], zp[0][0], zp[0][1]); emit(rowb + 48, lg[1], zp[1][0], zp[1][1]);
-      } else if (tcnt == 3) {
-        const f32x4 zp[1][2] = {{x[2][0], x[2][1]}};
-        float lg[1];
-        acq_tiles<1>(zp, Wl, lane, g, lg);
-        emit(rowb + 32, lg[0], zp[0][0], zp[0][1]);
-      }
+#pragma unroll
+      for (int i = 0; i + 1 < MAXT; ++i) { x[i][0] = x[i + 1][0]; x[i][1] = x[i + 1][1]; }
+      x[MAXT - 1][0] = zp[0][0];
+      x[MAXT - 1][1] = zp[0][1];
     }
     STAMP_PHASE(7)   // acquisition MLP
     __syncthreads();
     STAMP_PHASE(8)   // barrier after acquisition
 
-    if (wave == 0) {
-      // ---- softmax over the remaining queries + design selection (model/head.py:347-362) ---------
-      int nq = 0;
-      for (int c0 = 0; c0 < P; c0 += 64) {
-        const int p = c0 + lane;
-        const bool isq = p < P && role[p] == 0;
-        const unsigned long long bal = __ballot(isq);
-        if (isq) qslot[nq + __popcll(bal & ((1ull << lane) - 1ull))] = p;
-        nq += __popcll(bal);
-      }
-      float mx = -INFINITY;
-      for (int i = lane; i < nq; i += 64) mx = fmaxf(mx, logit[qslot[i]]);
-      mx = wave_max(mx);
-      float pv[4], sum = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = lane + 64 * c;
-        pv[c] = i < nq ? __expf(logit[qslot[i]] - mx) : 0.f;
-        sum += pv[c];
-      }
-      sum = wave_sum(sum);
-      const float inv = 1.f / sum;
-      float *prob = logit;   // compacted probabilities overwrite the logits (all reads done above)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        pv[c] *= inv;
-        const int i = lane + 64 * c;
-        if (i < nq) prob[i] = pv[c];
-      }
-      if (a.zt) {
+    // ---- softmax over the remaining queries + design selection (model/head.py:347-362), by the three
+    // waves of the episode: thread tid3 owns slots tid3 and tid3 + 192 --------------------------------
+    {
+      const int s0 = tid3, s1 = tid3 + ETH;
+      const bool q0 = valid && s0 < P && role[s0] == 0;
+      const bool q1 = valid && s1 < P && role[s1] == 0;
+      const float l0 = q0 ? logit[s0] : -INFINITY, l1 = q1 ? logit[s1] : -INFINITY;
+      const unsigned long long b0 = __ballot(q0), b1 = __ballot(q1);
+      const float mw = wmax(fmaxf(l0, l1));
+      if (lane == 0) { misc[2 + j] = __popcll(b0); if (j == 0) misc[5] = __popcll(b1); fmisc[j] = mw; }
+      __syncthreads();
+      const int cnt0 = misc[2], cnt1 = misc[3], cnt2 = misc[4], cnt3 = misc[5];
+      const int nq = cnt0 + cnt1 + cnt2 + cnt3;
+      const float mx = fmaxf(fmaxf(fmisc[0], fmisc[1]), fmisc[2]);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int rk0 = (j == 0 ? 0 : (j == 1 ? cnt0 : cnt0 + cnt1)) + __popcll(b0 & below);   // compacted index
+      const int rk1 = cnt0 + cnt1 + cnt2 + __popcll(b1 & below);
+      const float e0 = q0 ? __expf(l0 - mx) : 0.f, e1 = q1 ? __expf(l1 - mx) : 0.f;
+      const float sw = wsum(e0 + e1);
+      __syncthreads();                      // everyone has read fmisc (max) before it is reused
+      if (lane == 0) fmisc[j] = sw;
+      __syncthreads();
+      const float inv = 1.f / (fmisc[0] + fmisc[1] + fmisc[2]);
+      const float p0 = e0 * inv, p1 = e1 * inv;
+      if (valid && a.zt) {
         float *zo = a.zt + ((long)t * a.B + b) * zw;
-        for (int i = lane; i < zw; i += 64) zo[i] = i < nq ? prob[i] : 0.f;
+        if (q0) zo[rk0] = p0;
+        if (q1) zo[rk1] = p1;
+        for (int i = nq + tid3; i < zw; i += ETH) zo[i] = 0.f;
       }
-      int choice = 0;
-      float val = 0.f;
+      // choose: each thread proposes (value, compacted index) or "no"; winner found by reductions
+      int choice = -1;       // compacted index of the chosen query (episode-uniform after this block)
+      float pch = 0.f;
       if (a.mode == 0) {
-        float best = -1.f; int bi = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int i = lane + 64 * c;
-          if (i < nq && pv[c] > best) { best = pv[c]; bi = i; }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        choice = bi; val = best;
+        // argmax with first-index tie-break (torch.max)
+        float bv = fmaxf(p0, p1);
+        const float wbest = wmax(q0 || q1 ? bv : -1.f);
+        __syncthreads();
+        if (lane == 0) fmisc[j] = wbest;
+        __syncthreads();
+        const float best = fmaxf(fmaxf(fmisc[0], fmisc[1]), fmisc[2]);
+        int cand = 0x7fffffff;
+        if (q0 && p0 == best) cand = rk0;
+        if (q1 && p1 == best) cand = min(cand, rk1);
+        // min over the wave, then over the 3 waves
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if (lane == 0) misc[2 + j] = cand;
+        __syncthreads();
+        choice = min(min(misc[2], misc[3]), misc[4]);
+        pch = best;
+      } else if (a.mode == 2) {
+        choice = valid ? (int)a.forced[(long)b * a.T + t] : 0;
+        choice = min(max(choice, 0), nq - 1);
       } else {
-        float tot = wave_sum(pv[0] + pv[1] + pv[2] + pv[3]);
-        if (a.mode == 2) {
-          choice = (int)a.forced[(long)b * a.T + t];
-          choice = min(max(choice, 0), nq - 1);
-        } else {
-          const float u = a.uniform[(long)t * a.B + b] * tot;
-          float run = 0.f; int found = nq - 1; bool done = false;
-          for (int c0 = 0; c0 < nq && !done; c0 += 64) {
-            const int i = c0 + lane;
-            float v = i < nq ? prob[i] : 0.f, incl = v;
-            for (int o = 1; o < 64; o <<= 1) { const float tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
-            const bool hit = i < nq && (run + incl) > u;
-            const unsigned long long bal = __ballot(hit);
-            if (bal) { found = c0 + __ffsll((long long)bal) - 1; done = true; }
-            run += __shfl(incl, 63, 64);
-          }
-          choice = found;
+        // inverse CDF in compacted (= slot) order: inclusive prefix sums of p over slots
+        // chunk order: (j=0,s0) (1,s0) (2,s0) (0,s1): wave-level scans + chunk offsets
+        float inc0 = p0, inc1 = p1;
+        for (int o = 1; o < 64; o <<= 1) {
+          const float u0 = __shfl_up(inc0, o, 64), u1 = __shfl_up(inc1, o, 64);
+          if (lane >= o) { inc0 += u0; inc1 += u1; }
         }
-        // Categorical(probs).log_prob: probs / probs.sum(), clamped to [eps, 1 - eps]
-        val = fminf(fmaxf(prob[choice] / tot, 1.1920929e-07f), 1.f - 1.1920929e-07f);
+        __syncthreads();
+        if (lane == 63) { fmisc[j] = inc0; if (j == 0) fmisc[3] = inc1; }
+        __syncthreads();
+        const float c0 = fmisc[0], c1 = fmisc[1], c2 = fmisc[2], c3 = fmisc[3];
+        const float tot = c0 + c1 + c2 + c3;
+        const float u = (valid ? a.uniform[(long)t * a.B + b] : 0.f) * tot;
+        const float base0 = j == 0 ? 0.f : (j == 1 ? c0 : c0 + c1);
+        int cand = 0x7fffffff;
+        if (q0 && base0 + inc0 > u) cand = rk0;
+        if (q1 && (c0 + c1 + c2) + inc1 > u) cand = min(cand, rk1);
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if (lane == 0) misc[2 + j] = cand;
+        __syncthreads();
+        choice = min(min(misc[2], misc[3]), misc[4]);
+        if (choice == 0x7fffffff) choice = nq - 1;
       }
-      const int sl = qslot[choice];
-      const int order = (P - nq) + 1;
-      if (lane == 0) {
+      // the owner of the chosen compacted index publishes slot / log-prob and updates the role
+      const bool own0 = q0 && rk0 == choice, own1 = q1 && rk1 == choice;
+      if (own0 || own1) {
+        const int sl = own0 ? s0 : s1;
+        float val = own0 ? p0 : p1;
+        if (a.mode != 0) {
+          // Categorical(probs).log_prob: probs / probs.sum(), clamped to [eps, 1 - eps]
+          val = fminf(fmaxf(val, 1.1920929e-07f), 1.f - 1.1920929e-07f);
+        }
         const long o = (long)b * a.T + t;
         if (a.idx) a.idx[o] = choice;
         if (a.slot) a.slot[o] = sl;
         if (a.log_prob) a.log_prob[o] = logf(val);
-        role[sl] = order;
+        role[sl] = (unsigned char)((P - nq) + 1);
       }
-      // the chosen point joins the context: from the next step on its row adds Ey (embedder.py:156)
-    } else {
-      // ---- GMM heads on the target rows (model/head.py:172-177), fp32 FMA: n_t rows are few -----
-      for (int c = wave - 1; c < a.C; c += 3) {
-        const float *w1 = a.gmm_w1[c], *b1 = a.gmm_b1[c], *w2 = a.gmm_w2[c];
-        f32x4 wr[2][8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int q4 = 0; q4 < 8; ++q4) wr[u][q4] = ld4(w1 + (lane + 64 * u) * D + 4 * q4);
-        const float bb0 = b1[lane], bb1 = b1[lane + 64];
-        float w2v[3][2];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { w2v[j][0] = w2[j * F + lane]; w2v[j][1] = w2[j * F + lane + 64]; }
-        for (int r = 0; r < n_th; ++r) {
-          float h0 = bb0, h1 = bb1;
-#pragma unroll
-          for (int q4 = 0; q4 < 8; ++q4) {
-            const f32x4 zv = ld4(Zt + r * ES + 4 * q4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h0 = fmaf(wr[0][q4][e], zv[e], h0); h1 = fmaf(wr[1][q4][e], zv[e], h1); }
-          }
-          h0 = fmaxf(h0, 0.f); h1 = fmaxf(h1, 0.f);
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float sres = wave_sum(h0 * w2v[j][0] + h1 * w2v[j][1]);
-            if (lane == 0) raw[(r * 16 + c) * 4 + j] = sres + a.gmm_b2[c][j];
-          }
-        }
-      }
+      (void)pch;
     }
-    STAMP_PHASE(9)   // selection (wave 0) / GMM heads (waves 1-3)
-    __syncthreads();
-    STAMP_PHASE(10)  // barrier after selection / GMM
+    STAMP_PHASE(9)   // selection
 
-    // ---- GMM parameter maps + compute_ll (head.py:176-177, utils/eval.py:200-207) -------------------
-    if (wave == 1) {
-      for (int r = 0; r < n_th; ++r) {
-        const bool act = lane < a.C;
-        const float r0 = act ? raw[(r * 16 + lane) * 4 + 0] : 0.f;
-        const float r1 = act ? raw[(r * 16 + lane) * 4 + 1] : 0.f;
-        const float r2 = act ? raw[(r * 16 + lane) * 4 + 2] : -INFINITY;
-        const float sd = softplus_f(r1) + a.std_min;
-        const float m2 = wave_max(r2);
-        const float e = act ? __expf(r2 - m2) : 0.f;
-        const float wgt = e / wave_sum(e);
-        const long orow = ((long)t * a.B + b) * n_th + r;
-        if (act) {
-          if (a.post_mean) a.post_mean[orow * a.C + lane] = r0;
-          if (a.post_std) a.post_std[orow * a.C + lane] = sd;
-          if (a.post_weight) a.post_weight[orow * a.C + lane] = wgt;
-        }
-        if (a.target_ll && a.target_all) {
-          const float v = a.target_all[(long)b * n_th + r];
-          const float z = (v - r0) / sd;
-          const float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
-          const float m3 = wave_max(lp);
-          const float se = wave_sum(act ? __expf(lp - m3) : 0.f);
-          if (lane == 0) a.target_ll[orow] = m3 + logf(se);
-        }
-      }
-    }
-    // (the barrier at the top of the next step's key-list build orders role / E updates)
+    // (the GMM posterior of all T steps runs after the loop on the saved target-row encodings: it
+    //  does not feed back into the rollout, model/head.py:365 / train_aline.py:92-95)
     __syncthreads();
     STAMP_PHASE(11)  // GMM epilogue + barrier
   }
-  for (int r = tid; r < P; r += 256) a.role[(long)b * P + r] = role[r];
+  if (valid)
+    for (int r = tid3; r < P; r += ETH) {
+      const int rl = role[r];
+      a.role[(long)b * P + r] = rl;
+    }
 }
 
 }  // namespace fused

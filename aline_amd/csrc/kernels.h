@@ -313,6 +313,7 @@ struct GmmFinishArgs {
   float *mean, *std, *weight;            // [rows, C] (row-mapped)
   int R_out, G_out, off_out;             // output row map (rows per episode etc.)
   const float *value; float *ll;         // optional compute_ll, same row map
+  long value_row0, value_mod;            // value index = (value_row0 + orow) % value_mod when value_mod > 0
 };
 
 __global__ __launch_bounds__(256) void gmm_finish_kernel(GmmFinishArgs a) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void gmm_finish_kernel(GmmFinishArgs a) {
   }
   if (a.ll) {
     // compute_ll (utils/eval.py:200-207): logsumexp_c( Normal(mean, sd).log_prob(v) + log w )
-    float v = a.value[orow];
+    float v = a.value[a.value_mod > 0 ? (a.value_row0 + orow) % a.value_mod : orow];
     float z = (v - mean) / sd;
     float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
     float m2 = wave_max(lp);
