@@ -55,7 +55,7 @@ class AlineRollout(C.Structure):
         + [(n, _fp) for n in ("uniform", "forced_idx")]
         + [("time_token_T", C.c_int32)]
         + [(n, _fp) for n in ("idx", "slot", "log_prob", "target_ll", "zt", "post_mean", "post_std",
-                              "post_weight")]
+                              "post_weight", "ev_kernel_start", "ev_kernel_stop")]
     )
 
 

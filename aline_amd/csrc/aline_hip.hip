@@ -568,6 +568,7 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   a.ztg = c.at(c.pl.Ztg);
   // ALINE_FUSED_STAMPS=1 selects the diagnostic (s_memtime-stamped) instantiation; the stamps land
   // in the tail of the workspace scalar block and are never read by product code.
+  if (r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
   if (getenv("ALINE_FUSED_STAMPS")) {
     a.stamps = reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel<true>),
@@ -579,6 +580,7 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
     hipLaunchKernelGGL(fused::rollout_f32_kernel<false>, dim3((r->B + fused::EPW - 1) / fused::EPW), dim3(fused::NTHREADS), fused::LDS_BYTES, c.st, a);
   }
   CHECK_LAUNCH();
+  if (r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
   // GMM posterior + compute_ll of all T steps on the saved target-row encodings [T*B*n_t, d]
   if (r->post_mean || r->post_std || r->post_weight || r->target_ll) {
     const long rows = (long)r->T * r->B * m->n_theta;

@@ -1,0 +1,29 @@
+"""Episode-level data parallelism: episodes are independent through the whole
+rollout, so ranks shard the batch and never exchange data on the forward path.  One process per
+GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests)."""
+import os
+
+import torch
+
+
+def world_info():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous, balanced shard [lo, hi) of `total` episodes for `rank` (sizes differ by <= 1)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def aggregate_throughput(local_units: float, local_seconds: float, dist=None, device="cpu"):
+    """Whole-job rate = units of all ranks / max-over-ranks time (the bench.py contract)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_units / local_seconds, local_seconds, local_units
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
+    u = torch.tensor([local_units], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(u.item()) / float(t.item()), float(t.item()), float(u.item())

@@ -120,6 +120,9 @@ typedef struct aline_rollout {
   float *target_ll;                             /* [T,B,n_t] */
   float *zt;                                    /* [T,B,P - n_ctx0] zero padded, or NULL */
   float *post_mean, *post_std, *post_weight;    /* [T,B,n_t,C] or NULL */
+  /* optional hipEvent_t pair recorded on `stream` right before / after the dominant kernel of
+   * aline_rollout_forward (bench.py times that kernel with them); NULL = not recorded */
+  void *ev_kernel_start, *ev_kernel_stop;
 } aline_rollout;
 
 /* ABI / build info. */

@@ -1,0 +1,54 @@
+"""CPU, world_size 2 over gloo: the episode-sharding host logic of the multi-GPU path."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from aline_amd.parallel import aggregate_throughput, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(total, rank, world)
+    # every rank "rolls out" its own episodes; rank 1 is slower
+    rate, tmax, units = aggregate_throughput(float(hi - lo) * 6000.0, 1.0 + rank, dist)
+    covered = torch.zeros(total)
+    covered[lo:hi] = 1
+    dist.all_reduce(covered)
+    if rank == 0:
+        out.put((rate, tmax, units, covered.tolist()))
+    dist.destroy_process_group()
+
+
+def test_shards_cover_batch_once_and_rate_uses_max_time():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    total, world, port = 1001, 2, _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, out)) for r in range(world)]
+    [p.start() for p in procs]
+    rate, tmax, units, covered = out.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(c == 1.0 for c in covered)               # every episode on exactly one rank
+    assert tmax == 2.0 and units == total * 6000.0      # max over ranks, sum over ranks
+    assert abs(rate - total * 6000.0 / 2.0) < 1e-6
+
+
+def test_shard_range_properties():
+    for total in (0, 1, 7, 1000, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
