@@ -51,3 +51,46 @@ def test_location_eig_large_L_streaming_property():
     ref_S = sum(orc.location_log_likelihood(y[:, t].cpu().unsqueeze(0), x[:, t].cpu().unsqueeze(0),
                                             thetas[sl].cpu()).squeeze(-1) for t in range(T))
     assert maxdiff(crit.seq_logprobs[sl], ref_S) < 2e-3
+
+
+def test_ces_eig_bounds_match_reference(golden):
+    """CESTask.log_likelihood + CensoredSigmoidNormal.log_prob incl. the censored limits (a16)."""
+    from aline_amd.loss import EIGStepLoss
+    from aline_amd.tasks import CESTask
+    fx = golden("eig")
+    task = CESTask()
+    th0, x, y, th = (fx.t(k).cuda() for k in ("ces_theta0", "ces_x", "ces_y", "ces_thetas"))
+    thetas = torch.cat([th0.unsqueeze(0), th], 0).contiguous()
+    ref = fx.t("ces_ll")                                    # [T, L+1, B, 1]
+    L, B = th.shape[0], th.shape[1]
+    crit = EIGStepLoss(L, B, task, reduction="none")
+    for t in range(x.shape[1]):
+        ll = task.log_likelihood(y[:, t].unsqueeze(0), x[:, t].unsqueeze(0), thetas).cpu()
+        fin = torch.isfinite(ref[t])
+        assert (torch.isfinite(ll) == fin).all()
+        # fp32 powf / erff of |mu| up to 1e4: relative bound, as for the CPU oracle
+        assert torch.allclose(ll[fin], ref[t][fin], rtol=5e-3, atol=5e-3), float((ll[fin] - ref[t][fin]).abs().max())
+        pce, nmc = crit(y[:, t], x[:, t], thetas)
+        # bounds reach 1e5 in magnitude on this fixture (likelihoods of order -1e5): relative bound
+        assert torch.allclose((math.log(L + 1) - pce).cpu(), fx.t("ces_pce")[:, t], rtol=1e-4, atol=2e-2)
+        assert torch.allclose((math.log(L) - nmc).cpu(), fx.t("ces_nmc")[:, t], rtol=1e-4, atol=2e-2)
+
+
+def test_get_traces_and_eig_from_history_end_to_end():
+    """a17 + a14: eval rollout on the native model, then sPCE <= sNMC bounds from its history."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd.utils import compute_EIG_from_history, get_traces
+    torch.manual_seed(0)
+    model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3),
+                  OutputHead(2, 1, 32, 128)).cuda()
+    task = HiddenLocation(n_query_init=50)
+    T, B, L = 6, 16, 20000
+    theta0, x, y = get_traces(model, task, T=T, batch_size=B)
+    assert x.shape == (B, 1 + T, 2) and y.shape == (B, 1 + T, 1) and theta0.shape == (B, 1, 2)
+    pce, nmc = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=True)
+    assert pce.shape == (B, 1 + T) and torch.isfinite(pce).all() and torch.isfinite(nmc).all()
+    assert float(pce.mean(0)[-1]) <= float(nmc.mean(0)[-1]) + 1e-3      # lower <= upper bound
+    assert float(pce.mean(0)[-1]) <= math.log(L + 1)
+    pce1, nmc1 = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=False)
+    assert pce1.shape == (B,)
