@@ -35,6 +35,18 @@ class AlineModel(C.Structure):
     )
 
 
+class AlineGrads(C.Structure):
+    _fields_ = (
+        [(n, _fp) for n in ("x_w1", "x_b1", "x_w2", "x_b2", "y_w1", "y_b1", "y_w2", "y_b2",
+                            "theta_tokens")]
+        + [(n, _fp * MAX_LAYERS) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
+                                           "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm1_w",
+                                           "norm1_b", "norm2_w", "norm2_b")]
+        + [(n, _fp) for n in ("acq_w1", "acq_b1", "acq_w2", "acq_b2")]
+        + [(n, _fp * MAX_COMPONENTS) for n in ("gmm_w1", "gmm_b1", "gmm_w2", "gmm_b2")]
+    )
+
+
 class AlineStep(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("B", "n_ctx", "n_query", "n_target_data")]
@@ -67,6 +79,7 @@ def _load():
             "There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     MP, SP, RP = C.POINTER(AlineModel), C.POINTER(AlineStep), C.POINTER(AlineRollout)
+    GP = C.POINTER(AlineGrads)
     sig = {
         "aline_abi_version": (C.c_int, []),
         "aline_error_string": (C.c_char_p, [C.c_int]),
@@ -87,6 +100,8 @@ def _load():
                                          C.c_float, _fp, _fp]),
         "aline_eig_finalize_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
         "aline_debug_stamps_offset": (C.c_size_t, [MP, RP]),
+        "aline_rollout_backward_workspace_bytes": (C.c_size_t, [MP, RP, C.c_int]),
+        "aline_rollout_backward": (C.c_int, [MP, RP, _fp, _fp, GP, C.c_int, _fp, C.c_size_t, _fp]),
         "aline_eig_finalize": (C.c_int, [_fp, C.c_int64, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     }
     for name, (res, args) in sig.items():

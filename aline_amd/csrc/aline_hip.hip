@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include "eig.h"
 #include "fused_rollout.h"
+#include "backward.h"
 
 #include <algorithm>
 #include <cstring>
@@ -330,6 +331,7 @@ int step_geo(const aline_model &m, const aline_step &s, Geo &g) {
   if (m.embedding_type == ALINE_EMB_THETA && s.n_target_data != 0) return ALINE_EINVAL;
   g.B = s.B; g.P = s.n_ctx + s.n_query; g.n_td = s.n_target_data; g.n_th = m.n_theta;
   g.N = g.P + g.n_td + g.n_th; g.n_ctx = s.n_ctx; g.role = nullptr; g.tmask = s.target_mask;
+  g.inst_B = 0; g.inst_t0 = 0; g.n_ctx0 = 0;
   return ALINE_OK;
 }
 
@@ -458,6 +460,7 @@ static int rollout_ctx(const aline_model *m, const aline_rollout *r, void *ws, s
   c.g.B = r->B; c.g.P = r->P; c.g.n_td = r->n_target_data; c.g.n_th = m->n_theta;
   c.g.N = c.g.P + c.g.n_td + c.g.n_th; c.g.n_ctx = r->n_ctx0; c.g.role = r->role;
   c.g.tmask = r->target_mask;
+  c.g.inst_B = 0; c.g.inst_t0 = 0; c.g.n_ctx0 = r->n_ctx0;
   c.m = m;
   c.pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T);
   if (ws_bytes < c.pl.total * sizeof(float)) return ALINE_EWORKSPACE;
@@ -677,4 +680,303 @@ int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc
 extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return 0;
   return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).Stamps * sizeof(float);
+}
+
+// ================================= backward (training) ============================================
+namespace {
+
+struct BwdPlan {
+  size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt,
+      total;
+};
+
+BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
+  BwdPlan p{};
+  const size_t N = (size_t)P + n_td + m.n_theta, I = (size_t)B * tc, M = I * N, d = m.d, F = m.F, L = m.L;
+  const size_t n_t = (size_t)n_td + m.n_theta, rows_x = (size_t)B * (P + n_td), rows_y = (size_t)B * P;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
+  p.Xs = take((L + 1) * M * d);
+  p.QKV = take(L * M * 3 * d);
+  p.A = take(L * M * d);
+  p.U1 = take(L * M * d);
+  p.X1 = take(L * M * d);
+  p.Hid = take(L * M * F);
+  p.U2 = take(L * M * d);
+  p.HidA = take(I * P * F);
+  p.HidG = take(I * n_t * m.C * F);
+  p.dXa = take(M * d);
+  p.dXb = take(M * d);
+  p.dQKV = take(M * 3 * d);
+  p.dHid = take(std::max(M * F, rows_x * F));
+  p.dTmp = take(M * d);
+  p.Ex = take(rows_x * d);
+  p.Ey = take(rows_y * d);
+  p.EHx = take(rows_x * F);
+  p.EHy = take(rows_y * F);
+  p.dEx = take(rows_x * d);
+  p.dEy = take(rows_y * d);
+  p.Wt = take(std::max({(size_t)3 * d * d, F * d, (size_t)m.C * F * d}));
+  p.total = off;
+  return p;
+}
+
+struct BCtx {
+  const aline_model *m;
+  Geo g;
+  BwdPlan pl;
+  float *ws;
+  hipStream_t st;
+  float *at(size_t off) const { return ws + off; }
+};
+
+int transpose_to(const BCtx &c, const float *W, int rows, int cols, float *dst) {
+  hipLaunchKernelGGL(transpose_kernel, grid1d((size_t)rows * cols), dim3(256), 0, c.st, W, rows, cols, cols, dst);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// dX[M, K] (+)= dY[M, N] . W[N, K]   (W in PyTorch layout [N, K]); Wt scratch holds W^T [K, N]
+int gemm_dx(const BCtx &c, const float *dY, int ldy, const float *W, int N, int K, float *dX, int ldx, int M,
+            bool accum) {
+  float *Wt = c.at(c.pl.Wt);
+  TRY(transpose_to(c, W, N, K, Wt));
+  GemmArgs a = gemm_args(dY, ldy, Wt, nullptr, N, dX, ldx, M, K, N, false);
+  a.accum = accum ? 1 : 0;
+  TRY(launch_gemm(ALINE_PREC_F32, a, 1, c.st));
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// dW[N, K] += dY^T X, db[N] += colsum(dY)
+int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, long M,
+            int N, int K, int Ry = 1, int Gy = 1, int offy = 0, int Rx = 1, int Gx = 1, int offx = 0) {
+  if (N % 32 || K % 32) return ALINE_EUNSUPPORTED;
+  GemmTnArgs a{};
+  a.dY = dY; a.ldy = ldy; a.Ry = Ry; a.Gy = Gy; a.offy = offy;
+  a.X = X; a.ldx = ldx; a.Rx = Rx; a.Gx = Gx; a.offx = offx;
+  a.dW = dW; a.ldw = K; a.db = db; a.M = M; a.N = N; a.K = K;
+  a.mchunk = 4096;
+  dim3 grid((unsigned)((M + a.mchunk - 1) / a.mchunk), N / 32, K / 32);
+  hipLaunchKernelGGL(gemm_tn_atomic_kernel, grid, dim3(256), 0, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float *dU, float *dw, float *db,
+           long rows) {
+  const int rpb = 64;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
+                     (size_t)2 * c.m->d * sizeof(float), c.st, dY, U, w, dU, dw, db, rows, c.m->d, rpb);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+template <int HD>
+int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys) {
+  size_t smem = (size_t)max_keys * (4 * HD * sizeof(float) + sizeof(int));
+  if (smem > 160 * 1024 - 1024) return ALINE_EUNSUPPORTED;
+  if (smem > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_bwd_kernel<HD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(attention_bwd_kernel<HD>, dim3(c.g.B, c.m->H), dim3(256), smem, c.st, c.g, c.m->d, qkv,
+                     dA, dqkv, max_keys);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+}  // namespace
+
+extern "C" size_t aline_rollout_backward_workspace_bytes(const aline_model *m, const aline_rollout *r,
+                                                         int t_chunk) {
+  if (!m || !r || validate_model(*m, 0) != 0 || t_chunk < 1) return 0;
+  return make_bwd_plan(*m, r->B, r->P, r->n_target_data, std::min(t_chunk, (int)r->T)).total * sizeof(float);
+}
+
+extern "C" int aline_rollout_backward(const aline_model *m, const aline_rollout *r, const float *g_logp,
+                                      const float *g_ll, const aline_grads *gr, int t_chunk, void *ws,
+                                      size_t ws_bytes, void *stream) {
+  if (!m || !r || !g_logp || !g_ll || !gr || !ws || t_chunk < 1) return ALINE_EINVAL;
+  TRY(validate_model(*m));
+  if (m->precision != ALINE_PREC_F32 || m->time_token) return ALINE_EUNSUPPORTED;
+  if (!r->role || !r->slot || !r->point_x || !r->point_y || !r->target_all) return ALINE_EINVAL;
+  const int tc = std::min(t_chunk, (int)r->T);
+  BCtx c;
+  c.m = m;
+  c.pl = make_bwd_plan(*m, r->B, r->P, r->n_target_data, tc);
+  if (ws_bytes < c.pl.total * sizeof(float)) return ALINE_EWORKSPACE;
+  c.ws = static_cast<float *>(ws);
+  c.st = static_cast<hipStream_t>(stream);
+  const int B = r->B, P = r->P, n_td = r->n_target_data, n_th = m->n_theta, n_t = n_td + n_th;
+  const int N = P + n_t, d = m->d, F = m->F, L = m->L, C = m->C, hd = d / m->H;
+  const int rows_x = B * (P + n_td), rows_y = B * P;
+
+  // ---- step-invariant point embeddings, keeping the hidden activations -----------------------------
+  float *Ex = c.at(c.pl.Ex), *Ey = c.at(c.pl.Ey), *EHx = c.at(c.pl.EHx), *EHy = c.at(c.pl.EHy);
+  Src3 xs{{r->point_x, r->target_x, nullptr}, {P, n_td, 0}};
+  Src3 ys{{r->point_y, nullptr, nullptr}, {P, 0, 0}};
+  hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_x * F), dim3(256), 0, c.st, xs, P + n_td, B,
+                     m->dim_x, F, m->x_w1, m->x_b1, EHx);
+  CHECK_LAUNCH();
+  TRY(launch_gemm(0, gemm_args(EHx, F, m->x_w2, m->x_b2, F, Ex, d, rows_x, d, F, false), 1, c.st));
+  hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_y * F), dim3(256), 0, c.st, ys, P, B, m->dim_y,
+                     F, m->y_w1, m->y_b1, EHy);
+  CHECK_LAUNCH();
+  TRY(launch_gemm(0, gemm_args(EHy, F, m->y_w2, m->y_b2, F, Ey, d, rows_y, d, F, false), 1, c.st));
+  CHECK_LAUNCH();
+  (void)hipMemsetAsync(c.at(c.pl.dEx), 0, (size_t)rows_x * d * sizeof(float), c.st);
+  (void)hipMemsetAsync(c.at(c.pl.dEy), 0, (size_t)rows_y * d * sizeof(float), c.st);
+
+  for (int tA = 0; tA < r->T; tA += tc) {
+    const int nt_steps = std::min(tc, r->T - tA);
+    const int I = B * nt_steps;
+    const long M = (long)I * N;
+    Geo &g = c.g;
+    g.B = I; g.P = P; g.n_td = n_td; g.n_th = n_th; g.N = N; g.n_ctx = 0; g.role = r->role;
+    g.tmask = r->target_mask; g.inst_B = B; g.inst_t0 = tA; g.n_ctx0 = r->n_ctx0;
+    const int max_keys = r->n_ctx0 + tA + nt_steps - 1 + n_t;
+    auto Xs = [&](int l) { return c.at(c.pl.Xs) + (size_t)l * M * d; };
+    auto QKVl = [&](int l) { return c.at(c.pl.QKV) + (size_t)l * M * 3 * d; };
+    auto Al = [&](int l) { return c.at(c.pl.A) + (size_t)l * M * d; };
+    auto U1l = [&](int l) { return c.at(c.pl.U1) + (size_t)l * M * d; };
+    auto X1l = [&](int l) { return c.at(c.pl.X1) + (size_t)l * M * d; };
+    auto Hidl = [&](int l) { return c.at(c.pl.Hid) + (size_t)l * M * F; };
+    auto U2l = [&](int l) { return c.at(c.pl.U2) + (size_t)l * M * d; };
+    float *dTmp = c.at(c.pl.dTmp), *dQKV = c.at(c.pl.dQKV), *dHid = c.at(c.pl.dHid);
+
+    // ---- forward recompute, saving what the backward needs --------------------------------------------
+    hipLaunchKernelGGL(assemble_kernel, grid1d((size_t)M * d), dim3(256), 0, c.st, g, d, Ex, Ey, P,
+                       m->theta_tokens, Xs(0));
+    CHECK_LAUNCH();
+    for (int l = 0; l < L; ++l) {
+      TRY(launch_gemm(0, gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
+      Ctx fc; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
+      switch (hd) {
+        case 4: TRY(launch_attention<4>(fc, QKVl(l), Al(l), max_keys)); break;
+        case 8: TRY(launch_attention<8>(fc, QKVl(l), Al(l), max_keys)); break;
+        case 16: TRY(launch_attention<16>(fc, QKVl(l), Al(l), max_keys)); break;
+        case 32: TRY(launch_attention<32>(fc, QKVl(l), Al(l), max_keys)); break;
+        case 64: TRY(launch_attention<64>(fc, QKVl(l), Al(l), max_keys)); break;
+        default: return ALINE_EUNSUPPORTED;
+      }
+      TRY(launch_gemm(0, gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));
+      hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c.st, Xs(l), dTmp,
+                         m->norm1_w[l], m->norm1_b[l], X1l(l), M, d, U1l(l));
+      CHECK_LAUNCH();
+      TRY(launch_gemm(0, gemm_args(X1l(l), d, m->lin1_w[l], m->lin1_b[l], d, Hidl(l), F, (int)M, F, d, true), 1, c.st));
+      TRY(launch_gemm(0, gemm_args(Hidl(l), F, m->lin2_w[l], m->lin2_b[l], F, dTmp, d, (int)M, d, F, false), 1, c.st));
+      hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c.st, X1l(l), dTmp,
+                         m->norm2_w[l], m->norm2_b[l], Xs(l + 1), M, d, U2l(l));
+      CHECK_LAUNCH();
+    }
+    const float *Z = Xs(L);
+    float *HidA = c.at(c.pl.HidA), *HidG = c.at(c.pl.HidG);
+    {
+      GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, d, HidA, F, I * P, F, d, true);
+      a.R_in = P; a.G_in = N; a.off_in = 0;
+      TRY(launch_gemm(0, a, 1, c.st));
+      GemmArgs ag = gemm_args(Z, d, nullptr, nullptr, d, HidG, C * F, I * n_t, F, d, true);
+      ag.R_in = n_t; ag.G_in = N; ag.off_in = P; ag.col_per_group = F;
+      for (int k = 0; k < C; ++k) { ag.W[k] = m->gmm_w1[k]; ag.bias[k] = m->gmm_b1[k]; }
+      TRY(launch_gemm(0, ag, C, c.st));
+      CHECK_LAUNCH();
+    }
+
+    // ---- heads backward -> dZ --------------------------------------------------------------------------
+    float *dX = c.at(c.pl.dXa), *dXn = c.at(c.pl.dXb);
+    (void)hipMemsetAsync(dX, 0, (size_t)M * d * sizeof(float), c.st);
+    {
+      AcqBwdArgs a{};
+      a.g = g; a.F = F; a.hid = HidA; a.w2 = m->acq_w2; a.b2 = m->acq_b2; a.g_logp = g_logp; a.slot = r->slot;
+      a.T = r->T; a.dw2 = gr->acq_w2; a.db2 = gr->acq_b2;
+      hipLaunchKernelGGL(acq_bwd_kernel, dim3(I), dim3(256), (size_t)(P + F) * sizeof(float), c.st, a);
+      CHECK_LAUNCH();
+      TRY(gemm_dw(c, HidA, F, Z, d, gr->acq_w1, gr->acq_b1, (long)I * P, F, d, 1, 1, 0, P, N, 0));
+      // dZ[point rows] = dHidA . W1a
+      float *Wt = c.at(c.pl.Wt);
+      TRY(transpose_to(c, m->acq_w1, F, d, Wt));
+      GemmArgs ga = gemm_args(HidA, F, Wt, nullptr, F, dX, d, I * P, d, F, false);
+      ga.R_out = P; ga.G_out = N; ga.off_out = 0;
+      TRY(launch_gemm(0, ga, 1, c.st));
+      CHECK_LAUNCH();
+    }
+    {
+      GmmBwdArgs a{};
+      a.hid = HidG; a.rows = (long)I * n_t; a.C = C; a.F = F; a.std_min = m->std_min;
+      for (int k = 0; k < C; ++k) { a.w2[k] = m->gmm_w2[k]; a.b2[k] = m->gmm_b2[k]; a.dw2[k] = gr->gmm_w2[k]; a.db2[k] = gr->gmm_b2[k]; }
+      a.value = r->target_all; a.value_mod = (long)B * n_t;
+      a.g_ll = g_ll + (size_t)tA * B * n_t;
+      hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, c.st, a);
+      CHECK_LAUNCH();
+      float *Wt = c.at(c.pl.Wt);   // [d, C*F]: column block k = W1_k^T
+      for (int k = 0; k < C; ++k) {
+        TRY(gemm_dw(c, HidG + (size_t)k * F, C * F, Z, d, gr->gmm_w1[k], gr->gmm_b1[k], (long)I * n_t, F, d, 1, 1, 0,
+                    n_t, N, P));
+        // Wt[kk, k*F + f] = W1_k[f, kk]
+        hipLaunchKernelGGL(transpose_kernel, grid1d((size_t)F * d), dim3(256), 0, c.st, m->gmm_w1[k], F, d, d,
+                           Wt + (size_t)k * F * d);   // temporarily packed [d, F] blocks, fixed below
+        CHECK_LAUNCH();
+      }
+      // dZ[target rows] += sum_k dHidG_k . W1_k : one GEMM per component (K = F), accumulating
+      for (int k = 0; k < C; ++k) {
+        GemmArgs ga = gemm_args(HidG + (size_t)k * F, C * F, Wt + (size_t)k * F * d, nullptr, F, dX, d, I * n_t, d, F, false);
+        ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
+        TRY(launch_gemm(0, ga, 1, c.st));
+      }
+      CHECK_LAUNCH();
+    }
+
+    // ---- encoder layers backward ---------------------------------------------------------------------------
+    for (int l = L - 1; l >= 0; --l) {
+      // LN2
+      TRY(ln_bwd(c, dX, U2l(l), m->norm2_w[l], dTmp, gr->norm2_w[l], gr->norm2_b[l], M));   // dTmp = dU2
+      // FFN
+      TRY(gemm_dw(c, dTmp, d, Hidl(l), F, gr->lin2_w[l], gr->lin2_b[l], M, d, F));
+      TRY(gemm_dx(c, dTmp, d, m->lin2_w[l], d, F, dHid, F, (int)M, false));
+      hipLaunchKernelGGL(relu_mask_kernel, grid1d((size_t)M * F), dim3(256), 0, c.st, dHid, Hidl(l), M * F);
+      CHECK_LAUNCH();
+      TRY(gemm_dw(c, dHid, F, X1l(l), d, gr->lin1_w[l], gr->lin1_b[l], M, F, d));
+      TRY(gemm_dx(c, dHid, F, m->lin1_w[l], F, d, dTmp, d, (int)M, true));                      // dTmp = dX1
+      // LN1
+      TRY(ln_bwd(c, dTmp, U1l(l), m->norm1_w[l], dXn, gr->norm1_w[l], gr->norm1_b[l], M));   // dXn = dU1
+      // out-proj
+      TRY(gemm_dw(c, dXn, d, Al(l), d, gr->out_proj_w[l], gr->out_proj_b[l], M, d, d));
+      TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false));                  // dTmp = dA
+      // attention
+      switch (hd) {
+        case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
+        case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
+        case 16: TRY(launch_attention_bwd<16>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
+        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
+        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
+        default: return ALINE_EUNSUPPORTED;
+      }
+      // in-proj
+      TRY(gemm_dw(c, dQKV, 3 * d, Xs(l), d, gr->in_proj_w[l], gr->in_proj_b[l], M, 3 * d, d));
+      TRY(gemm_dx(c, dQKV, 3 * d, m->in_proj_w[l], 3 * d, d, dXn, d, (int)M, true));             // dXn = dX_l
+      std::swap(dX, dXn);
+    }
+    // ---- embeddings: sum over the chunk's steps ------------------------------------------------------------
+    hipLaunchKernelGGL(assemble_bwd_kernel, grid1d((size_t)B * N * d), dim3(256), 0, c.st, g, d, nt_steps, dX,
+                       c.at(c.pl.dEx), c.at(c.pl.dEy), P, gr->theta_tokens ? gr->theta_tokens : c.at(c.pl.dTmp));
+    CHECK_LAUNCH();
+  }
+
+  // ---- point embedders backward (model/embedder.py:47-57) -------------------------------------------------
+  {
+    float *dEx = c.at(c.pl.dEx), *dEy = c.at(c.pl.dEy), *dH = c.at(c.pl.dHid);
+    TRY(gemm_dw(c, dEx, d, EHx, F, gr->x_w2, gr->x_b2, rows_x, d, F));
+    TRY(gemm_dx(c, dEx, d, m->x_w2, d, F, dH, F, rows_x, false));
+    hipLaunchKernelGGL(relu_mask_kernel, grid1d((size_t)rows_x * F), dim3(256), 0, c.st, dH, EHx, (long)rows_x * F);
+    hipLaunchKernelGGL(embed_first_bwd_kernel, dim3((rows_x + 255) / 256), dim3(128), 0, c.st, xs, P + n_td, B,
+                       m->dim_x, F, dH, gr->x_w1, gr->x_b1, 256);
+    CHECK_LAUNCH();
+    TRY(gemm_dw(c, dEy, d, EHy, F, gr->y_w2, gr->y_b2, rows_y, d, F));
+    TRY(gemm_dx(c, dEy, d, m->y_w2, d, F, dH, F, rows_y, false));
+    hipLaunchKernelGGL(relu_mask_kernel, grid1d((size_t)rows_y * F), dim3(256), 0, c.st, dH, EHy, (long)rows_y * F);
+    hipLaunchKernelGGL(embed_first_bwd_kernel, dim3((rows_y + 255) / 256), dim3(128), 0, c.st, ys, P, B, m->dim_y,
+                       F, dH, gr->y_w1, gr->y_b1, 256);
+    CHECK_LAUNCH();
+  }
+  return ALINE_OK;
 }

@@ -1,0 +1,431 @@
+// Backward kernels of one design step (fp32).  The T steps of a rollout are independent given the
+// roles (design selection is discrete: no gradient flows through it, train_aline.py:113-125), so the
+// backward pass treats the T x B (step, episode) pairs as one batch of "instances", recomputes the
+// forward with the generic pipeline while saving what it needs, and back-propagates once.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+// dW[n, k] += sum_m dY[m, n] * X[m, k]   and (optionally) db[n] += sum_m dY[m, n]
+// "TN" product over a very tall M.  One workgroup = one 32x32 output tile x one chunk of rows; its 4
+// waves take interleaved row groups, accumulate with exact-fp32 16x16x4 MFMAs (A = dY^T: lane n holds
+// dY[m, n], k index = row m), are summed through LDS and added to global memory with float atomics.
+struct GemmTnArgs {
+  const float *dY; int ldy; int Ry, Gy, offy;   // row maps as in gemm.h
+  const float *X; int ldx; int Rx, Gx, offx;
+  float *dW; int ldw;                            // [N, K]
+  float *db;                                     // [N] or null
+  long M; int N, K; long mchunk;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_atomic_kernel(GemmTnArgs a) {
+  __shared__ float red[4][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.z * 32;
+  const long m_lo = (long)blockIdx.x * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  // wave w handles row groups of 4: m = m_lo + 4 * (w + 4 * it) + fg
+  for (long mb = m_lo + 4 * wave; mb < m_hi; mb += 16) {
+    const long m = mb + fg;
+    float av[2] = {0.f, 0.f}, bv[2] = {0.f, 0.f};
+    if (m < m_hi) {
+      const long ry = (m / a.Ry) * a.Gy + a.offy + (m % a.Ry);
+      const long rx = (m / a.Rx) * a.Gx + a.offx + (m % a.Rx);
+      av[0] = a.dY[ry * a.ldy + n0 + fr];
+      av[1] = a.dY[ry * a.ldy + n0 + 16 + fr];
+      bv[0] = a.X[rx * a.ldx + k0 + fr];
+      bv[1] = a.X[rx * a.ldx + k0 + 16 + fr];
+    }
+    bsum[0] += av[0];
+    bsum[1] += av[1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+  }
+  // acc[i][j][r]: n = 16 i + 4 fg + r, k = 16 j + fr
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][16 * i + 4 * fg + r][16 * j + fr] = acc[i][j][r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+    const int n = e >> 5, k = e & 31;
+    const float v = red[0][n][k] + red[1][n][k] + red[2][n][k] + red[3][n][k];
+    atomicAdd(a.dW + (long)(n0 + n) * a.ldw + k0 + k, v);
+  }
+  if (a.db && blockIdx.z == 0) {
+    // column sums of dY: lanes (fr, fg) hold partial sums of column 16 i + fr
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float s = bsum[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (fg == 0) atomicAdd(a.db + n0 + 16 * i + fr, s);
+    }
+  }
+}
+
+// LayerNorm backward (post-norm block): y = LN(u) * w + b.
+//   dU = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dY * w;  dw += dY * xhat;  db += dY
+// One wave per row; per-workgroup partial dw/db through LDS, then one atomic per feature.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dY,
+                                                            const float *__restrict__ U,
+                                                            const float *__restrict__ w, float *__restrict__ dU,
+                                                            float *dw, float *db, long rows, int d,
+                                                            int rows_per_block) {
+  extern __shared__ float sm[];   // [2][d]
+  float *sdw = sm, *sdb = sm + d;
+  for (int i = threadIdx.x; i < 2 * d; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  float pdw[8], pdb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { pdw[i] = 0.f; pdb[i] = 0.f; }
+  for (long row = r0 + wave; row < min(rows, r0 + rows_per_block); row += 4) {
+    float u[8], gy[8];
+    float s = 0.f;
+    int n = 0;
+    for (int c = lane; c < d; c += 64, ++n) { u[n] = U[row * d + c]; gy[n] = dY[row * d + c]; s += u[n]; }
+    const float mean = wave_sum(s) / d;
+    float ss = 0.f;
+    for (int i = 0; i < n; ++i) { const float t = u[i] - mean; ss += t * t; }
+    const float rstd = rsqrtf(wave_sum(ss) / d + 1e-5f);
+    float sg = 0.f, sgx = 0.f;
+    n = 0;
+    for (int c = lane; c < d; c += 64, ++n) {
+      const float xh = (u[n] - mean) * rstd, g = gy[n] * w[c];
+      pdw[n] += gy[n] * xh;
+      pdb[n] += gy[n];
+      u[n] = xh;
+      gy[n] = g;
+      sg += g;
+      sgx += g * xh;
+    }
+    const float mg = wave_sum(sg) / d, mgx = wave_sum(sgx) / d;
+    n = 0;
+    for (int c = lane; c < d; c += 64, ++n) dU[row * d + c] = rstd * (gy[n] - mg - u[n] * mgx);
+  }
+  int n = 0;
+  for (int c = lane; c < d; c += 64, ++n) { atomicAdd(&sdw[c], pdw[n]); atomicAdd(&sdb[c], pdb[n]); }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) { atomicAdd(dw + c, sdw[c]); atomicAdd(db + c, sdb[c]); }
+}
+
+// elementwise helpers
+__global__ void relu_mask_kernel(float *__restrict__ g, const float *__restrict__ act, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(act[i] > 0.f)) g[i] = 0.f;
+}
+__global__ void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+__global__ void transpose_kernel(const float *__restrict__ src, int rows, int cols, int ld, float *__restrict__ dst) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // dst [cols, rows]
+  if (i >= (long)rows * cols) return;
+  const int c = i / rows, r = i % rows;
+  dst[i] = src[(long)r * ld + c];
+}
+
+// Masked set-attention backward.  One workgroup per (instance, head), like attention_kernel.
+//   dV_j += sum_i P_ij dO_i;  dS_ij = P_ij (dO_i.V_j - sum_j' P_ij' dO_i.V_j');
+//   dQ_i = scale * sum_j dS_ij K_j;  dK_j += scale * sum_i dS_ij Q_i
+// dQKV rows of non-key tokens get zero K/V gradients.
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const float *__restrict__ QKV,
+                                                            const float *__restrict__ dA,
+                                                            float *__restrict__ dQKV, int max_keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *Ks = reinterpret_cast<float *>(smem_raw);
+  float *Vs = Ks + (size_t)max_keys * HD;
+  float *dKs = Vs + (size_t)max_keys * HD;
+  float *dVs = dKs + (size_t)max_keys * HD;
+  int *keyrow = reinterpret_cast<int *>(dVs + (size_t)max_keys * HD);
+  __shared__ int wave_cnt[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_t = g.n_td + g.n_th;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < g.N; c0 += 256) {
+    int row = c0 + tid;
+    bool key = false;
+    if (row < g.P) key = is_ctx(g, b, row);
+    unsigned long long bal = __ballot(key);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (key) keyrow[off + __popcll(bal & ((1ull << lane) - 1ull))] = row;
+    __syncthreads();
+    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int n_ck = s_base;
+  __syncthreads();
+  if (tid == 0) {
+    int n = n_ck;
+    for (int j = 0; j < n_t; ++j)
+      if (!g.tmask || g.tmask[j]) keyrow[n++] = g.P + j;
+    s_base = n;
+  }
+  __syncthreads();
+  const int n_ak = s_base;
+  const long ep = (long)b * g.N;
+  for (int i = tid; i < n_ak * HD; i += 256) {
+    int j = i / HD, c = i % HD;
+    const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
+    Ks[j * HD + c] = src[d];
+    Vs[j * HD + c] = src[2 * d];
+    dKs[j * HD + c] = 0.f;
+    dVs[j * HD + c] = 0.f;
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)HD);
+  for (int row = tid; row < g.N; row += 256) {
+    const bool isq = row < g.P && !is_ctx(g, b, row);
+    const int nk = isq ? n_ak : n_ck;
+    float q[HD], go[HD], dq[HD];
+    const float *qp = QKV + (ep + row) * 3 * d + h * HD;
+    const float *gp = dA + (ep + row) * d + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { q[c] = qp[c] * scale; go[c] = gp[c]; dq[c] = 0.f; }
+    // pass 1: softmax statistics and delta = sum_j P_ij (dO_i . V_j)
+    float mx = -INFINITY;
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j * HD + c], s);
+      mx = fmaxf(mx, s);
+    }
+    float l = 0.f, delta = 0.f;
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
+      const float p = __expf(s - mx);
+      l += p;
+      delta += p * dp;
+    }
+    const float inv = 1.f / l;
+    delta *= inv;
+    // pass 2: gradients
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
+      const float p = __expf(s - mx) * inv;
+      const float ds = p * (dp - delta);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        dq[c] = fmaf(ds, Ks[j * HD + c], dq[c]);
+        atomicAdd(&dKs[j * HD + c], ds * q[c]);     // q already carries the 1/sqrt(hd)
+        atomicAdd(&dVs[j * HD + c], p * go[c]);
+      }
+    }
+    float *out = dQKV + (ep + row) * 3 * d + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { out[c] = dq[c] * scale; out[d + c] = 0.f; out[2 * d + c] = 0.f; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n_ak * HD; i += 256) {
+    int j = i / HD, c = i % HD;
+    float *dst = dQKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
+    dst[d] = dKs[i];
+    dst[2 * d] = dVs[i];
+  }
+}
+
+// Acquisition head backward, first part (model/head.py:27-33 + log-softmax of the chosen design):
+//   logits = hid . w2 + b2 over the point rows; p = softmax over the remaining queries;
+//   dlogit[row] = g_logp * (1[row == chosen] - p[row]);  dhid = dlogit * w2 * (hid > 0);
+//   dw2 += sum dlogit * hid;  db2 += sum dlogit.          One workgroup per instance; dhid overwrites hid.
+struct AcqBwdArgs {
+  Geo g; int F;
+  float *hid;                  // [I*P, F] in: relu(z W1^T + b1), out: gradient wrt the pre-activation
+  const float *w2, *b2;
+  const float *g_logp;         // [B, T] dLoss/dlog_prob
+  const int *slot;             // [B, T] chosen slot
+  int T;
+  float *dw2, *db2;
+};
+__global__ __launch_bounds__(256) void acq_bwd_kernel(AcqBwdArgs a) {
+  extern __shared__ float lds[];   // logits [P], dw2 partial [F]
+  float *logit = lds, *sdw = lds + a.g.P;
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = a.g.P, F = a.F;
+  const int b = i % a.g.inst_B, t = a.g.inst_t0 + i / a.g.inst_B;
+  for (int f = tid; f < F; f += 256) sdw[f] = 0.f;
+  for (int p = wave; p < P; p += 4) {
+    const float *hp = a.hid + ((long)i * P + p) * F;
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s = fmaf(hp[f], a.w2[f], s);
+    s = wave_sum(s);
+    if (lane == 0) logit[p] = s + a.b2[0];
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int p = tid; p < P; p += 256) if (!is_ctx(a.g, i, p)) mx = fmaxf(mx, logit[p]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int p = tid; p < P; p += 256) if (!is_ctx(a.g, i, p)) sum += __expf(logit[p] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  const float gl = a.g_logp[(long)b * a.T + t];
+  const int chosen = a.slot[(long)b * a.T + t];
+  __syncthreads();
+  float dbl = 0.f;
+  for (int p = tid; p < P; p += 256) {
+    float dl = 0.f;
+    if (!is_ctx(a.g, i, p)) dl = gl * ((p == chosen ? 1.f : 0.f) - __expf(logit[p] - mx) * inv);
+    logit[p] = dl;     // each p is owned by one thread
+    dbl += dl;
+  }
+  dbl = wave_sum(dbl);
+  if (lane == 0) atomicAdd(a.db2, dbl);
+  __syncthreads();
+  for (int p = wave; p < P; p += 4) {
+    float *hp = a.hid + ((long)i * P + p) * F;
+    const float dl = logit[p];
+    for (int f = lane; f < F; f += 64) {
+      const float hv = hp[f];
+      if (dl != 0.f) atomicAdd(&sdw[f], dl * hv);
+      hp[f] = hv > 0.f ? dl * a.w2[f] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < F; f += 256) atomicAdd(a.dw2 + f, sdw[f]);
+}
+
+// GMM head backward, second layer + log-likelihood (model/head.py:172-177, utils/eval.py:200-207).
+// One wave per target row; lane c = component.  hid [rows, C*F] (ReLU output) is overwritten by the
+// gradient wrt the first layer's pre-activation; dw2/db2 accumulate with atomics.
+struct GmmBwdArgs {
+  float *hid; long rows; int C, F;
+  const float *w2[16]; const float *b2[16];
+  float *dw2[16]; float *db2[16];
+  float std_min;
+  const float *value; long value_mod;          // target value of row r: value[r % value_mod]
+  const float *g_ll;                           // [rows] dLoss/d ll
+};
+__global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;
+  for (int c = 0; c < a.C; ++c) {
+    const float *hp = a.hid + (row * a.C + c) * a.F;
+    const float *w = a.w2[c];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int f = lane; f < a.F; f += 64) {
+      const float hv = hp[f];
+      s0 = fmaf(hv, w[f], s0); s1 = fmaf(hv, w[a.F + f], s1); s2 = fmaf(hv, w[2 * a.F + f], s2);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == c) { raw0 = s0 + a.b2[c][0]; raw1 = s1 + a.b2[c][1]; raw2 = s2 + a.b2[c][2]; }
+  }
+  const bool act = lane < a.C;
+  const float mean = raw0, sd = softplus_f(raw1) + a.std_min;
+  const float mxw = wave_max(act ? raw2 : -INFINITY);
+  const float ew = act ? __expf(raw2 - mxw) : 0.f;
+  const float wgt = ew / wave_sum(ew);
+  const float v = a.value[row % a.value_mod];
+  const float z = (v - mean) / sd;
+  const float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
+  const float m2 = wave_max(lp);
+  const float er = act ? __expf(lp - m2) : 0.f;
+  const float resp = er / wave_sum(er);          // responsibilities
+  const float gl = a.g_ll[row];
+  // d ll / d raw
+  const float d0 = act ? gl * resp * z / sd : 0.f;                                  // mean
+  const float dsd = act ? gl * resp * (z * z - 1.f) / sd : 0.f;                     // sigma
+  const float d1 = dsd * (1.f / (1.f + __expf(-raw1)));                             // softplus'
+  const float d2 = act ? gl * (resp - wgt) : 0.f;                                   // mixture logits
+  for (int c = 0; c < a.C; ++c) {
+    const float g0 = __shfl(d0, c, 64), g1 = __shfl(d1, c, 64), g2 = __shfl(d2, c, 64);
+    float *hp = a.hid + (row * a.C + c) * a.F;
+    const float *w = a.w2[c];
+    for (int f = lane; f < a.F; f += 64) {
+      const float hv = hp[f];
+      if (hv > 0.f) {
+        atomicAdd(a.dw2[c] + f, g0 * hv);
+        atomicAdd(a.dw2[c] + a.F + f, g1 * hv);
+        atomicAdd(a.dw2[c] + 2 * a.F + f, g2 * hv);
+        hp[f] = g0 * w[f] + g1 * w[a.F + f] + g2 * w[2 * a.F + f];
+      } else {
+        hp[f] = 0.f;
+      }
+    }
+    if (lane == 0) { atomicAdd(a.db2[c] + 0, g0); atomicAdd(a.db2[c] + 1, g1); atomicAdd(a.db2[c] + 2, g2); }
+  }
+}
+
+// Gradient of the step-invariant embeddings: X0[(t,b), row] = Ex[b, row] (+ Ey[b, p] while p is context),
+// theta rows = tokens.   dEx[b,row] += sum_t dX0;  dEy[b,p] += sum_{t: ctx} dX0;  dtheta += sum_{t,b} dX0.
+__global__ void assemble_bwd_kernel(Geo g, int d, int n_inst_t, const float *__restrict__ dX0,
+                                    float *__restrict__ dEx, float *__restrict__ dEy, int ey_rows,
+                                    float *__restrict__ dtheta) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int B = g.inst_B;
+  long total = (long)B * g.N * d;
+  if (i >= total) return;
+  const int c = i % d;
+  const long r = i / d;
+  const int b = r / g.N, row = r % g.N;
+  float sx = 0.f, sy = 0.f;
+  for (int tt = 0; tt < n_inst_t; ++tt) {
+    const long inst = (long)tt * B + b;
+    const float v = dX0[(inst * g.N + row) * d + c];
+    sx += v;
+    if (row < g.P && is_ctx(g, (int)inst, row)) sy += v;
+  }
+  if (row < g.P + g.n_td) {
+    dEx[((long)b * (g.P + g.n_td) + row) * d + c] += sx;
+    if (row < g.P) dEy[((long)b * ey_rows + row) * d + c] += sy;
+  } else {
+    atomicAdd(dtheta + (row - g.P - g.n_td) * d + c, sx);
+  }
+}
+
+// First layer of the point embedder, backward:  hid = relu(b1 + x W1^T) with tiny K.
+// dhid [rows, F] (already masked by relu) -> dW1[f,k] += sum_r dhid[r,f] x[r,k], db1[f] += sum_r dhid[r,f]
+__global__ __launch_bounds__(256) void embed_first_bwd_kernel(Src3 src, int rows_per_ep, int B, int K, int F,
+                                                              const float *__restrict__ dhid,
+                                                              float *dW1, float *db1, int rows_per_block) {
+  // thread f-major: each thread owns one f and loops over the block's rows
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long rows = (long)B * rows_per_ep;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float gw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gb = 0.f;
+    for (long r = r0; r < min(rows, r0 + rows_per_block); ++r) {
+      const int b = r / rows_per_ep, p = r % rows_per_ep;
+      const float *x;
+      if (p < src.n[0]) x = src.p[0] + ((long)b * src.n[0] + p) * K;
+      else if (p < src.n[0] + src.n[1]) x = src.p[1] + ((long)b * src.n[1] + (p - src.n[0])) * K;
+      else x = src.p[2] + ((long)b * src.n[2] + (p - src.n[0] - src.n[1])) * K;
+      const float gv = dhid[r * F + f];
+      gb += gv;
+      for (int k = 0; k < K; ++k) gw[k] = fmaf(gv, x[k], gw[k]);
+    }
+    atomicAdd(db1 + f, gb);
+    for (int k = 0; k < K; ++k) atomicAdd(dW1 + f * K + k, gw[k]);
+  }
+}

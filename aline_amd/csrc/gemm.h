@@ -19,7 +19,7 @@ struct GemmArgs {
   const float *X; int ldx; int R_in, G_in, off_in;
   const float *W[GEMM_MAX_GROUPS]; const float *bias[GEMM_MAX_GROUPS]; int ldw;
   float *Y; int ldy; int R_out, G_out, off_out; int col_per_group;
-  int M, N, K; int relu;
+  int M, N, K; int relu; int accum;   // accum: Y += result
   const float *tscalar; const float *tcol; int tcol_stride;  // optional rank-1 term (time token)
 };
 
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
           float v = acc[i][j][r] + add;
           if (a.relu) v = fmaxf(v, 0.f);
           long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
-          a.Y[dst * a.ldy + grp * a.col_per_group + n] = v;
+          float *yp = a.Y + dst * a.ldy + grp * a.col_per_group + n;
+          *yp = a.accum ? *yp + v : v;
         }
       }
     }

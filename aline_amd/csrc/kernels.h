@@ -13,9 +13,16 @@ struct Geo {
   int n_ctx;             // static context count (step API) / current count (rollout, informational)
   const int *role;       // [B, P] or nullptr
   const uint8_t *tmask;  // [n_td + n_th] or nullptr (= every target is visible to the queries)
+  // instance mode (backward pass): "episode" index i is a (step, episode) pair, t = inst_t0 + i / inst_B,
+  // b = i % inst_B; slot p is context at step t iff 0 < role[b, p] <= n_ctx0 + t (role = order of entry)
+  int inst_B, inst_t0, n_ctx0;
 };
 
 __device__ __forceinline__ bool is_ctx(const Geo &g, int b, int p) {
+  if (g.inst_B > 0) {
+    const int r = g.role[(long)(b % g.inst_B) * g.P + p];
+    return r > 0 && r <= g.n_ctx0 + g.inst_t0 + b / g.inst_B;
+  }
   return g.role ? g.role[(long)b * g.P + p] > 0 : p < g.n_ctx;
 }
 
@@ -53,9 +60,10 @@ __global__ void assemble_kernel(Geo g, int d, const float *__restrict__ Ex, cons
   long r = i / d;
   int b = r / g.N, row = r % g.N;
   float v;
+  const int eb = g.inst_B > 0 ? b % g.inst_B : b;   // embeddings are per episode, shared by its steps
   if (row < g.P + g.n_td) {
-    v = Ex[((long)b * (g.P + g.n_td) + row) * d + c];
-    if (row < g.P && is_ctx(g, b, row)) v += Ey[((long)b * ey_rows + row) * d + c];
+    v = Ex[((long)eb * (g.P + g.n_td) + row) * d + c];
+    if (row < g.P && is_ctx(g, b, row)) v += Ey[((long)eb * ey_rows + row) * d + c];
   } else {
     v = theta_tokens[(row - g.P - g.n_td) * d + c];
   }
@@ -144,7 +152,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
                                                             const float *__restrict__ b2,
                                                             const float *__restrict__ w,
                                                             const float *__restrict__ bias,
-                                                            float *__restrict__ out, long rows, int d) {
+                                                            float *__restrict__ out, long rows, int d,
+                                                            float *__restrict__ usave = nullptr) {
   const int lane = threadIdx.x & 63;
   long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
   float v[8];  // d <= 512
   float s = 0.f;
   int n = 0;
-  for (int c = lane; c < d; c += 64, ++n) { v[n] = pa[c] + pb[c]; s += v[n]; }
+  for (int c = lane; c < d; c += 64, ++n) { v[n] = pa[c] + pb[c]; s += v[n]; if (usave) usave[row * d + c] = v[n]; }
   const float mean = wave_sum(s) / d;
   float ss = 0.f;
   for (int i = 0; i < n; ++i) { float t = v[i] - mean; ss += t * t; }

@@ -1,0 +1,126 @@
+"""Training objective of the reference (train_aline.py:80-152) on the native kernels: fused forward
+rollout, REINFORCE reductions (tiny on-device torch ops), native backward of all T steps, and the
+episode-data-parallel gradient all-reduce (one flat bucket per optimiser step)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .rollout import Rollout
+
+
+def _grad_struct(model):
+    """`aline_grads` pointing at param.grad of every weight (allocated + zeroed if missing)."""
+    for p in model.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    g = _lib.AlineGrads()
+    emb, enc, head = model.embedder, model.encoder, model.head
+    for nm in ("x", "y"):
+        seq = getattr(emb, f"{nm}_embedder")
+        setattr(g, f"{nm}_w1", seq[0].weight.grad.data_ptr())
+        setattr(g, f"{nm}_b1", seq[0].bias.grad.data_ptr())
+        setattr(g, f"{nm}_w2", seq[2].weight.grad.data_ptr())
+        setattr(g, f"{nm}_b2", seq[2].bias.grad.data_ptr())
+    if hasattr(emb, "theta_tokens"):
+        g.theta_tokens = emb.theta_tokens.grad.data_ptr()
+    for l, layer in enumerate(enc.encoder.layers):
+        g.in_proj_w[l] = layer.self_attn.in_proj_weight.grad.data_ptr()
+        g.in_proj_b[l] = layer.self_attn.in_proj_bias.grad.data_ptr()
+        g.out_proj_w[l] = layer.self_attn.out_proj.weight.grad.data_ptr()
+        g.out_proj_b[l] = layer.self_attn.out_proj.bias.grad.data_ptr()
+        g.lin1_w[l], g.lin1_b[l] = layer.linear1.weight.grad.data_ptr(), layer.linear1.bias.grad.data_ptr()
+        g.lin2_w[l], g.lin2_b[l] = layer.linear2.weight.grad.data_ptr(), layer.linear2.bias.grad.data_ptr()
+        g.norm1_w[l], g.norm1_b[l] = layer.norm1.weight.grad.data_ptr(), layer.norm1.bias.grad.data_ptr()
+        g.norm2_w[l], g.norm2_b[l] = layer.norm2.weight.grad.data_ptr(), layer.norm2.bias.grad.data_ptr()
+    pr = head.acquisition_head.predictor
+    g.acq_w1, g.acq_b1 = pr[0].weight.grad.data_ptr(), pr[0].bias.grad.data_ptr()
+    g.acq_w2, g.acq_b2 = pr[2].weight.grad.data_ptr(), pr[2].bias.grad.data_ptr()
+    for c, h in enumerate(head.target_head.heads):
+        g.gmm_w1[c], g.gmm_b1[c] = h[0].weight.grad.data_ptr(), h[0].bias.grad.data_ptr()
+        g.gmm_w2[c], g.gmm_b2[c] = h[2].weight.grad.data_ptr(), h[2].bias.grad.data_ptr()
+    return g
+
+
+_bwd_ws = _lib.Workspace()
+
+
+def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, burn_in=False):
+    """train_aline.py:97-132 on the rollout's per-step log-likelihoods.  Returns the losses and the two
+    upstream gradients of `aline_rollout_backward` (dLoss/dlog_prob [B,T], dLoss/dtarget_ll [T,B,n_t])."""
+    B, T, n_t = ro.B, ro.T, ro.n_t
+    nll_q, nll = ro.nlls(embedding_type, mask_type)                      # [B, T]
+    predict_loss = nll.mean()
+    dev = nll.device
+    g_logp = torch.zeros(B, T, device=dev)
+    design_loss = torch.zeros((), device=dev)
+    if T > 1:
+        disc = torch.tensor([gamma ** t for t in range(1, T)], device=dev)
+        R = disc * torch.clamp(nll_q[:, :-1] - nll_q[:, 1:], min=0.0)    # [B, T-1], detached by construction
+        R = (R - R.mean(dim=0, keepdim=True)) / (R.std(dim=0, keepdim=True) + 1e-9)
+        design_loss = -(ro.log_prob[:, :-1] * R).mean()
+        if not burn_in:
+            g_logp[:, :-1] = -alpha * R / (B * (T - 1))
+    n_th = ro.m.n_theta
+    g_ll = torch.empty(T, B, n_t, device=dev)
+    if embedding_type == "mix":                                           # two means (train_aline.py:106-107)
+        n_td = n_t - n_th
+        g_ll[..., :n_td] = -1.0 / (T * B * n_td)
+        g_ll[..., n_td:] = -1.0 / (T * B * n_th)
+    else:
+        g_ll.fill_(-1.0 / (T * B * n_t))
+    loss = predict_loss if burn_in else alpha * design_loss + predict_loss
+    return dict(loss=loss, design_loss=design_loss, predict_loss=predict_loss, g_logp=g_logp.contiguous(),
+                g_ll=g_ll.contiguous())
+
+
+def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30):
+    """Accumulates dLoss/dW into param.grad of every weight of `model` (C ABI aline_rollout_backward)."""
+    m, r = ro.m, ro.r
+    grads = _grad_struct(model)
+    if t_chunk is None:
+        t_chunk = ro.T
+        while t_chunk > 1 and _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), t_chunk) > max_ws_bytes:
+            t_chunk = (t_chunk + 1) // 2
+    nbytes = _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), t_chunk)
+    if nbytes == 0:
+        raise RuntimeError("aline_amd: unsupported configuration for backward")
+    ws = _bwd_ws.get(nbytes, ro.device)
+    _lib.check(_lib.lib.aline_rollout_backward(C.byref(m), C.byref(r), g_logp.data_ptr(), g_ll.data_ptr(),
+                                               C.byref(grads), t_chunk, ws.data_ptr(), ws.numel(),
+                                               _lib.stream_ptr(ro.device)), "rollout_backward")
+    return t_chunk
+
+
+def all_reduce_grads(model, dist, world):
+    """One flat-bucket all-reduce (sum, then / world) of every gradient (RCCL over xGMI on the node)."""
+    params = [p for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat)
+    flat /= world
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_type="all", gamma=1.0, alpha=1.0,
+               burn_in=False, forced_idx=None, clip_grads=True, dist=None, world=1, t_chunk=None):
+    """One epoch body of train_aline.py:55-152 (without the hydra / logging shell)."""
+    model.train()
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    with torch.no_grad():
+        select = "forced" if forced_idx is not None else "sample"
+        ro = Rollout(model, batch, T, select=select, forced_idx=forced_idx).run()
+        terms = reinforce_terms(ro, embedding_type, mask_type, gamma, alpha, burn_in)
+        backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=t_chunk)
+        if dist is not None and world > 1:
+            all_reduce_grads(model, dist, world)
+        if clip_grads:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0, norm_type="inf")   # train_aline.py:138
+        if optimizer is not None:
+            optimizer.step()
+    return terms, ro

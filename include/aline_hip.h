@@ -181,6 +181,35 @@ size_t aline_eig_finalize_workspace_bytes(int64_t L1, int B);
 int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc, void *ws,
                        size_t ws_bytes, void *stream);
 
+/* --- training: backward of the T-step objective ------------------------------------------------- */
+/* Gradient buffers, one per weight of aline_model (same shapes), ACCUMULATED into (+=): the caller
+ * zeroes them (optimizer.zero_grad(), train_aline.py:56) and owns them (param.grad storage). */
+typedef struct aline_grads {
+  float *x_w1, *x_b1, *x_w2, *x_b2, *y_w1, *y_b1, *y_w2, *y_b2, *theta_tokens;
+  float *in_proj_w[ALINE_MAX_LAYERS], *in_proj_b[ALINE_MAX_LAYERS];
+  float *out_proj_w[ALINE_MAX_LAYERS], *out_proj_b[ALINE_MAX_LAYERS];
+  float *lin1_w[ALINE_MAX_LAYERS], *lin1_b[ALINE_MAX_LAYERS];
+  float *lin2_w[ALINE_MAX_LAYERS], *lin2_b[ALINE_MAX_LAYERS];
+  float *norm1_w[ALINE_MAX_LAYERS], *norm1_b[ALINE_MAX_LAYERS];
+  float *norm2_w[ALINE_MAX_LAYERS], *norm2_b[ALINE_MAX_LAYERS];
+  float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
+  float *gmm_w1[ALINE_MAX_COMPONENTS], *gmm_b1[ALINE_MAX_COMPONENTS];
+  float *gmm_w2[ALINE_MAX_COMPONENTS], *gmm_b2[ALINE_MAX_COMPONENTS];
+} aline_grads;
+
+/* loss.backward() of train_aline.py:124-132 for a finished rollout.  The T steps are independent
+ * given the designs (selection is discrete; rewards are detached, train_aline.py:116), so the caller
+ * passes the two upstream gradients
+ *     g_logp [B,T]      = dLoss / d design_out.log_prob[b,t]   (= -alpha R[b,t] / (B (T-1)), 0 at t=T-1)
+ *     g_ll   [T,B,n_t]  = dLoss / d target_ll[t,b,j]           (= -1 / (T B n_t) for the plain NLL mean)
+ * and gets dLoss/dW accumulated into `grads`.  Needs r->role (final roles) and r->slot from the
+ * forward rollout.  Steps are processed `t_chunk` at a time (workspace ~ t_chunk * B * N * (14 d + 4 F)
+ * floats).  fp32 only. */
+size_t aline_rollout_backward_workspace_bytes(const aline_model *m, const aline_rollout *r, int t_chunk);
+int aline_rollout_backward(const aline_model *m, const aline_rollout *r, const float *g_logp,
+                           const float *g_ll, const aline_grads *grads, int t_chunk, void *ws,
+                           size_t ws_bytes, void *stream);
+
 /* --- diagnostics ----------------------------------------------------------------------------- */
 /* Byte offset, inside a rollout workspace, of the per-phase cycle stamps the fused rollout kernel
  * writes when the process runs with ALINE_FUSED_STAMPS=1 (diagnostic instantiation only). */
