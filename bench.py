@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--train-steps", type=int, default=2,
+                    help="also time K full training steps (rollout + backward + all-reduce + AdamW); 0 = skip")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,6 +275,29 @@ def main():
                      "note": "peak = fp32 MFMA (v_mfma_f32_16x16x4_f32) for dtype f32, dense bf16 MFMA otherwise"},
     }
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms per rollout")
+    if args.train_steps > 0 and args.precision == "f32":
+        # secondary measurement (not `value`): one optimiser step of train_aline.py:55-152 -- sampled
+        # rollout, REINFORCE terms, native backward of all T steps, ONE flat-bucket RCCL all-reduce of the
+        # gradients (N > 1), inf-norm clipping, AdamW.
+        from aline_amd.train import train_step
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)        # warm-up
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)
+        barrier()
+        tdt = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([tdt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tdt = float(tt.item())
+        out["train_step"] = {"value": world * designs_per_rollout * args.train_steps / tdt, "unit": "designs/s",
+                             "ms_per_step": tdt / args.train_steps * 1e3, "steps": args.train_steps,
+                             "includes": "fused forward rollout + generic fp32 backward of all T steps + "
+                                         "flat-bucket gradient all-reduce (N>1) + inf-norm clip + AdamW",
+                             "collective": "1 all-reduce / optimiser step" if world > 1 else "none (N=1)"}
+        log(f"train step: {tdt / args.train_steps * 1e3:.1f} ms")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, model)
         log("cpu baseline done")

@@ -28,9 +28,9 @@ def test_gradients_match_reference_autograd(golden, name):
         err = float((got - ref).abs().max()) / scale
         if err > worst[1]:
             worst = (k, err)
-    # R is a z-score of small NLL differences, so 1e-5 forward differences are amplified in the
-    # design-loss part of the gradient; bound the worst parameter's max error relative to its max |grad|
-    assert worst[1] < 2e-2, worst
+    # measured on MI355X: <= 4e-5 of each parameter's max |grad| (the acquisition output bias has a
+    # mathematically zero gradient -- softmax shift invariance -- hence the absolute floor in `scale`)
+    assert worst[1] < 1e-3, worst
 
 
 def test_backward_chunking_is_consistent(golden):

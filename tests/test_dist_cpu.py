@@ -52,3 +52,28 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aline_amd.train import all_reduce_grads
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    for i, p in enumerate(model.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    all_reduce_grads(model, dist, world)          # one flat bucket: sum over ranks / world
+    if rank == 0:
+        out.put([float(p.grad.mean()) for p in model.parameters()])
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_gradient_all_reduce_averages_over_ranks():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, out)) for r in range(world)]
+    [p.start() for p in procs]
+    means = out.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert means == [1.5 * (i + 1) for i in range(4)]     # mean of rank values (1, 2) * (i + 1)
