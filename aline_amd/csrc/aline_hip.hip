@@ -774,7 +774,8 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 
 template <int HD>
 int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys) {
-  size_t smem = (size_t)max_keys * (4 * HD * sizeof(float) + sizeof(int));
+  size_t smem = (size_t)max_keys * (2 * HD * sizeof(float) + sizeof(int)) +
+                (size_t)c.g.N * (2 * HD + 4) * sizeof(float);
   if (smem > 160 * 1024 - 1024) return ALINE_EUNSUPPORTED;
   if (smem > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_bwd_kernel<HD>),

@@ -139,19 +139,22 @@ __global__ void transpose_kernel(const float *__restrict__ src, int rows, int co
 }
 
 // Masked set-attention backward.  One workgroup per (instance, head), like attention_kernel.
-//   dV_j += sum_i P_ij dO_i;  dS_ij = P_ij (dO_i.V_j - sum_j' P_ij' dO_i.V_j');
-//   dQ_i = scale * sum_j dS_ij K_j;  dK_j += scale * sum_i dS_ij Q_i
-// dQKV rows of non-key tokens get zero K/V gradients.
+//   dV_j = sum_i P_ij dO_i;  dS_ij = P_ij (dO_i.V_j - delta_i),  delta_i = sum_j P_ij dO_i.V_j;
+//   dQ_i = scale * sum_j dS_ij K_j;  dK_j = scale * sum_i dS_ij Q_i
+// Phase 1 (threads = token rows): softmax statistics, delta and dQ.  Phase 2 (threads = (key, channel
+// pair)): every key row sums its own dK / dV over the token rows from the statistics kept in LDS -- no
+// atomics.  dQKV rows of non-key tokens get zero K/V gradients.
 template <int HD>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const float *__restrict__ QKV,
                                                             const float *__restrict__ dA,
                                                             float *__restrict__ dQKV, int max_keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float *Ks = reinterpret_cast<float *>(smem_raw);
-  float *Vs = Ks + (size_t)max_keys * HD;
-  float *dKs = Vs + (size_t)max_keys * HD;
-  float *dVs = dKs + (size_t)max_keys * HD;
-  int *keyrow = reinterpret_cast<int *>(dVs + (size_t)max_keys * HD);
+  float *Ks = reinterpret_cast<float *>(smem_raw);                 // [max_keys][HD]
+  float *Vs = Ks + (size_t)max_keys * HD;                          // [max_keys][HD]
+  float *Qs = Vs + (size_t)max_keys * HD;                          // [N][HD]  scaled queries
+  float *Gs = Qs + (size_t)g.N * HD;                               // [N][HD]  dO
+  float *St = Gs + (size_t)g.N * HD;                               // [N][4]   max, 1/l, delta, #keys
+  int *keyrow = reinterpret_cast<int *>(St + (size_t)g.N * 4);     // [max_keys]
   __shared__ int wave_cnt[4];
   __shared__ int s_base;
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,8 +191,6 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
     Ks[j * HD + c] = src[d];
     Vs[j * HD + c] = src[2 * d];
-    dKs[j * HD + c] = 0.f;
-    dVs[j * HD + c] = 0.f;
   }
   __syncthreads();
   const float scale = rsqrtf((float)HD);
@@ -200,8 +201,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     const float *qp = QKV + (ep + row) * 3 * d + h * HD;
     const float *gp = dA + (ep + row) * d + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) { q[c] = qp[c] * scale; go[c] = gp[c]; dq[c] = 0.f; }
-    // pass 1: softmax statistics and delta = sum_j P_ij (dO_i . V_j)
+    for (int c = 0; c < HD; ++c) {
+      q[c] = qp[c] * scale; go[c] = gp[c]; dq[c] = 0.f;
+      Qs[row * HD + c] = q[c];
+      Gs[row * HD + c] = go[c];
+    }
     float mx = -INFINITY;
     for (int j = 0; j < nk; ++j) {
       float s = 0.f;
@@ -220,30 +224,39 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     }
     const float inv = 1.f / l;
     delta *= inv;
-    // pass 2: gradients
     for (int j = 0; j < nk; ++j) {
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
-      const float p = __expf(s - mx) * inv;
-      const float ds = p * (dp - delta);
+      const float ds = __expf(s - mx) * inv * (dp - delta);
 #pragma unroll
-      for (int c = 0; c < HD; ++c) {
-        dq[c] = fmaf(ds, Ks[j * HD + c], dq[c]);
-        atomicAdd(&dKs[j * HD + c], ds * q[c]);     // q already carries the 1/sqrt(hd)
-        atomicAdd(&dVs[j * HD + c], p * go[c]);
-      }
+      for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, Ks[j * HD + c], dq[c]);
     }
+    St[row * 4 + 0] = mx; St[row * 4 + 1] = inv; St[row * 4 + 2] = delta; St[row * 4 + 3] = (float)nk;
     float *out = dQKV + (ep + row) * 3 * d + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; ++c) { out[c] = dq[c] * scale; out[d + c] = 0.f; out[2 * d + c] = 0.f; }
   }
   __syncthreads();
-  for (int i = tid; i < n_ak * HD; i += 256) {
-    int j = i / HD, c = i % HD;
+  // phase 2: thread = (key j, channel c); loops over the token rows that see key j
+  for (int e = tid; e < n_ak * HD; e += 256) {
+    const int j = e / HD, c = e % HD;
+    float kj[HD], vj[HD];
+#pragma unroll
+    for (int cc = 0; cc < HD; ++cc) { kj[cc] = Ks[j * HD + cc]; vj[cc] = Vs[j * HD + cc]; }
+    float dk = 0.f, dv = 0.f;
+    for (int row = 0; row < g.N; ++row) {
+      if ((float)j >= St[row * 4 + 3]) continue;      // key not visible to this row
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < HD; ++cc) { s = fmaf(Qs[row * HD + cc], kj[cc], s); dp = fmaf(Gs[row * HD + cc], vj[cc], dp); }
+      const float p = __expf(s - St[row * 4 + 0]) * St[row * 4 + 1];
+      dv = fmaf(p, Gs[row * HD + c], dv);
+      dk = fmaf(p * (dp - St[row * 4 + 2]), Qs[row * HD + c], dk);
+    }
     float *dst = dQKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
-    dst[d] = dKs[i];
-    dst[2 * d] = dVs[i];
+    dst[d] = dk;            // Qs already carries the 1/sqrt(hd)
+    dst[2 * d] = dv;
   }
 }
 

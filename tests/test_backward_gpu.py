@@ -24,7 +24,7 @@ def test_gradients_match_reference_autograd(golden, name):
     for k, p in model.named_parameters():
         ref = fx.t("train.grad." + k)
         got = p.grad.detach().cpu()
-        scale = float(ref.abs().max()) + 1e-6
+        scale = max(float(ref.abs().max()), 1e-4)
         err = float((got - ref).abs().max()) / scale
         if err > worst[1]:
             worst = (k, err)
