@@ -29,15 +29,19 @@ constexpr int NKMAX = 32;       // key rows (context + selected targets) per epi
 constexpr int MAXROWS = 256;    // token rows per episode (16 tiles)
 constexpr int MAXNT = 8;        // target rows
 constexpr int ES = 36;          // LDS row stride (floats) of E / Xk / Zt
-constexpr int FRAG = 512;       // floats per operand fragment: 64 lanes x 8 k-elements
-constexpr int NFRAG_LAYER = 24; // Wq 2, Wk 2, Wv 2, Wo 2, W1 8, W2 8
-constexpr int FQ = 0, FK = 2, FV = 4, FO = 6, F1 = 8, F2 = 16;
+constexpr int FRAG = 512;       // floats per fp32 operand fragment: 64 lanes x 8 k-elements
+constexpr int FRAG3 = 768;      // 32-bit words per split-bf16 fragment: 3 planes x 64 lanes x 8 bf16
+constexpr int FQ = 0, FK = 2, FV = 4, FO = 6;        // fp32 fragments (attention projections)
+constexpr int NF32 = 8;                               // Wq 2, Wk 2, Wv 2, Wo 2
+constexpr int FFN_BASE = NF32 * FRAG;                 // then 16 split-bf16 fragments: W1 8, W2 8
+constexpr int F1 = 0, F2 = 8;                         // indices into the FFN fragment block
+constexpr int PRM_BASE = FFN_BASE + 16 * FRAG3;
 // per-layer parameter block (floats) after the fragments
 constexpr int PB_Q = 0, PB_K = 32, PB_V = 64, PB_O = 96, PB_1 = 128, PB_2 = 256, PLN1W = 288,
               PLN1B = 320, PLN2W = 352, PLN2B = 384, PARAMS = 416;
-constexpr int LAYER_FLOATS = NFRAG_LAYER * FRAG + PARAMS;     // 12704
-// acquisition head image: W1 8 fragments + b1[128] + w2[128] + b2 (padded to 4)
-constexpr int HEAD_FLOATS = 8 * FRAG + 128 + 128 + 4;          // 4356
+constexpr int LAYER_FLOATS = PRM_BASE + PARAMS;                 // 16800 (67.2 KB)
+// acquisition head image: W1 8 split-bf16 fragments + b1[128] + w2[128] + b2 (padded to 4)
+constexpr int HEAD_FLOATS = 8 * FRAG3 + 128 + 128 + 4;         // 6404
 
 // ---- weight packing (once per rollout; weights are constant during a rollout) -------------------
 struct PackArgs {
@@ -49,11 +53,30 @@ struct PackArgs {
 };
 
 // element (lane, j) of fragment (mt, kb) of a [rows, K] row-major weight: W[16 mt + (lane & 15)][pi]
-__device__ __forceinline__ float frag_elem(const float *W, int K, int mt, int kb, int e) {
-  const int sub = e >> 8, lane = (e >> 2) & 63, jj = e & 3;   // image = [sub-plane][lane][4]
-  const int j = sub * 4 + jj, g = lane >> 4;
+__device__ __forceinline__ float frag_val(const float *W, int K, int mt, int kb, int lane, int j) {
+  const int g = lane >> 4;
   const int k = 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3);
   return W[(16 * mt + (lane & 15)) * K + k];
+}
+__device__ __forceinline__ float frag_elem(const float *W, int K, int mt, int kb, int e) {
+  const int sub = e >> 8, lane = (e >> 2) & 63, jj = e & 3;   // fp32 image = [sub-plane][lane][4]
+  return frag_val(W, K, mt, kb, lane, sub * 4 + jj);
+}
+// exact 3-way split of an fp32 value into bf16 planes: a == hi + mid + lo (8 + 8 + 8 mantissa bits)
+__device__ __forceinline__ unsigned short split3_plane(float a, int plane) {
+  const unsigned short h = f2bf(a);
+  if (plane == 0) return h;
+  const float r = a - bf2f(h);
+  const unsigned short m = f2bf(r);
+  if (plane == 1) return m;
+  return f2bf(r - bf2f(m));
+}
+// 32-bit word e of a split-bf16 fragment image [plane][lane][4 words]: elements j = 2w, 2w + 1
+__device__ __forceinline__ float frag3_word(const float *W, int K, int mt, int kb, int e) {
+  const int plane = e >> 8, lane = (e >> 2) & 63, w = e & 3;
+  const unsigned lo = split3_plane(frag_val(W, K, mt, kb, lane, 2 * w), plane);
+  const unsigned hi = split3_plane(frag_val(W, K, mt, kb, lane, 2 * w + 1), plane);
+  return __uint_as_float(lo | (hi << 16));
 }
 
 __global__ void pack_weights_kernel(PackArgs a) {
@@ -64,22 +87,21 @@ __global__ void pack_weights_kernel(PackArgs a) {
     float v = 0.f;
     if (i < a.L * LAYER_FLOATS) {
       const int l = i / LAYER_FLOATS, o = i % LAYER_FLOATS;
-      if (o < NFRAG_LAYER * FRAG) {
+      if (o < FFN_BASE) {
         const int f = o / FRAG, e = o % FRAG;
         if (f < FO) {            // in_proj rows: q 0..31, k 32..63, v 64..95   (K = 32)
           const int which = f >> 1, mt = f & 1;
           v = frag_elem(a.in_proj_w[l] + which * D * D, D, mt, 0, e);
           if (which == 0) v *= qscale;
-        } else if (f < F1) {
-          v = frag_elem(a.out_proj_w[l], D, f - FO, 0, e);
-        } else if (f < F2) {
-          v = frag_elem(a.lin1_w[l], D, f - F1, 0, e);          // [128, 32]: 8 m-tiles
         } else {
-          const int q = f - F2;                                  // [32, 128]: (mt, kb) = (q / 4, q % 4)
-          v = frag_elem(a.lin2_w[l], F, q >> 2, q & 3, e);
+          v = frag_elem(a.out_proj_w[l], D, f - FO, 0, e);
         }
+      } else if (o < PRM_BASE) {
+        const int q = (o - FFN_BASE) / FRAG3, e = (o - FFN_BASE) % FRAG3;
+        if (q < F2) v = frag3_word(a.lin1_w[l], D, q, 0, e);                       // [128, 32]: 8 m-tiles
+        else v = frag3_word(a.lin2_w[l], F, (q - F2) >> 2, (q - F2) & 3, e);       // [32, 128]: (mt, kb)
       } else {
-        const int p = o - NFRAG_LAYER * FRAG;
+        const int p = o - PRM_BASE;
         if (p < PB_K) v = a.in_proj_b[l][p] * qscale;
         else if (p < PB_O) v = a.in_proj_b[l][p];                // k, v biases (offsets 32..95)
         else if (p < PB_1) v = a.out_proj_b[l][p - PB_O];
@@ -92,10 +114,10 @@ __global__ void pack_weights_kernel(PackArgs a) {
       }
     } else {
       const int o = i - a.L * LAYER_FLOATS;
-      if (o < 8 * FRAG) v = frag_elem(a.acq_w1, D, o / FRAG, 0, o % FRAG);
-      else if (o < 8 * FRAG + 128) v = a.acq_b1[o - 8 * FRAG];
-      else if (o < 8 * FRAG + 256) v = a.acq_w2[o - 8 * FRAG - 128];
-      else if (o == 8 * FRAG + 256) v = a.acq_b2[0];
+      if (o < 8 * FRAG3) v = frag3_word(a.acq_w1, D, o / FRAG3, 0, o % FRAG3);
+      else if (o < 8 * FRAG3 + 128) v = a.acq_b1[o - 8 * FRAG3];
+      else if (o < 8 * FRAG3 + 256) v = a.acq_w2[o - 8 * FRAG3 - 128];
+      else if (o == 8 * FRAG3 + 256) v = a.acq_b2[0];
     }
     a.out[i] = v;
   }
@@ -122,6 +144,64 @@ __device__ __forceinline__ void mma_block(f32x4 &acc, const Frag &A, const Frag 
 __device__ __forceinline__ void mma_half(f32x4 &acc, const f32x4 &A, const f32x4 &B) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], B[j], acc, 0, 0, 0);
+}
+
+// ---- split-bf16 ("bf16x6") products for the weight matmuls of the FFN and the acquisition MLP ---------
+// An fp32 value is EXACTLY hi + mid + lo with three bf16 (8 + 8 + 8 mantissa bits).  A product of two
+// such operands keeps the six terms down to 2^-16 relative (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
+// lo*hi) -- what is dropped is <= 3 * 2^-24, the size of fp32 rounding itself -- on the bf16 matrix
+// pipe: 6 x 16 cycles per 16x16x32 block instead of 8 x 32 cycles of v_mfma_f32_16x16x4_f32.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+struct Frag3 { bf16x8 p[3]; };
+
+__device__ __forceinline__ Frag3 ld_frag3(const float *base, int lane) {
+  Frag3 f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    f.p[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(base + p * 256 + lane * 4));
+  return f;
+}
+// two fp32 values -> three packed bf16 pairs (v_cvt_pk_bf16_f32 rounds to nearest even)
+__device__ __forceinline__ void split3_pair(float a0, float a1, unsigned &h, unsigned &m, unsigned &l) {
+  const f32x2 a = {a0, a1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+  const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  const f32x2 r = a - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  const f32x2 r2 = r - mf;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+// B operand of a 32-feature block from the two accumulator tiles that hold it (k order j = 0..7)
+__device__ __forceinline__ Frag3 split_acc(const f32x4 &lo, const f32x4 &hi) {
+  unsigned hh[4], mm[4], ll[4];
+  split3_pair(lo[0], lo[1], hh[0], mm[0], ll[0]);
+  split3_pair(lo[2], lo[3], hh[1], mm[1], ll[1]);
+  split3_pair(hi[0], hi[1], hh[2], mm[2], ll[2]);
+  split3_pair(hi[2], hi[3], hh[3], mm[3], ll[3]);
+  const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+  Frag3 f;
+  f.p[0] = __builtin_bit_cast(bf16x8, h);
+  f.p[1] = __builtin_bit_cast(bf16x8, m);
+  f.p[2] = __builtin_bit_cast(bf16x8, l);
+  return f;
+}
+#define MFMA16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+// acc += A B over one 32-deep block, six bf16 passes, small terms first
+__device__ __forceinline__ void mma6(f32x4 &acc, const Frag3 &A, const Frag3 &B) {
+  MFMA16(acc, A.p[0], B.p[2]); MFMA16(acc, A.p[2], B.p[0]); MFMA16(acc, A.p[1], B.p[1]);
+  MFMA16(acc, A.p[0], B.p[1]); MFMA16(acc, A.p[1], B.p[0]); MFMA16(acc, A.p[0], B.p[0]);
+}
+// the same for two independent accumulators sharing the B operand, interleaved
+__device__ __forceinline__ void mma6x2(f32x4 &acc0, f32x4 &acc1, const Frag3 &A0, const Frag3 &A1, const Frag3 &B) {
+  MFMA16(acc0, A0.p[0], B.p[2]); MFMA16(acc1, A1.p[0], B.p[2]);
+  MFMA16(acc0, A0.p[2], B.p[0]); MFMA16(acc1, A1.p[2], B.p[0]);
+  MFMA16(acc0, A0.p[1], B.p[1]); MFMA16(acc1, A1.p[1], B.p[1]);
+  MFMA16(acc0, A0.p[0], B.p[1]); MFMA16(acc1, A1.p[0], B.p[1]);
+  MFMA16(acc0, A0.p[1], B.p[0]); MFMA16(acc1, A1.p[1], B.p[0]);
+  MFMA16(acc0, A0.p[0], B.p[0]); MFMA16(acc1, A1.p[0], B.p[0]);
 }
 
 // reduce over the 4 lane groups (lanes l, l^16, l^32, l^48 hold the same token) with the gfx950
@@ -319,52 +399,30 @@ __device__ __forceinline__ void layer_tiles(f32x4 (&x)[NT][2], const float *Wl, 
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) layer_norm(x1[t], prm + PLN1W, prm + PLN1B, g);
-  // ---- x = LN2(x1 + W2 relu(W1 x1 + b1) + b2), hidden streamed in 32-wide chunks ----------------------------
+  // ---- x = LN2(x1 + W2 relu(W1 x1 + b1) + b2), hidden streamed in 32-wide chunks; split-bf16 products ----
   {
+    const float *Wf = Wl + FFN_BASE;
     const f32x4 b0 = ld4(prm + PB_2 + 4 * g), b1 = ld4(prm + PB_2 + 16 + 4 * g);
+    Frag3 x1f[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { x[t][0] = b0 + x1[t][0]; x[t][1] = b1 + x1[t][1]; }
+    for (int t = 0; t < NT; ++t) {
+      x[t][0] = b0 + x1[t][0]; x[t][1] = b1 + x1[t][1];
+      x1f[t] = split_acc(x1[t][0], x1[t][1]);
+    }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      const Frag u0 = ld_frag(Wl + (F1 + 2 * kb) * FRAG, lane), u1 = ld_frag(Wl + (F1 + 2 * kb + 1) * FRAG, lane);
+      const Frag3 u0 = ld_frag3(Wf + (F1 + 2 * kb) * FRAG3, lane), u1 = ld_frag3(Wf + (F1 + 2 * kb + 1) * FRAG3, lane);
       const f32x4 hb0 = ld4(prm + PB_1 + 32 * kb + 4 * g), hb1 = ld4(prm + PB_1 + 32 * kb + 16 + 4 * g);
       f32x4 hd[NT][2];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { hd[t][0] = hb0; hd[t][1] = hb1; }
+      for (int t = 0; t < NT; ++t) { hd[t][0] = hb0; hd[t][1] = hb1; mma6x2(hd[t][0], hd[t][1], u0, u1, x1f[t]); }
+      const Frag3 d0 = ld_frag3(Wf + (F2 + kb) * FRAG3, lane), d1 = ld_frag3(Wf + (F2 + 4 + kb) * FRAG3, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.lo[j], x1[t][0][j]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.lo[j], x1[t][0][j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.hi[j], x1[t][1][j]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.hi[j], x1[t][1][j]);
-      }
-      const Frag d0 = ld_frag(Wl + (F2 + kb) * FRAG, lane), d1 = ld_frag(Wl + (F2 + 4 + kb) * FRAG, lane);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hd[t][mt][r] = fmaxf(hd[t][mt][r], 0.f);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(x[t][0], d0.lo[j], hd[t][0][j]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(x[t][1], d1.lo[j], hd[t][0][j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(x[t][0], d0.hi[j], hd[t][1][j]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) MFMA4(x[t][1], d1.hi[j], hd[t][1][j]);
+        for (int r = 0; r < 4; ++r) { hd[t][0][r] = fmaxf(hd[t][0][r], 0.f); hd[t][1][r] = fmaxf(hd[t][1][r], 0.f); }
+        const Frag3 hf = split_acc(hd[t][0], hd[t][1]);
+        mma6x2(x[t][0], x[t][1], d0, d1, hf);
       }
     }
   }
@@ -376,39 +434,26 @@ __device__ __forceinline__ void layer_tiles(f32x4 (&x)[NT][2], const float *Wl, 
 template <int NT>
 __device__ __forceinline__ void acq_tiles(const f32x4 (&z)[NT][2], const float *Wl, int lane, int g,
                                           float (&lg)[NT]) {
-  const float *hb1 = Wl + 8 * FRAG, *hw2 = hb1 + 128, *hb2 = hw2 + 128;
+  const float *hb1 = Wl + 8 * FRAG3, *hw2 = hb1 + 128, *hb2 = hw2 + 128;
   float p[NT];
+  Frag3 zf[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) p[t] = 0.f;
+  for (int t = 0; t < NT; ++t) { p[t] = 0.f; zf[t] = split_acc(z[t][0], z[t][1]); }
 #pragma unroll
   for (int mp = 0; mp < 4; ++mp) {
-    const Frag u0 = ld_frag(Wl + (2 * mp) * FRAG, lane), u1 = ld_frag(Wl + (2 * mp + 1) * FRAG, lane);
+    const Frag3 u0 = ld_frag3(Wl + (2 * mp) * FRAG3, lane), u1 = ld_frag3(Wl + (2 * mp + 1) * FRAG3, lane);
     const f32x4 hb0 = ld4(hb1 + 32 * mp + 4 * g), hbb = ld4(hb1 + 32 * mp + 16 + 4 * g);
     const f32x4 w20 = ld4(hw2 + 32 * mp + 4 * g), w21 = ld4(hw2 + 32 * mp + 16 + 4 * g);
-    f32x4 hd[NT][2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { hd[t][0] = hb0; hd[t][1] = hbb; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.lo[j], z[t][0][j]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.lo[j], z[t][0][j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) MFMA4(hd[t][0], u0.hi[j], z[t][1][j]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) MFMA4(hd[t][1], u1.hi[j], z[t][1][j]);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      f32x4 h0 = hb0, h1 = hbb;
+      mma6x2(h0, h1, u0, u1, zf[t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[t] = fmaf(fmaxf(hd[t][0][r], 0.f), w20[r], p[t]);
-        p[t] = fmaf(fmaxf(hd[t][1][r], 0.f), w21[r], p[t]);
+        p[t] = fmaf(fmaxf(h0[r], 0.f), w20[r], p[t]);
+        p[t] = fmaf(fmaxf(h1[r], 0.f), w21[r], p[t]);
       }
+    }
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) lg[t] = group_sum(p[t]) + hb2[0];
@@ -587,15 +632,16 @@ __global__ __launch_bounds__(NTHREADS, 3) void rollout_f32_kernel(RolloutArgs a)
       {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wpack + (long)l * LAYER_FLOATS);
         f32x4 *dst = reinterpret_cast<f32x4 *>(Wl);
-        f32x4 buf[5];
+        constexpr int NIT = (LAYER_FLOATS / 4 + NTHREADS - 1) / NTHREADS;
+        f32x4 buf[NIT];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { const int q = tid + i * NTHREADS; if (q < LAYER_FLOATS / 4) buf[i] = src[q]; }
+        for (int i = 0; i < NIT; ++i) { const int q = tid + i * NTHREADS; if (q < LAYER_FLOATS / 4) buf[i] = src[q]; }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { const int q = tid + i * NTHREADS; if (q < LAYER_FLOATS / 4) dst[q] = buf[i]; }
+        for (int i = 0; i < NIT; ++i) { const int q = tid + i * NTHREADS; if (q < LAYER_FLOATS / 4) dst[q] = buf[i]; }
       }
       __syncthreads();   // weights + Xk visible
       STAMP_PHASE(2)   // weight stream + barrier
-      const float *prm = Wl + NFRAG_LAYER * FRAG;
+      const float *prm = Wl + PRM_BASE;
 
       // ---- pre-pass: K^T / V of the key tiles.  items: 0 K kt0, 1 V kt0, 2 K kt1, 3 V kt1 ------------
       if (valid) {
