@@ -557,17 +557,12 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   hipLaunchKernelGGL(fused::pack_weights_kernel, dim3(64), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
   fused::RolloutArgs a{};
-  a.B = r->B; a.P = r->P; a.n_ctx0 = r->n_ctx0; a.n_th = m->n_theta; a.T = r->T; a.L = m->L; a.C = m->C;
+  a.B = r->B; a.P = r->P; a.n_ctx0 = r->n_ctx0; a.n_th = m->n_theta; a.T = r->T; a.L = m->L;
   a.wpack = c.at(c.pl.Wpack); a.Ex = c.at(c.pl.Ex); a.Ey = c.at(c.pl.Ey);
-  a.theta_tokens = m->theta_tokens; a.tmask = r->target_mask; a.target_all = r->target_all;
-  for (int k = 0; k < m->C; ++k) {
-    a.gmm_w1[k] = m->gmm_w1[k]; a.gmm_b1[k] = m->gmm_b1[k];
-    a.gmm_w2[k] = m->gmm_w2[k]; a.gmm_b2[k] = m->gmm_b2[k];
-  }
-  a.std_min = m->std_min; a.mode = r->select_mode; a.uniform = r->uniform; a.forced = r->forced_idx;
+  a.theta_tokens = m->theta_tokens; a.tmask = r->target_mask;
+  a.mode = r->select_mode; a.uniform = r->uniform; a.forced = r->forced_idx;
   a.role = r->role; a.idx = r->idx; a.slot = r->slot; a.log_prob = r->log_prob;
-  a.target_ll = r->target_ll; a.zt = r->zt;
-  a.post_mean = r->post_mean; a.post_std = r->post_std; a.post_weight = r->post_weight;
+  a.zt = r->zt;
   a.ztg = c.at(c.pl.Ztg);
   // ALINE_FUSED_STAMPS=1 selects the diagnostic (s_memtime-stamped) instantiation; the stamps land
   // in the tail of the workspace scalar block and are never read by product code.

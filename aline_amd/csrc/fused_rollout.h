@@ -460,22 +460,17 @@ __device__ __forceinline__ void acq_tiles(const f32x4 (&z)[NT][2], const float *
 }
 
 struct RolloutArgs {
-  int B, P, n_ctx0, n_th, T, L, C;
+  int B, P, n_ctx0, n_th, T, L;
   const float *wpack;           // packed layer + head images
   const float *Ex, *Ey;         // [B, P, 32] cached point embeddings (rollout_init)
   const float *theta_tokens;    // [n_th, 32]
   const uint8_t *tmask;         // [n_th] or null
-  const float *target_all;      // [B, n_th] or null
-  const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
-  float std_min;
   int mode;                     // ALINE_SELECT_*
   const float *uniform;         // [T, B]
   const int64_t *forced;        // [B, T]
   int *role;                    // [B, P] out (final roles, for export)
   int64_t *idx; int *slot; float *log_prob;           // [B, T]
-  float *target_ll;                                   // [T, B, n_th]
   float *zt;                                          // [T, B, P - n_ctx0] or null
-  float *post_mean, *post_std, *post_weight;          // [T, B, n_th, C] or null
   float *ztg;                   // [T, B, n_th, 32] encoder outputs of the target rows (GMM runs after the loop)
   unsigned long long *stamps;   // diagnostic build only: per-phase cycle sums [8 waves x 16]
 };
@@ -602,28 +597,39 @@ __global__ __launch_bounds__(NTHREADS, 3) void rollout_f32_kernel(RolloutArgs a)
     STAMP_PHASE(0)   // key list
 
     // ---- X^(0): this wave's token tiles --------------------------------------------------------------
+    // all loads are issued before the first use so that their HBM/L2 latencies overlap
     f32x4 x[MAXT][2];
+    {
+      f32x4 ey[MAXT][2];
+      int kk[MAXT];
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int row = 16 * (t0 + i) + tok;
-      f32x4 v0 = zero4(), v1 = zero4();
-      if (valid && i < tcnt && row < N) {
-        const float *src = row < P ? a.Ex + ((long)b * P + row) * D : a.theta_tokens + (long)(row - P) * D;
-        v0 = ld4(src + 4 * g);
-        v1 = ld4(src + 16 + 4 * g);
-        if (row < P && role[row] != 0) {
-          const float *ey = a.Ey + ((long)b * P + row) * D;
-          v0 += ld4(ey + 4 * g);
-          v1 += ld4(ey + 16 + 4 * g);
-        }
-        const int k = kidx[row];
-        if (k >= 0) {
-          *reinterpret_cast<f32x4 *>(Xk + k * ES + 4 * g) = v0;
-          *reinterpret_cast<f32x4 *>(Xk + k * ES + 16 + 4 * g) = v1;
+      for (int i = 0; i < MAXT; ++i) {
+        int row = 16 * (t0 + i) + tok;
+        // keep the address arithmetic inside the step loop: hoisted to kernel entry it gets spilled and
+        // every reload drains the outstanding loads (s_waitcnt vmcnt(0)), serialising the whole prologue
+        asm volatile("" : "+v"(row));
+        const bool ok = valid && i < tcnt && row < N;
+        const float *src = ok ? (row < P ? a.Ex + ((long)b * P + row) * D : a.theta_tokens + (long)(row - P) * D)
+                              : a.theta_tokens;
+        x[i][0] = ld4(src + 4 * g);
+        x[i][1] = ld4(src + 16 + 4 * g);
+        const bool ctx = ok && row < P && role[row] != 0;
+        const float *eyp = ctx ? a.Ey + ((long)b * P + row) * D : a.theta_tokens;
+        ey[i][0] = ld4(eyp + 4 * g);
+        ey[i][1] = ld4(eyp + 16 + 4 * g);
+        if (!ctx) { ey[i][0] = zero4(); ey[i][1] = zero4(); }
+        if (!ok) { x[i][0] = zero4(); x[i][1] = zero4(); }
+        kk[i] = ok ? kidx[row] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        x[i][0] += ey[i][0];
+        x[i][1] += ey[i][1];
+        if (kk[i] >= 0) {
+          *reinterpret_cast<f32x4 *>(Xk + kk[i] * ES + 4 * g) = x[i][0];
+          *reinterpret_cast<f32x4 *>(Xk + kk[i] * ES + 16 + 4 * g) = x[i][1];
         }
       }
-      x[i][0] = v0;
-      x[i][1] = v1;
     }
     STAMP_PHASE(1)   // x0 load
 
