@@ -61,6 +61,23 @@ def fused_kernel_flops_per_episode(d, F, L, n_c0, n_q0, n_t, n_s, T):
     return total
 
 
+def fused_kernel_mfma_cycles_per_simd(L, n_c0, n_q0, n_t, n_s, T):
+    """MFMA issue cycles one SIMD spends on one episode in fused::rollout_f32_kernel (3 waves of an
+    episode share a SIMD).  v_mfma_f32_16x16x4_f32 = 32 cycles, v_mfma_f32_16x16x32_bf16 = 16 cycles
+    (MI355X_MICROARCH.md, per-instruction cycle constants).  Per 16-token tile and layer:
+      fp32 MFMAs:  Wq 16 + Wo 16 + scores 16 * kt + PV 16 * kt     (kt = 1 while <= 16 keys, else 2)
+      split-bf16:  FFN 16 blocks x 6 passes;   acquisition MLP: 8 blocks x 6 passes per tile and step
+    plus the K/V pre-pass of the key tiles (2 blocks x 8 fp32 MFMAs per item, 2 * kt items)."""
+    cyc = 0.0
+    N = n_c0 + n_q0 + n_t
+    tiles = (N + 15) // 16
+    for t in range(T):
+        kt = 2 if (n_c0 + t + n_s) > 16 else 1
+        per_tile_layer = (32 + 32 * kt) * 32 + 16 * 6 * 16
+        cyc += L * (tiles * per_tile_layer + 2 * kt * 16 * 32) + tiles * 8 * 6 * 16
+    return cyc
+
+
 class HipEvents:
     """A hipEvent_t pair created through libamdhip64 (torch's own HIP runtime) so that the C ABI can
     record them on the launch stream around the dominant kernel."""
@@ -243,20 +260,39 @@ def main():
                                           1, args.n_query, 0, 2, 2, args.T, with_query_gmm=False)
     fused = (args.d_model == 32 and args.d_ff == 128 and args.heads == 4 and args.precision == "f32"
              and kernel_ms > 0.0)
+    extra = {}
     if fused:
         fl_k = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
         achieved_tflops = fl_k * args.batch / (kernel_ms * 1e-3) / 1e12
         kname, per_launch = "fused::rollout_f32_kernel<false>", fl_k * args.batch
+        # The kernel issues two MFMA kinds (fp32 16x16x4 for attention / projections, split-bf16 x6 for
+        # the FFN and the acquisition MLP), so its matrix-pipe roofline is the time its own MFMA stream
+        # needs at 100 % issue on all 1024 SIMDs (one episode per SIMD, ceil(B / 1024) rounds).
+        cyc = fused_kernel_mfma_cycles_per_simd(args.layers, 1, args.n_query, 2, 2, args.T)
+        rounds = -(-args.batch // 1024)
+        roof_ms = cyc * rounds / 2.4e9 * 1e3
+        peak = fl_k * args.batch / (roof_ms * 1e-3) / 1e12
+        extra = {"mfma_issue_roofline_ms": roof_ms, "frac_vs_fp32_mfma_peak_157.3": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                 "peak_note": "peak = algorithmic FLOPs / (MFMA issue cycles of this kernel's instruction mix "
+                              "at 2.4 GHz on 1024 SIMDs); pure-fp32-MFMA peak 157.3 TF/s given beside it"}
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_fused_f32_d32_pmc_traffic.json")))
+            traffic = tr["hbm_bytes_per_launch"] if args.batch == 1000 and args.T == 30 else None
+            extra["traffic_source"] = "rocprofv3 PMC (profiles/r01_fused_f32_d32_pmc_traffic.json), not re-measured in this run"
+        except Exception:
+            traffic = None
     else:   # generic pipeline: many kernels per step; report the whole graph as a lower bound
         achieved_tflops = fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12
         kname, per_launch, kernel_ms = "whole rollout graph (generic pipeline, all kernels)", fl_ep * args.batch, dev_ms / args.steps
-    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_DENSE_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_DENSE_TFLOPS
+        traffic = None
     out = {
         "metric": "candidate designs scored/sec (batch x T x n_query), location_finding T=30",
         "value": value, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32", "bf16": "bf16", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)"}[args.precision],
+        "dtype": {"f32": "f32 (fp32 MFMA; FFN/acquisition products as exact 3-way split-bf16, fp32 accumulate)",
+                  "bf16": "bf16", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": "location_finding K=1, batch=1000, T=30, n_query_init=200: T-step rollout "
                                "forward (embed + encoder + heads + design sampling + context update + "
@@ -268,11 +304,11 @@ def main():
                    "hip_graph": bool(args.graph), "exact_designs_per_rollout": exact,
                    "parallelism": f"episode-dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved_tflops / peak, "traffic": None, "kernel": kname,
+                     "frac": achieved_tflops / peak, "traffic": traffic, "kernel": kname,
                      "kernel_ms_per_launch": kernel_ms, "algorithmic_flops_per_launch": per_launch,
                      "algorithmic_flops_per_episode_all_kernels": fl_ep,
                      "device_ms_per_rollout": dev_ms / args.steps,
-                     "note": "peak = fp32 MFMA (v_mfma_f32_16x16x4_f32) for dtype f32, dense bf16 MFMA otherwise"},
+                     **extra},
     }
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms per rollout")
     if args.train_steps > 0 and args.precision == "f32":
