@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include "eig.h"
 #include "fused_rollout.h"
+#include "fused_side.h"
 #include "backward.h"
 
 #include <algorithm>
@@ -61,7 +62,8 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   p.Tm = take(M * d);
   p.Wacq = take(F * d);
   p.scalar = take(64);
-  p.Wpack = take((size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS);
+  p.Wpack = take((size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS +
+                 (size_t)(ALINE_MAX_COMPONENTS + 2) * fused::SIDE_FRAGS);
   p.Stamps = take(512);   // diagnostic stamps of the fused kernel (8 x 16 x u64)
   p.Ztg = take((size_t)T * B * n_t * d);   // fused rollout: target-row encodings of all steps
   p.total = off;
@@ -539,9 +541,6 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   Ctx c;
   TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
   TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
-  // step-invariant point embeddings (x- and y-embedder of every slot)
-  Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
-  TRY(do_embed_points(c, xs, r->point_y, r->P));
   fused::PackArgs pa{};
   pa.L = m->L;
   for (int l = 0; l < m->L; ++l) {
@@ -553,9 +552,27 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
     pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
   }
   pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
+  pa.C = m->C;
+  for (int k = 0; k < m->C; ++k) pa.gmm_w1[k] = m->gmm_w1[k];
+  pa.x_w2 = m->x_w2; pa.y_w2 = m->y_w2;
   pa.out = c.at(c.pl.Wpack);
-  hipLaunchKernelGGL(fused::pack_weights_kernel, dim3(64), dim3(256), 0, c.st, pa);
+  hipLaunchKernelGGL(fused::pack_weights_kernel, dim3(128), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
+  const float *side = c.at(c.pl.Wpack) + (size_t)m->L * fused::LAYER_FLOATS + fused::HEAD_FLOATS;
+  // step-invariant point embeddings (x- and y-embedder of every slot): fused embedder kernel
+  {
+    const long rows = (long)r->B * r->P;
+    fused::EmbedArgs ex{};
+    ex.x = r->point_x; ex.K = m->dim_x; ex.rows = rows; ex.w1 = m->x_w1; ex.b1 = m->x_b1; ex.b2 = m->x_b2;
+    ex.w2img = side + (size_t)m->C * fused::SIDE_FRAGS; ex.out = c.at(c.pl.Ex);
+    const unsigned grid = (unsigned)std::min<long>((rows + 63) / 64, 2048);
+    hipLaunchKernelGGL(fused::embed_points_kernel, dim3(grid), dim3(256), 0, c.st, ex);
+    fused::EmbedArgs ey = ex;
+    ey.x = r->point_y; ey.K = m->dim_y; ey.w1 = m->y_w1; ey.b1 = m->y_b1; ey.b2 = m->y_b2;
+    ey.w2img = side + (size_t)(m->C + 1) * fused::SIDE_FRAGS; ey.out = c.at(c.pl.Ey);
+    hipLaunchKernelGGL(fused::embed_points_kernel, dim3(grid), dim3(256), 0, c.st, ey);
+    CHECK_LAUNCH();
+  }
   fused::RolloutArgs a{};
   a.B = r->B; a.P = r->P; a.n_ctx0 = r->n_ctx0; a.n_th = m->n_theta; a.T = r->T; a.L = m->L;
   a.wpack = c.at(c.pl.Wpack); a.Ex = c.at(c.pl.Ex); a.Ey = c.at(c.pl.Ey);
@@ -581,14 +598,15 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   if (r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
   // GMM posterior + compute_ll of all T steps on the saved target-row encodings [T*B*n_t, d]
   if (r->post_mean || r->post_std || r->post_weight || r->target_ll) {
-    const long rows = (long)r->T * r->B * m->n_theta;
-    for (long r0 = 0; r0 < rows; r0 += (long)kGmmChunkRows) {
-      const int nr = (int)std::min<long>(kGmmChunkRows, rows - r0);
-      TRY(do_gmm_rows(c, c.at(c.pl.Ztg) + r0 * m->d, nr, r->post_mean ? r->post_mean + r0 * m->C : nullptr,
-                      r->post_std ? r->post_std + r0 * m->C : nullptr,
-                      r->post_weight ? r->post_weight + r0 * m->C : nullptr, r->target_all,
-                      r->target_ll ? r->target_ll + r0 : nullptr, r0, (long)r->B * m->n_theta));
-    }
+    fused::GmmRowsArgs ga{};
+    ga.z = c.at(c.pl.Ztg); ga.rows = (long)r->T * r->B * m->n_theta; ga.C = m->C; ga.std_min = m->std_min;
+    ga.w1img = side;
+    for (int k = 0; k < m->C; ++k) { ga.b1[k] = m->gmm_b1[k]; ga.w2[k] = m->gmm_w2[k]; ga.b2[k] = m->gmm_b2[k]; }
+    ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
+    ga.value = r->target_all; ga.value_row0 = 0; ga.value_mod = (long)r->B * m->n_theta;
+    ga.ll = r->target_all ? r->target_ll : nullptr;
+    hipLaunchKernelGGL(fused::gmm_rows_kernel, dim3((unsigned)((ga.rows + 63) / 64)), dim3(256), 0, c.st, ga);
+    CHECK_LAUNCH();
   }
   return ALINE_OK;
 }

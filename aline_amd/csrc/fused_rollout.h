@@ -49,8 +49,12 @@ struct PackArgs {
   const float *in_proj_w[8], *in_proj_b[8], *out_proj_w[8], *out_proj_b[8], *lin1_w[8], *lin1_b[8],
       *lin2_w[8], *lin2_b[8], *n1w[8], *n1b[8], *n2w[8], *n2b[8];
   const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
-  float *out;   // [L * LAYER_FLOATS + HEAD_FLOATS]
+  int C;                                        // side images (fused_side.h), after the head image:
+  const float *gmm_w1[16];                      //   C x 8 split-bf16 fragments of the GMM first layers
+  const float *x_w2, *y_w2;                     //   8 + 8 fragments of the point embedders' second layers
+  float *out;   // [L * LAYER_FLOATS + HEAD_FLOATS + (C + 2) * 8 * FRAG3]
 };
+constexpr int SIDE_FRAGS = 8 * FRAG3;          // one [128 x 32] or [32 x 128] weight as 8 fragments
 
 // element (lane, j) of fragment (mt, kb) of a [rows, K] row-major weight: W[16 mt + (lane & 15)][pi]
 __device__ __forceinline__ float frag_val(const float *W, int K, int mt, int kb, int lane, int j) {
@@ -80,7 +84,8 @@ __device__ __forceinline__ float frag3_word(const float *W, int K, int mt, int k
 }
 
 __global__ void pack_weights_kernel(PackArgs a) {
-  const int total = a.L * LAYER_FLOATS + HEAD_FLOATS;
+  const int core = a.L * LAYER_FLOATS + HEAD_FLOATS;
+  const int total = core + (a.C + 2) * SIDE_FRAGS;
   // 1/sqrt(hd) and log2(e) folded into Wq, bq: the kernel's softmax is exp2(s - max)
   const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -112,6 +117,10 @@ __global__ void pack_weights_kernel(PackArgs a) {
         else if (p < PLN2B) v = a.n2w[l][p - PLN2W];
         else v = a.n2b[l][p - PLN2B];
       }
+    } else if (i >= core) {
+      const int o = i - core, img = o / SIDE_FRAGS, e = o % SIDE_FRAGS;
+      if (img < a.C) v = frag3_word(a.gmm_w1[img], D, e / FRAG3, 0, e % FRAG3);                 // [128, 32]
+      else v = frag3_word(img == a.C ? a.x_w2 : a.y_w2, F, (e / FRAG3) >> 2, (e / FRAG3) & 3, e % FRAG3);   // [32, 128]
     } else {
       const int o = i - a.L * LAYER_FLOATS;
       if (o < 8 * FRAG3) v = frag3_word(a.acq_w1, D, o / FRAG3, 0, o % FRAG3);
