@@ -994,3 +994,11 @@ extern "C" int aline_rollout_backward(const aline_model *m, const aline_rollout 
   }
   return ALINE_OK;
 }
+
+extern "C" int aline_cholesky_upper(float *A, int n, int batch, int32_t *info, void *stream) {
+  if (!A || n < 1 || batch < 1 || n > 8192) return ALINE_EINVAL;
+  hipLaunchKernelGGL(cholesky_upper_kernel, dim3(batch), dim3(256), (size_t)n * sizeof(float),
+                     static_cast<hipStream_t>(stream), A, n, info);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}

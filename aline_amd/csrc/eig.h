@@ -151,3 +151,34 @@ __global__ void eig_lse_combine_kernel(const float *__restrict__ S, const float 
   if (pce) pce[b] = logf(L + 1.f) - (lse0 - s0);
   if (nmc) nmc[b] = logf(L) - (lse1 - s0);
 }
+
+
+// ---- batched Cholesky for the GP task sampler (tasks/gaussian_process.py:391-415) ------
+// A = U^T U, U upper triangular, in place on the upper triangle of each [n, n] matrix (the strict lower
+// triangle is zeroed).  One workgroup per matrix, left-looking by rows of U:
+//   s_i = A[j][i] - sum_{k<j} U[k][i] U[k][j]   (i >= j; threads run over i: coalesced rows of U)
+//   U[j][j] = sqrt(s_j);  U[j][i] = s_i / U[j][j]
+__global__ __launch_bounds__(256) void cholesky_upper_kernel(float *__restrict__ A, int n, int *info) {
+  extern __shared__ float colj[];              // U[0..j)[j]
+  __shared__ float diag;
+  float *M = A + (long)blockIdx.x * n * n;
+  const int tid = threadIdx.x;
+  for (int j = 0; j < n; ++j) {
+    for (int k = tid; k < j; k += 256) colj[k] = M[(long)k * n + j];
+    __syncthreads();
+    for (int i = j + tid; i < n; i += 256) {
+      float s = M[(long)j * n + i];
+      for (int k = 0; k < j; ++k) s = fmaf(-M[(long)k * n + i], colj[k], s);
+      M[(long)j * n + i] = s;
+      if (i == j) {
+        if (!(s > 0.f)) atomicOr(info, 1);
+        diag = sqrtf(fmaxf(s, 1e-30f));
+      }
+    }
+    __syncthreads();
+    const float inv = 1.f / diag;
+    for (int i = j + tid; i < n; i += 256) M[(long)j * n + i] = (i == j) ? diag : M[(long)j * n + i] * inv;
+    for (int i = tid; i < j; i += 256) M[(long)j * n + i] = 0.f;     // strict lower part of row j
+    __syncthreads();
+  }
+}

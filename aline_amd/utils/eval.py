@@ -59,3 +59,30 @@ def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=4
     else:
         pce, nmc = pce_l[-1], nmc_l[-1]
     return math.log(L + 1) - pce, math.log(L) - nmc
+
+
+@torch.no_grad()
+def eval_boed(model, experiment, T=30, L=int(1e6), M=2000, batch_size=40, time_token=False, stepwise=False,
+              err_type="se"):
+    """Final evaluation of the EIG bounds (eval.py:142-198): ceil(M / batch) x (rollout, bounds)."""
+    from .attrdict import AttrDict
+    model.eval()
+    pce_l, nmc_l = [], []
+    for _ in range((M + batch_size - 1) // batch_size):
+        theta_0, x, y = get_traces(model, experiment, T, batch_size, time_token)
+        pce, nmc = compute_EIG_from_history(experiment, theta_0, x, y, L, batch_size, stepwise)
+        pce_l.append(pce)
+        nmc_l.append(nmc)
+    pce, nmc = torch.cat(pce_l, dim=0), torch.cat(nmc_l, dim=0)
+    n = pce.shape[0]
+    out = {}
+    for nm, v in (("pce", pce), ("nmc", nmc)):
+        err = torch.std(v, dim=0)
+        if err_type == "se":
+            err = err / math.sqrt(n)
+        elif err_type == "ci":
+            err = 1.96 * err / math.sqrt(n)
+        elif err_type != "std":
+            raise ValueError(f"Unknown err_type: {err_type}")
+        out[nm + "_mean"], out[nm + "_err"] = torch.mean(v, dim=0).cpu(), err.cpu()
+    return AttrDict(out)

@@ -181,6 +181,13 @@ size_t aline_eig_finalize_workspace_bytes(int64_t L1, int B);
 int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc, void *ws,
                        size_t ws_bytes, void *stream);
 
+/* --- task samplers (input generators) ---------------------------------------------- */
+/* Batched in-place Cholesky A = U^T U of `batch` symmetric positive-definite [n,n] matrices (upper
+ * factor; strict lower triangle zeroed), for GPTask.generate_gp_data (tasks/gaussian_process.py:391-415:
+ * one torch.linalg.cholesky per episode in a Python loop).  info (device int, may be NULL) is set to 1
+ * if a pivot is not positive. */
+int aline_cholesky_upper(float *A, int n, int batch, int32_t *info, void *stream);
+
 /* --- training: backward of the T-step objective ------------------------------------------------- */
 /* Gradient buffers, one per weight of aline_model (same shapes), ACCUMULATED into (+=): the caller
  * zeroes them (optimizer.zero_grad(), train_aline.py:56) and owns them (param.grad storage). */
