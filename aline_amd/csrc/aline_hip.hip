@@ -307,7 +307,6 @@ int do_acquisition(const Ctx &c, const float *Z, HeadIO io) {
 
 // OutputHead.forward (model/head.py:319-393)
 int do_head(const Ctx &c, const float *Z, HeadIO io) {
-  const aline_model &m = *c.m;
   const Geo &g = c.g;
   const int n_t = g.n_td + g.n_th;
   const bool want_sel = io.sel.idx || io.sel.log_prob || io.sel.zt || io.sel.slot || io.sel.role_out;

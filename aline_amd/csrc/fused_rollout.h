@@ -518,7 +518,7 @@ constexpr int MAXT = 5;   // tiles per wave (at most 15 tiles / 3 waves: N <= 24
 //     VB  4 fragments x 512           V head-block fragments
 //         (head phase reuses KB: logits[256])
 //     XK  [NKMAX][ES]                 inputs of the key rows for the next pre-pass
-//     INT role u8[256] | kidx i8[256] | qslot u8[256] | misc int[16]
+//     INT role u8[256] | kidx i8[256] | (spare 256 B) | misc int[16]
 constexpr int EP_KB = 0, EP_VB = EP_KB + 8 * 256, EP_XK = EP_VB + 4 * FRAG, EP_INT = EP_XK + NKMAX * ES;
 constexpr int EP_FLOATS = EP_INT + (3 * MAXROWS) / 4 + 16;
 constexpr int HP_LOGIT = 0, HP_ZT = HP_LOGIT + MAXROWS, HP_RAW = HP_ZT + MAXNT * ES;   // inside KB
@@ -553,7 +553,6 @@ __global__ __launch_bounds__(NTHREADS, 3) void rollout_f32_kernel(RolloutArgs a)
   float *logit = Kb + HP_LOGIT;
   unsigned char *role = reinterpret_cast<unsigned char *>(ep + EP_INT);   // 0 query, k>0 k-th context, 255 n/a
   signed char *kidx = reinterpret_cast<signed char *>(role + MAXROWS);
-  unsigned char *qslot = role + 2 * MAXROWS;
   int *misc = reinterpret_cast<int *>(role + 3 * MAXROWS);
   float *fmisc = reinterpret_cast<float *>(misc + 8);
   // misc: 0 n_ck, 1 n_ak, 2..4 per-wave counts, 5 nq, 6 choice;  fmisc: 0..2 per-wave partials, 3 total

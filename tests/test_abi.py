@@ -94,3 +94,58 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "aline_oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
+
+
+def _small_model():
+    from aline_amd import _lib
+    m = _lib.AlineModel()
+    m.dim_x, m.dim_y, m.d, m.F, m.H, m.L, m.C = 2, 1, 32, 128, 4, 3, 10
+    m.n_theta, m.embedding_type = 2, 1
+    fake = 0x1000                                    # never dereferenced: validation fails first
+    for n in ("x_w1", "x_b1", "x_w2", "x_b2", "y_w1", "y_b1", "y_w2", "y_b2", "theta_tokens", "acq_w1", "acq_b1",
+              "acq_w2", "acq_b2"):
+        setattr(m, n, fake)
+    for l in range(3):
+        for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+                  "norm1_w", "norm1_b", "norm2_w", "norm2_b"):
+            getattr(m, n)[l] = fake
+    for c in range(10):
+        for n in ("gmm_w1", "gmm_b1", "gmm_w2", "gmm_b2"):
+            getattr(m, n)[c] = fake
+    return m
+
+
+def test_error_codes_before_any_launch(lib):
+    """Argument / shape / workspace validation happens on the host before the first kernel launch, so
+    the error behaviour is testable without a GPU: bad calls return ALINE_E* and never throw."""
+    from aline_amd import _lib
+    L = _lib.lib
+    m = _small_model()
+    s = _lib.AlineStep()
+    s.B, s.n_ctx, s.n_query, s.n_target_data = 4, 1, 20, 0
+    s.context_x = s.context_y = s.query_x = s.target_all = 0x1000
+    ws = 0x2000
+    byref = ctypes.byref
+    assert L.aline_step_forward(byref(m), byref(s), ws, 16, None) == -3            # ALINE_EWORKSPACE
+    assert L.aline_step_forward(None, byref(s), ws, 1 << 30, None) == -1           # ALINE_EINVAL
+    s.n_ctx = 0                                                                     # n_ctx >= 1 (SURVEY 7, edge cases)
+    assert L.aline_step_forward(byref(m), byref(s), ws, 1 << 30, None) == -1
+    s.n_ctx = 1
+    s.select_mode = 1                                                               # SAMPLE without uniforms
+    assert L.aline_step_forward(byref(m), byref(s), ws, 1 << 30, None) == -1
+    s.select_mode = 0
+    m.d = 48                                                                        # d % 32 != 0
+    assert L.aline_step_forward(byref(m), byref(s), ws, 1 << 30, None) == -2       # ALINE_EUNSUPPORTED
+    m.d = 32
+    m.dim_y = 2                                                                     # GMM head is single-output
+    assert L.aline_step_forward(byref(m), byref(s), ws, 1 << 30, None) == -2
+    m.dim_y = 1
+    m.lin1_w[1] = None                                                              # missing weight pointer
+    assert L.aline_step_forward(byref(m), byref(s), ws, 1 << 30, None) == -1
+    r = _lib.AlineRollout()
+    r.B, r.P, r.n_ctx0, r.T = 4, 21, 1, 30                                          # n_ctx0 + T > P
+    r.point_x = r.point_y = r.role = 0x1000
+    m = _small_model()
+    assert L.aline_rollout_forward(byref(m), byref(r), ws, 1 << 40, None) == -1
+    assert L.aline_eig_finalize(0x1000, 1, 4, None, None, ws, 1 << 20, None) == -1  # needs L >= 1
+    assert L.aline_cholesky_upper(None, 4, 1, None, None) == -1
