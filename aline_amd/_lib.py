@@ -103,6 +103,7 @@ def _load():
         "aline_cholesky_upper": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp]),
         "aline_rollout_backward_workspace_bytes": (C.c_size_t, [MP, RP, C.c_int]),
         "aline_rollout_backward": (C.c_int, [MP, RP, _fp, _fp, GP, C.c_int, _fp, C.c_size_t, _fp]),
+        "aline_rollout_backward_ex": (C.c_int, [MP, RP, _fp, _fp, _fp, _fp, _fp, GP, C.c_int, _fp, C.c_size_t, _fp]),
         "aline_eig_finalize": (C.c_int, [_fp, C.c_int64, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     }
     for name, (res, args) in sig.items():

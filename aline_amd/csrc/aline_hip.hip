@@ -809,7 +809,16 @@ extern "C" size_t aline_rollout_backward_workspace_bytes(const aline_model *m, c
 extern "C" int aline_rollout_backward(const aline_model *m, const aline_rollout *r, const float *g_logp,
                                       const float *g_ll, const aline_grads *gr, int t_chunk, void *ws,
                                       size_t ws_bytes, void *stream) {
-  if (!m || !r || !g_logp || !g_ll || !gr || !ws || t_chunk < 1) return ALINE_EINVAL;
+  if (!g_ll) return ALINE_EINVAL;
+  return aline_rollout_backward_ex(m, r, g_logp, g_ll, nullptr, nullptr, nullptr, gr, t_chunk, ws, ws_bytes, stream);
+}
+
+extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollout *r, const float *g_logp,
+                                         const float *g_ll, const float *g_pm, const float *g_ps,
+                                         const float *g_pw, const aline_grads *gr, int t_chunk, void *ws,
+                                         size_t ws_bytes, void *stream) {
+  if (!m || !r || !g_logp || !gr || !ws || t_chunk < 1) return ALINE_EINVAL;
+  if (!g_ll && !g_pm && !g_ps && !g_pw) return ALINE_EINVAL;
   TRY(validate_model(*m));
   if (m->precision != ALINE_PREC_F32 || m->time_token) return ALINE_EUNSUPPORTED;
   if (!r->role || !r->slot || !r->point_x || !r->point_y || !r->target_all) return ALINE_EINVAL;
@@ -918,7 +927,10 @@ extern "C" int aline_rollout_backward(const aline_model *m, const aline_rollout 
       a.hid = HidG; a.rows = (long)I * n_t; a.C = C; a.F = F; a.std_min = m->std_min;
       for (int k = 0; k < C; ++k) { a.w2[k] = m->gmm_w2[k]; a.b2[k] = m->gmm_b2[k]; a.dw2[k] = gr->gmm_w2[k]; a.db2[k] = gr->gmm_b2[k]; }
       a.value = r->target_all; a.value_mod = (long)B * n_t;
-      a.g_ll = g_ll + (size_t)tA * B * n_t;
+      a.g_ll = g_ll ? g_ll + (size_t)tA * B * n_t : nullptr;
+      a.g_mean = g_pm ? g_pm + (size_t)tA * B * n_t * C : nullptr;
+      a.g_std = g_ps ? g_ps + (size_t)tA * B * n_t * C : nullptr;
+      a.g_wgt = g_pw ? g_pw + (size_t)tA * B * n_t * C : nullptr;
       hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();
       float *Wt = c.at(c.pl.Wt);   // [d, C*F]: column block k = W1_k^T

@@ -337,7 +337,8 @@ struct GmmBwdArgs {
   float *dw2[16]; float *db2[16];
   float std_min;
   const float *value; long value_mod;          // target value of row r: value[r % value_mod]
-  const float *g_ll;                           // [rows] dLoss/d ll
+  const float *g_ll;                           // [rows] dLoss/d ll, or null
+  const float *g_mean, *g_std, *g_wgt;         // [rows, C] dLoss/d mixture_{means,stds,weights}, or null
 };
 __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
   const int lane = threadIdx.x & 63;
@@ -366,12 +367,20 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
   const float m2 = wave_max(lp);
   const float er = act ? __expf(lp - m2) : 0.f;
   const float resp = er / wave_sum(er);          // responsibilities
-  const float gl = a.g_ll[row];
+  const float gl = a.g_ll ? a.g_ll[row] : 0.f;
   // d ll / d raw
-  const float d0 = act ? gl * resp * z / sd : 0.f;                                  // mean
-  const float dsd = act ? gl * resp * (z * z - 1.f) / sd : 0.f;                     // sigma
+  float d0 = act ? gl * resp * z / sd : 0.f;                                        // mean
+  float dsd = act ? gl * resp * (z * z - 1.f) / sd : 0.f;                           // sigma
+  float d2 = act ? gl * (resp - wgt) : 0.f;                                         // mixture logits
+  // direct upstream gradients of the GMM parameters (autograd through the caller's own compute_ll)
+  if (a.g_mean && act) d0 += a.g_mean[row * a.C + lane];
+  if (a.g_std && act) dsd += a.g_std[row * a.C + lane];
+  if (a.g_wgt) {
+    const float gw = act ? a.g_wgt[row * a.C + lane] : 0.f;
+    const float dot = wave_sum(gw * wgt);
+    if (act) d2 += wgt * (gw - dot);                                                // softmax backward
+  }
   const float d1 = dsd * (1.f / (1.f + __expf(-raw1)));                             // softplus'
-  const float d2 = act ? gl * (resp - wgt) : 0.f;                                   // mixture logits
   for (int c = 0; c < a.C; ++c) {
     const float g0 = __shfl(d0, c, 64), g1 = __shfl(d1, c, 64), g2 = __shfl(d2, c, 64);
     float *hp = a.hid + (row * a.C + c) * a.F;

@@ -13,6 +13,30 @@ from .encoder import Encoder
 from .head import OutputHead
 
 
+class _AlineStepFn(torch.autograd.Function):
+    """Autograd node of one `Aline.forward(batch)`: HIP forward (aline_step_forward), HIP backward
+    (aline_rollout_backward_ex on the step as a T = 1 rollout).  Differentiable outputs: design_out.log_prob
+    and posterior_out.mixture_{means,stds,weights} -- what train_aline.py:84-125 back-propagates through."""
+
+    @staticmethod
+    def forward(ctx, model, batch, forced_idx, uniform, *params):
+        with torch.no_grad():
+            out = model._forward_impl(batch, forced_idx, uniform, False)
+        ctx.model, ctx.batch = model, {k: _native._get(batch, k) for k in
+                                       ("context_x", "context_y", "query_x", "target_x", "target_all", "target_mask")}
+        d, p = out.design_out, out.posterior_out
+        ctx.idx = d.idx
+        ctx.mark_non_differentiable(d.idx, d.zt)
+        ctx.lazy_query = out.posterior_out_query
+        return d.log_prob, p.mixture_means, p.mixture_stds, p.mixture_weights, d.zt, d.idx
+
+    @staticmethod
+    def backward(ctx, g_logp, g_mean, g_std, g_weight, _g_zt, _g_idx):
+        from ..train import step_backward
+        grads = step_backward(ctx.model, ctx.batch, ctx.idx, g_logp, g_mean, g_std, g_weight)
+        return (None, None, None, None, *grads)
+
+
 class Aline(nn.Module):
     def __init__(self, embedder: Embedder, encoder: Encoder, head: OutputHead,
                  precision: str = None) -> None:
@@ -44,8 +68,24 @@ class Aline(nn.Module):
     def forward(self, batch, forced_idx=None, uniform=None, return_hidden=False):
         """batch: AttrDict of SURVEY.md 8-b.4.  Extra (optional) arguments are not in the
         reference: `forced_idx` teacher-forces the design (parity tests), `uniform` [B] supplies the
-        sampling randoms, `return_hidden` adds `embedding` / `encoding` to the output."""
-        _native.require_no_grad(self)
+        sampling randoms, `return_hidden` adds `embedding` / `encoding` to the output.
+
+        Under autograd (grad enabled and trainable parameters) the call is one autograd node with a native
+        backward, so the reference's own training loop (`loss.backward()`, train_aline.py:128) works on
+        the returned `design_out.log_prob` / `posterior_out.*`."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if return_hidden:
+                raise NotImplementedError("aline_amd: return_hidden is forward-only (use torch.no_grad())")
+            from ..utils.attrdict import AttrDict
+            params = list(self.parameters())
+            lp, pm, ps, pw, zt, idx = _AlineStepFn.apply(self, batch, forced_idx, uniform, *params)
+            node = lp.grad_fn
+            return AttrDict(posterior_out_query=getattr(node, "lazy_query", None) or AttrDict(),
+                            posterior_out=AttrDict(mixture_means=pm, mixture_stds=ps, mixture_weights=pw),
+                            design_out=AttrDict(idx=idx, log_prob=lp, zt=zt))
+        return self._forward_impl(batch, forced_idx, uniform, return_hidden)
+
+    def _forward_impl(self, batch, forced_idx, uniform, return_hidden):
         m = self.model_struct()
         call = _native.StepCall(batch, m.n_theta)
         outs = self.head._prepare(call, batch, forced_idx, uniform)

@@ -9,36 +9,38 @@ from . import _lib
 from .rollout import Rollout
 
 
-def _grad_struct(model):
-    """`aline_grads` pointing at param.grad of every weight (allocated + zeroed if missing)."""
-    for p in model.parameters():
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
+def _grad_struct(model, into=None):
+    """`aline_grads` pointing at param.grad of every weight (allocated + zeroed if missing), or at the
+    tensors of `into` (dict id(param) -> tensor) when given."""
+    if into is None:
+        for p in model.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+
+    def gp(p):
+        return (p.grad if into is None else into[id(p)]).data_ptr()
+
     g = _lib.AlineGrads()
     emb, enc, head = model.embedder, model.encoder, model.head
     for nm in ("x", "y"):
         seq = getattr(emb, f"{nm}_embedder")
-        setattr(g, f"{nm}_w1", seq[0].weight.grad.data_ptr())
-        setattr(g, f"{nm}_b1", seq[0].bias.grad.data_ptr())
-        setattr(g, f"{nm}_w2", seq[2].weight.grad.data_ptr())
-        setattr(g, f"{nm}_b2", seq[2].bias.grad.data_ptr())
+        setattr(g, f"{nm}_w1", gp(seq[0].weight))
+        setattr(g, f"{nm}_b1", gp(seq[0].bias))
+        setattr(g, f"{nm}_w2", gp(seq[2].weight))
+        setattr(g, f"{nm}_b2", gp(seq[2].bias))
     if hasattr(emb, "theta_tokens"):
-        g.theta_tokens = emb.theta_tokens.grad.data_ptr()
+        g.theta_tokens = gp(emb.theta_tokens)
     for l, layer in enumerate(enc.encoder.layers):
-        g.in_proj_w[l] = layer.self_attn.in_proj_weight.grad.data_ptr()
-        g.in_proj_b[l] = layer.self_attn.in_proj_bias.grad.data_ptr()
-        g.out_proj_w[l] = layer.self_attn.out_proj.weight.grad.data_ptr()
-        g.out_proj_b[l] = layer.self_attn.out_proj.bias.grad.data_ptr()
-        g.lin1_w[l], g.lin1_b[l] = layer.linear1.weight.grad.data_ptr(), layer.linear1.bias.grad.data_ptr()
-        g.lin2_w[l], g.lin2_b[l] = layer.linear2.weight.grad.data_ptr(), layer.linear2.bias.grad.data_ptr()
-        g.norm1_w[l], g.norm1_b[l] = layer.norm1.weight.grad.data_ptr(), layer.norm1.bias.grad.data_ptr()
-        g.norm2_w[l], g.norm2_b[l] = layer.norm2.weight.grad.data_ptr(), layer.norm2.bias.grad.data_ptr()
+        g.in_proj_w[l], g.in_proj_b[l] = gp(layer.self_attn.in_proj_weight), gp(layer.self_attn.in_proj_bias)
+        g.out_proj_w[l], g.out_proj_b[l] = gp(layer.self_attn.out_proj.weight), gp(layer.self_attn.out_proj.bias)
+        g.lin1_w[l], g.lin1_b[l] = gp(layer.linear1.weight), gp(layer.linear1.bias)
+        g.lin2_w[l], g.lin2_b[l] = gp(layer.linear2.weight), gp(layer.linear2.bias)
+        g.norm1_w[l], g.norm1_b[l] = gp(layer.norm1.weight), gp(layer.norm1.bias)
+        g.norm2_w[l], g.norm2_b[l] = gp(layer.norm2.weight), gp(layer.norm2.bias)
     pr = head.acquisition_head.predictor
-    g.acq_w1, g.acq_b1 = pr[0].weight.grad.data_ptr(), pr[0].bias.grad.data_ptr()
-    g.acq_w2, g.acq_b2 = pr[2].weight.grad.data_ptr(), pr[2].bias.grad.data_ptr()
+    g.acq_w1, g.acq_b1, g.acq_w2, g.acq_b2 = gp(pr[0].weight), gp(pr[0].bias), gp(pr[2].weight), gp(pr[2].bias)
     for c, h in enumerate(head.target_head.heads):
-        g.gmm_w1[c], g.gmm_b1[c] = h[0].weight.grad.data_ptr(), h[0].bias.grad.data_ptr()
-        g.gmm_w2[c], g.gmm_b2[c] = h[2].weight.grad.data_ptr(), h[2].bias.grad.data_ptr()
+        g.gmm_w1[c], g.gmm_b1[c], g.gmm_w2[c], g.gmm_b2[c] = gp(h[0].weight), gp(h[0].bias), gp(h[2].weight), gp(h[2].bias)
     return g
 
 
@@ -124,3 +126,49 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
         if optimizer is not None:
             optimizer.step()
     return terms, ro
+
+
+def step_backward(model, batch, idx, g_logp, g_mean=None, g_std=None, g_weight=None):
+    """Gradients of one `Aline.forward(batch)` call (the reference's per-step API) wrt every parameter,
+    given the upstream gradients of design_out.log_prob [B] and posterior_out.mixture_* [B,n_t,C].
+    The step is expressed in the static-slot layout (T = 1) and handed to aline_rollout_backward_ex."""
+    from .model import _native
+    g = _native._get
+    m = model.model_struct()
+    cx, cy, qx = _lib.f32(g(batch, "context_x")), _lib.f32(g(batch, "context_y")), _lib.f32(g(batch, "query_x"))
+    dev = cx.device
+    B, n_c, n_q = cx.shape[0], cx.shape[1], qx.shape[1]
+    P = n_c + n_q
+    px = torch.cat([cx, qx], dim=1).contiguous()
+    py = torch.cat([cy, torch.zeros(B, n_q, cy.shape[-1], device=dev)], dim=1).contiguous()
+    role = torch.zeros(B, P, dtype=torch.int32, device=dev)
+    role[:, :n_c] = torch.arange(1, n_c + 1, dtype=torch.int32, device=dev)
+    ta = g(batch, "target_all")
+    n_t = ta.shape[1]
+    target_all = _lib.f32(ta.reshape(B, n_t))
+    n_td = n_t - m.n_theta
+    tx = g(batch, "target_x")
+    tx = _lib.f32(tx) if (tx is not None and n_td > 0) else None
+    tm = g(batch, "target_mask")
+    tmask = None if tm is None else tm.to(dev, torch.uint8).contiguous()
+    slot = (n_c + idx.reshape(B).to(torch.int32)).contiguous()
+    r = _lib.AlineRollout()
+    r.B, r.P, r.n_ctx0, r.n_target_data, r.T = B, P, n_c, n_td, 1
+    r.point_x, r.point_y, r.role = px.data_ptr(), py.data_ptr(), role.data_ptr()
+    r.target_x, r.target_all, r.target_mask = _lib.ptr(tx), target_all.data_ptr(), _lib.ptr(tmask)
+    r.slot = slot.data_ptr()
+    params = list(model.parameters())
+    into = {id(p): torch.zeros_like(p) for p in params}
+    grads = _grad_struct(model, into)
+    glp = _lib.f32(g_logp.reshape(B, 1)) if g_logp is not None else torch.zeros(B, 1, device=dev)
+    gm, gs, gw = (None if t is None else _lib.f32(t.reshape(1, B, n_t, -1)) for t in (g_mean, g_std, g_weight))
+    if gm is None and gs is None and gw is None:
+        gm = torch.zeros(1, B, n_t, m.C, device=dev)
+    nbytes = _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), 1)
+    if nbytes == 0:
+        raise RuntimeError("aline_amd: unsupported configuration for backward")
+    ws = _bwd_ws.get(nbytes, dev)
+    _lib.check(_lib.lib.aline_rollout_backward_ex(C.byref(m), C.byref(r), glp.data_ptr(), None, _lib.ptr(gm),
+                                                  _lib.ptr(gs), _lib.ptr(gw), C.byref(grads), 1, ws.data_ptr(),
+                                                  ws.numel(), _lib.stream_ptr(dev)), "rollout_backward_ex")
+    return [into[id(p)] for p in params]

@@ -11,6 +11,10 @@ from ..loss.eig import EIGStepLoss
 def compute_ll(value, means, stds, weights):
     """GMM log-likelihood logsumexp_c(Normal(mu_c, sd_c).log_prob(v) + log w_c)  (eval.py:200-207).
     value [B, n_t, 1] (or [B, n_t]) against [B, n_t, C] -> [B, n_t]."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (means, stds, weights) if torch.is_tensor(t)):
+        raise NotImplementedError(
+            "aline_amd.utils.compute_ll is the forward-only HIP kernel; for autograd use the reference's own "
+            "torch expression (utils/eval.py:200-207) on the outputs of Aline.forward, or aline_amd.train")
     C_ = means.shape[-1]
     lead = means.shape[:-1]
     v = _lib.f32(value).expand(*lead, 1) if value.dim() == means.dim() else _lib.f32(value)

@@ -216,6 +216,14 @@ size_t aline_rollout_backward_workspace_bytes(const aline_model *m, const aline_
 int aline_rollout_backward(const aline_model *m, const aline_rollout *r, const float *g_logp,
                            const float *g_ll, const aline_grads *grads, int t_chunk, void *ws,
                            size_t ws_bytes, void *stream);
+/* Same, with (optional) upstream gradients of the GMM parameters themselves, [T,B,n_t,C] each:
+ * dLoss/d posterior_out.mixture_{means,stds,weights} as autograd delivers them when the caller computes
+ * the log-likelihood with its own differentiable code (utils/eval.py:200-207).  g_ll may then be NULL.
+ * This is what `loss.backward()` of the reference's own training loop needs from Aline.forward. */
+int aline_rollout_backward_ex(const aline_model *m, const aline_rollout *r, const float *g_logp,
+                              const float *g_ll, const float *g_post_mean, const float *g_post_std,
+                              const float *g_post_weight, const aline_grads *grads, int t_chunk, void *ws,
+                              size_t ws_bytes, void *stream);
 
 /* --- diagnostics ----------------------------------------------------------------------------- */
 /* Byte offset, inside a rollout workspace, of the per-phase cycle stamps the fused rollout kernel

@@ -45,3 +45,48 @@ def test_backward_chunking_is_consistent(golden):
         train_step(model, to_dev(fx.batch()), T, forced_idx=forced, clip_grads=False, t_chunk=tc)
         grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu())
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[0].abs().max()) + 1e-7
+
+
+def test_reference_style_training_loop_with_autograd(golden):
+    """The reference's own loop body (train_aline.py:80-132) written against the drop-in modules:
+    model.forward(batch) per step, Task.update_batch, a *torch* compute_ll (utils/eval.py:200-207 is plain
+    differentiable torch code), loss.backward().  Gradients must equal the reference's."""
+    from aline_amd.tasks import Task
+    from aline_amd.utils import select_targets_by_mask
+    fx = golden("cfg2_location_d32")
+    dims, T = fx.meta["dims"], fx.meta["T"]
+    model, _ = native_model(dims, fx.meta["wseed"])
+    model.train()
+    task = Task(dim_x=dims["dim_x"], dim_y=1)
+    batch = to_dev(fx.batch())
+    forced = fx.forced_idx("train").cuda()
+
+    def compute_ll(value, means, stds, weights):          # reference utils/eval.py:200-207
+        comp = torch.distributions.Normal(means, stds, validate_args=False)
+        return torch.logsumexp(comp.log_prob(value) + torch.log(weights), dim=-1)
+
+    log_probs, nlls, nlls_q = [], [], []
+    for t in range(T):
+        pred = model.forward(batch, forced_idx=forced[:, t])
+        d, p = pred.design_out, pred.posterior_out
+        batch = task.update_batch(batch, d.idx)
+        log_probs.append(d.log_prob)
+        ll = compute_ll(batch.target_all, p.mixture_means, p.mixture_stds, p.mixture_weights)
+        masked = select_targets_by_mask(ll, batch.target_mask)
+        nlls_q.append(-masked.mean(dim=-1))
+        nlls.append(-ll.mean(dim=-1))
+    log_probs = torch.stack(log_probs, 1)
+    R = torch.stack([torch.clamp(nlls_q[t - 1] - nlls_q[t], min=0.0).detach() for t in range(1, T)], 1)
+    R = (R - R.mean(dim=0, keepdim=True)) / (R.std(dim=0, keepdim=True) + 1e-9)
+    design_loss = -torch.mean(log_probs[:, :-1] * R)
+    predict_loss = torch.mean(torch.stack(nlls))
+    (design_loss + predict_loss).backward()
+    torch.cuda.synchronize()
+    assert abs(float(predict_loss) - float(fx.np("train.predict_loss"))) < 1e-4
+    worst = ("", 0.0)
+    for k, prm in model.named_parameters():
+        ref = fx.t("train.grad." + k)
+        err = float((prm.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-4)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 1e-3, worst
