@@ -285,16 +285,24 @@ __device__ __forceinline__ void layer_tiles(f32x4 (&x)[NT][2], const float *Wl, 
       for (int t = 0; t < NT; ++t) MFMA4(q[t][1], w1.hi[j], x[t][1][j]);
     }
   }
-  // ---- S^T = Kblk q for the 4 heads (only the head's 16-channel sub-plane is non-zero) ----------------
+  // ---- S^T = Kblk q for the 4 heads (only the head's 16-channel sub-plane is non-zero).  The key mask
+  // is the accumulator's initial value (0 / -inf per key row), so masking costs no instruction per head.
   f32x4 s[NT][H][2];
   {
     f32x4 kf[H][2];
+    f32x4 mb[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mb[t][kt][r] = (16 * kt + 4 * g + r) < nv[t] ? 0.f : -INFINITY;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       kf[h][0] = ld4(Kb + (h * 2 + 0) * 256 + lane * 4);
       kf[h][1] = two_kt ? ld4(Kb + (h * 2 + 1) * 256 + lane * 4) : zero4();
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { s[t][h][0] = zero4(); s[t][h][1] = zero4(); }
+      for (int t = 0; t < NT; ++t) { s[t][h][0] = mb[t][0]; s[t][h][1] = mb[t][1]; }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -311,34 +319,23 @@ __device__ __forceinline__ void layer_tiles(f32x4 (&x)[NT][2], const float *Wl, 
           for (int t = 0; t < NT; ++t) MFMA4(s[t][h][1], kf[h][1][j], q[t][h >> 1][j]);
     }
   }
-  // ---- masked softmax over the key axis (registers x lane groups); p stays unnormalised ---------------
+  // ---- softmax over the key axis (registers x lane groups); p stays unnormalised.  While at most 16 keys
+  // exist the second key tile is all -inf and is skipped entirely ------------------------------------------
   float inv[NT][H];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    bool ok[2][4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ok[kt][r] = (16 * kt + 4 * g + r) < nv[t];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[t][h][kt][r] = ok[kt][r] ? s[t][h][kt][r] : -INFINITY;
-          mx = fmaxf(mx, s[t][h][kt][r]);
-        }
+      float mx = fmaxf(fmaxf(s[t][h][0][0], s[t][h][0][1]), fmaxf(s[t][h][0][2], s[t][h][0][3]));
+      if (two_kt) mx = fmaxf(mx, fmaxf(fmaxf(s[t][h][1][0], s[t][h][1][1]), fmaxf(s[t][h][1][2], s[t][h][1][3])));
       mx = group_max(mx);
       float sum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int r = 0; r < 4; ++r) { s[t][h][0][r] = __builtin_amdgcn_exp2f(s[t][h][0][r] - mx); sum += s[t][h][0][r]; }
+      if (two_kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[t][h][kt][r] = __builtin_amdgcn_exp2f(s[t][h][kt][r] - mx);
-          sum += s[t][h][kt][r];
-        }
+        for (int r = 0; r < 4; ++r) { s[t][h][1][r] = __builtin_amdgcn_exp2f(s[t][h][1][r] - mx); sum += s[t][h][1][r]; }
+      }
       inv[t][h] = __builtin_amdgcn_rcpf(group_sum(sum));
     }
   }
