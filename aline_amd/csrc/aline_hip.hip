@@ -7,6 +7,7 @@
 #include "eig.h"
 #include "fused_rollout.h"
 #include "fused_side.h"
+#include "wide.h"
 #include "backward.h"
 
 #include <algorithm>
@@ -31,7 +32,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -66,6 +67,12 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
                  (size_t)(ALINE_MAX_COMPONENTS + 2) * fused::SIDE_FRAGS);
   p.Stamps = take(512);   // diagnostic stamps of the fused kernel (8 x 16 x u64)
   p.Ztg = take((size_t)T * B * n_t * d);   // fused rollout: target-row encodings of all steps
+  if (T > 0 && m.d == wide::D && m.precision == ALINE_PREC_BF16) {   // wide path (bf16 rows = half a float)
+    p.wX = take(M * d / 2 + 64); p.wX1 = take(M * d / 2 + 64); p.wQKV = take(M * 3 * d / 2 + 64);
+    p.wA = take(M * d / 2 + 64); p.wLog = take(M);
+    p.wImg = take((size_t)m.L * wide::layer_words(m.F) + wide::head_words(m.F));
+    p.wZt = take((size_t)B * n_t * d);
+  }
   p.total = off;
   return p;
 }
@@ -389,6 +396,21 @@ __global__ void set_scalar_kernel(float *p, float v) { p[0] = v; }
 
 }  // namespace
 
+template <int MODE>
+static int launch_wide_block(const Ctx &c, wide::BlockArgs a) {
+  const int F = c.m->F;
+  const int nprm = MODE == wide::WB_QKV ? 3 * wide::D : MODE == wide::WB_OUT ? 3 * wide::D
+                   : MODE == wide::WB_FFN ? F + 3 * wide::D : 2 * F + 4;
+  const size_t smem = (size_t)(2 * wide::CHUNK_W + nprm) * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_block_kernel<MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const unsigned grid = (unsigned)((a.M + wide::WG_TOK - 1) / wide::WG_TOK);
+  hipLaunchKernelGGL(wide::wide_block_kernel<MODE>, dim3(grid), dim3(wide::NTHREADS), smem, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+
 extern "C" {
 
 int aline_abi_version(void) { return ALINE_ABI_VERSION; }
@@ -610,10 +632,112 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   return ALINE_OK;
 }
 
+// The wide path (wide.h) covers d = 256 / head_dim 32 in bf16: streamed-weight fused blocks.
+static bool wide_eligible(const aline_model &m, const aline_rollout &r) {
+  if (getenv("ALINE_DISABLE_WIDE")) return false;
+  if (m.precision != ALINE_PREC_BF16 || m.d != wide::D || m.H != wide::H || m.F % 64 || m.time_token) return false;
+  if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > wide::WNK) return false;
+  return true;
+}
+
+static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes, void *stream) {
+  Ctx c;
+  TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
+  TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
+  const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, M = r->B * N, F = m->F;
+  hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B, r->P, r->n_ctx0);
+  CHECK_LAUNCH();
+  Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
+  TRY(do_embed_points(c, xs, r->point_y, r->P));
+  // weights -> streamed bf16 fragment images (once per rollout)
+  wide::PackArgs pa{};
+  pa.L = m->L; pa.F = F;
+  for (int l = 0; l < m->L; ++l) {
+    pa.in_proj_w[l] = m->in_proj_w[l]; pa.in_proj_b[l] = m->in_proj_b[l];
+    pa.out_proj_w[l] = m->out_proj_w[l]; pa.out_proj_b[l] = m->out_proj_b[l];
+    pa.lin1_w[l] = m->lin1_w[l]; pa.lin1_b[l] = m->lin1_b[l];
+    pa.lin2_w[l] = m->lin2_w[l]; pa.lin2_b[l] = m->lin2_b[l];
+    pa.n1w[l] = m->norm1_w[l]; pa.n1b[l] = m->norm1_b[l];
+    pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
+  }
+  pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
+  unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.wImg));
+  pa.out = img;
+  hipLaunchKernelGGL(wide::pack_kernel, dim3(1024), dim3(256), 0, c.st, pa);
+  CHECK_LAUNCH();
+  unsigned short *X = reinterpret_cast<unsigned short *>(c.at(c.pl.wX));
+  unsigned short *X1 = reinterpret_cast<unsigned short *>(c.at(c.pl.wX1));
+  unsigned short *QKV = reinterpret_cast<unsigned short *>(c.at(c.pl.wQKV));
+  unsigned short *A = reinterpret_cast<unsigned short *>(c.at(c.pl.wA));
+  float *logits = c.at(c.pl.wLog), *Zt = c.at(c.pl.wZt);
+  const long lw = wide::layer_words(F);
+  const long nfw = (long)wide::layer_chunks(F) * wide::CHUNK_W;
+  for (int t = 0; t < r->T; ++t) {
+    c.g.n_ctx = r->n_ctx0 + t;
+    hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)M * wide::D / 2), dim3(256), 0, c.st, c.g,
+                       c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X);
+    CHECK_LAUNCH();
+    for (int l = 0; l < m->L; ++l) {
+      const unsigned *li = img + (long)l * lw;
+      const float *prm = reinterpret_cast<const float *>(li + nfw);
+      wide::BlockArgs b{};
+      b.M = M; b.F = F; b.prm = prm;
+      b.X = X; b.Y = QKV; b.wimg = li;
+      TRY(launch_wide_block<wide::WB_QKV>(c, b));
+      wide::AttnArgs aa{c.g, QKV, A};
+      hipLaunchKernelGGL(wide::wide_attention_kernel, dim3(r->B), dim3(wide::NTHREADS), 0, c.st, aa);
+      CHECK_LAUNCH();
+      b.X = A; b.Xres = X; b.Y = X1; b.wimg = li + 12 * wide::CHUNK_W;
+      TRY(launch_wide_block<wide::WB_OUT>(c, b));
+      b.X = X1; b.Xres = nullptr; b.Y = X; b.wimg = li + 16 * wide::CHUNK_W;
+      const bool timed = (t == r->T - 1 && l == m->L - 1);     // bench.py times this launch of the dominant kernel
+      if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
+      TRY(launch_wide_block<wide::WB_FFN>(c, b));
+      if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
+    }
+    {
+      const unsigned *hi = img + (long)m->L * lw;
+      wide::BlockArgs b{};
+      b.M = M; b.F = F; b.X = X; b.logits = logits; b.wimg = hi;
+      b.prm = reinterpret_cast<const float *>(hi + (long)wide::head_chunks(F) * wide::CHUNK_W);
+      TRY(launch_wide_block<wide::WB_ACQ>(c, b));
+    }
+    SelectArgs sel{};
+    sel.g = c.g; sel.F = F; sel.logits = logits; sel.logit_stride = N;
+    sel.mode = r->select_mode;
+    sel.uniform = r->uniform ? r->uniform + (size_t)t * r->B : nullptr;
+    sel.forced = r->forced_idx ? r->forced_idx + t : nullptr; sel.forced_stride = r->T;
+    sel.idx = r->idx ? r->idx + t : nullptr; sel.idx_stride = r->T;
+    sel.slot = r->slot ? r->slot + t : nullptr; sel.slot_stride = r->T;
+    sel.log_prob = r->log_prob ? r->log_prob + t : nullptr; sel.lp_stride = r->T;
+    const int zw = r->P - r->n_ctx0;
+    sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
+    sel.role_out = r->role;
+    if (r->P > 1024) return ALINE_EUNSUPPORTED;
+    // posterior of this step first (the selection kernel updates the roles afterwards; order is free)
+    if (r->post_mean || r->post_std || r->post_weight || r->target_ll) {
+      const long rows = (long)r->B * n_t;
+      hipLaunchKernelGGL(wide::bf16_rows_to_f32_kernel, grid1d((size_t)rows * wide::D), dim3(256), 0, c.st, X, n_t, N,
+                         r->P, rows, Zt);
+      CHECK_LAUNCH();
+      const size_t po = (size_t)t * r->B * n_t;
+      TRY(do_gmm_rows(c, Zt, (int)rows, r->post_mean ? r->post_mean + po * m->C : nullptr,
+                      r->post_std ? r->post_std + po * m->C : nullptr,
+                      r->post_weight ? r->post_weight + po * m->C : nullptr, r->target_all,
+                      r->target_ll ? r->target_ll + po : nullptr, 0, rows));
+    }
+    hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
+    CHECK_LAUNCH();
+  }
+  return ALINE_OK;
+}
+
 int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
                           void *stream) {
   if (m && r && validate_model(*m) == 0 && fused_eligible(*m, *r))
     return rollout_fused(m, r, ws, ws_bytes, stream);
+  if (m && r && validate_model(*m) == 0 && wide_eligible(*m, *r))
+    return rollout_wide(m, r, ws, ws_bytes, stream);
   TRY(aline_rollout_init(m, r, ws, ws_bytes, stream));
   for (int t = 0; t < r->T; ++t) TRY(aline_rollout_step(m, r, t, ws, ws_bytes, stream));
   return ALINE_OK;

@@ -179,6 +179,7 @@ struct SelectArgs {
   Geo g;
   int F;
   const float *hid, *w2, *b2;
+  const float *logits; int logit_stride;   // precomputed logits[b * logit_stride + p] (wide path), or null
   int mode;                      // ALINE_SELECT_*
   const float *uniform;          // [B]
   const int64_t *forced; int forced_stride;   // forced[b * stride]
@@ -200,7 +201,10 @@ __global__ __launch_bounds__(256) void acq_select_kernel(SelectArgs a) {
   __shared__ float s_val;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = a.g.P;
-  // logits: one wave per row, lanes over F
+  // logits: one wave per row, lanes over F (or precomputed by the wide path)
+  if (a.logits) {
+    for (int p = tid; p < P; p += 256) logit[p] = a.logits[(long)b * a.logit_stride + p];
+  } else
   for (int p = wave; p < P; p += 4) {
     const float *hp = a.hid + ((long)b * P + p) * a.F;
     float s = 0.f;

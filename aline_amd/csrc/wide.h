@@ -1,0 +1,504 @@
+// Wide path: d = 256 (head_dim 32), any F multiple of 64, bf16 MFMA with fp32 accumulate -- the
+// matrix-core-bound regime of the same step (north star: ">= 40 % of the bf16 MFMA roofline at d >= 256").
+//
+// Same operand scheme as fused_rollout.h, scaled up: a token tile is X^T [features x 16 tokens]; every
+// linear layer is Y^T = W X^T, so an accumulator tile is the B operand of the next product (k order
+// pi(ks,g,j) = 32 ks + 16 (j>>2) + 4 g + (j&3)) and weights are A fragments pre-permuted at pack time.
+// What changes at d = 256: a layer's weights (1.5 MB bf16) no longer fit in LDS, so they are STREAMED:
+// 32 KB chunks of 32 fragments go global -> registers -> LDS (double buffered, one barrier per chunk) and
+// are consumed by all 8 waves of the workgroup, each of which keeps 32 tokens (2 column tiles) on chip:
+// its input as 64 VGPRs of bf16 B fragments, its 256-feature output as 128 fp32 accumulator VGPRs.
+// Activations travel between kernels as bf16 rows [M, 256]; LayerNorm, softmax and biases are fp32.
+//
+//   wide_block_kernel<WB_QKV>   Q,K,V = in_proj X               (3 passes over the resident input)
+//   wide_attention_kernel       masked set-attention, one workgroup per episode, one wave per head
+//   wide_block_kernel<WB_OUT>   X1 = LN1(X + Wo A + bo)
+//   wide_block_kernel<WB_FFN>   X  = LN2(X1 + W2 relu(W1 X1 + b1) + b2): the hidden layer never leaves
+//                               the CU (32-unit chunks: 16 fragments of W1, 16 of W2)
+//   wide_block_kernel<WB_ACQ>   acquisition logits = w2 . relu(W1a z + b1a) + b2a
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace wide {
+
+constexpr int D = 256, HD = 32, H = 8, NMT = D / 16, NKS = D / 32;
+constexpr int CHUNK_FRAGS = 32, FRAG_W = 256, CHUNK_W = CHUNK_FRAGS * FRAG_W;   // 32-bit words
+constexpr int WTOK = 32, WG_TOK = 256, NTHREADS = 512;
+enum { WB_QKV = 0, WB_OUT = 1, WB_FFN = 2, WB_ACQ = 3 };
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+#define WMFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+
+// layer image (32-bit words): [QKV 12 chunks][OUT 4 chunks][FFN F/32 chunks], then fp32 params
+__host__ __device__ inline int layer_chunks(int F) { return 12 + 4 + F / 32; }
+__host__ __device__ inline int layer_params(int F) { return 3 * D + D + F + D + 4 * D; }   // bqkv, bo, b1, b2, ln1w, ln1b, ln2w, ln2b
+__host__ __device__ inline long layer_words(int F) { return (long)layer_chunks(F) * CHUNK_W + layer_params(F); }
+__host__ __device__ inline int head_chunks(int F) { return F / 64; }
+__host__ __device__ inline long head_words(int F) { return (long)head_chunks(F) * CHUNK_W + 2 * F + 4; }   // b1a, w2a, b2a
+
+struct PackArgs {
+  int L, F;
+  const float *in_proj_w[8], *in_proj_b[8], *out_proj_w[8], *out_proj_b[8], *lin1_w[8], *lin1_b[8], *lin2_w[8],
+      *lin2_b[8], *n1w[8], *n1b[8], *n2w[8], *n2b[8];
+  const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
+  unsigned *out;
+};
+
+// word w (0..3) of lane `lane` of the fragment (rows row0.., k-step ks) of a [*, K] row-major weight
+__device__ __forceinline__ unsigned frag_word(const float *W, int K, int row0, int ks, int lane, int w, float scale) {
+  const int g = lane >> 4, j0 = 2 * w;
+  const int k0 = 32 * ks + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
+  const float *p = W + (long)(row0 + (lane & 15)) * K + k0;
+  return pack_bf16(p[0] * scale, p[1] * scale);
+}
+
+__global__ void pack_kernel(PackArgs a) {
+  const long lw = layer_words(a.F), total = a.L * lw + head_words(a.F);
+  const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;   // softmax runs in exp2
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    unsigned v = 0;
+    if (i < a.L * lw) {
+      const int l = i / lw;
+      const long o = i % lw;
+      const long nfw = (long)layer_chunks(a.F) * CHUNK_W;
+      if (o < nfw) {
+        const int chunk = o / CHUNK_W, fid = (o % CHUNK_W) / FRAG_W, e = o % FRAG_W, lane = e >> 2, w = e & 3;
+        if (chunk < 12) {               // QKV pass p, chunk cc: fragments (ks_local, mt)
+          const int p = chunk / 4, cc = chunk % 4, ks = 2 * cc + fid / 16, mt = fid % 16;
+          v = frag_word(a.in_proj_w[l], D, 256 * p + 16 * mt, ks, lane, w, p == 0 ? qscale : 1.f);
+        } else if (chunk < 16) {
+          const int cc = chunk - 12, ks = 2 * cc + fid / 16, mt = fid % 16;
+          v = frag_word(a.out_proj_w[l], D, 16 * mt, ks, lane, w, 1.f);
+        } else {
+          const int c = chunk - 16;
+          if (fid < 16) v = frag_word(a.lin1_w[l], D, 32 * c + 16 * (fid & 1), fid >> 1, lane, w, 1.f);   // (ks, mt')
+          else v = frag_word(a.lin2_w[l], a.F, 16 * (fid - 16), c, lane, w, 1.f);                           // (mt, ks = c)
+        }
+      } else {
+        const int p = o - nfw;
+        float f;
+        if (p < 3 * D) f = a.in_proj_b[l][p] * (p < D ? qscale : 1.f);
+        else if (p < 4 * D) f = a.out_proj_b[l][p - 3 * D];
+        else if (p < 4 * D + a.F) f = a.lin1_b[l][p - 4 * D];
+        else {
+          const int q = p - 4 * D - a.F;
+          f = q < D ? a.lin2_b[l][q] : q < 2 * D ? a.n1w[l][q - D] : q < 3 * D ? a.n1b[l][q - 2 * D]
+            : q < 4 * D ? a.n2w[l][q - 3 * D] : a.n2b[l][q - 4 * D];
+        }
+        v = __float_as_uint(f);
+      }
+    } else {
+      const long o = i - a.L * lw;
+      const long nfw = (long)head_chunks(a.F) * CHUNK_W;
+      if (o < nfw) {                    // acquisition W1a [F, 256]: chunk c = hidden groups 2c, 2c+1; (grp, ks, mt')
+        const int chunk = o / CHUNK_W, fid = (o % CHUNK_W) / FRAG_W, e = o % FRAG_W, lane = e >> 2, w = e & 3;
+        const int grp = 2 * chunk + fid / 16, f16 = fid % 16;
+        v = frag_word(a.acq_w1, D, 32 * grp + 16 * (f16 & 1), f16 >> 1, lane, w, 1.f);
+      } else {
+        const int p = o - nfw;
+        const float f = p < a.F ? a.acq_b1[p] : p < 2 * a.F ? a.acq_w2[p - a.F] : p == 2 * a.F ? a.acq_b2[0] : 0.f;
+        v = __float_as_uint(f);
+      }
+    }
+    a.out[i] = v;
+  }
+}
+
+// X0 (bf16) from the cached fp32 point embeddings: Ex (+ Ey on context rows), theta tokens
+__global__ void assemble_bf16_kernel(Geo g, const float *__restrict__ Ex, const float *__restrict__ Ey,
+                                     int ey_rows, const float *__restrict__ theta_tokens,
+                                     unsigned short *__restrict__ X) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one thread = 2 features
+  long total = (long)g.B * g.N * (D / 2);
+  if (i >= total) return;
+  const int c = (i % (D / 2)) * 2;
+  const long r = i / (D / 2);
+  const int b = r / g.N, row = r % g.N;
+  float v0, v1;
+  if (row < g.P + g.n_td) {
+    const float *e = Ex + ((long)b * (g.P + g.n_td) + row) * D + c;
+    v0 = e[0]; v1 = e[1];
+    if (row < g.P && is_ctx(g, b, row)) { const float *y = Ey + ((long)b * ey_rows + row) * D + c; v0 += y[0]; v1 += y[1]; }
+  } else {
+    const float *t = theta_tokens + (row - g.P - g.n_td) * D + c;
+    v0 = t[0]; v1 = t[1];
+  }
+  reinterpret_cast<unsigned *>(X)[i] = pack_bf16(v0, v1);
+}
+
+__global__ void bf16_rows_to_f32_kernel(const unsigned short *__restrict__ X, int rows_per_ep, int ep_stride,
+                                        int off, long rows, float *__restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * D) return;
+  const long r = i / D;
+  const long src = (r / rows_per_ep) * ep_stride + off + (r % rows_per_ep);
+  out[i] = __uint_as_float(((unsigned)X[src * D + (i % D)]) << 16);
+}
+
+struct BlockArgs {
+  const unsigned short *X;       // [M, 256] bf16 input of the matmul chain
+  const unsigned short *Xres;    // [M, 256] residual (WB_OUT), else unused
+  unsigned short *Y;             // bf16 output rows ([M, 768] for WB_QKV, [M, 256] otherwise)
+  float *logits;                 // [M] (WB_ACQ)
+  const unsigned *wimg;          // first chunk of this block's weights
+  const float *prm;              // this layer's (or the head's) fp32 parameter block
+  int M, F;
+};
+
+// B fragments of 32 tokens from bf16 rows: lane (tok, g) reads features 32 ks + 4 g .. +3 and + 16
+__device__ __forceinline__ void load_xfrags(const unsigned short *X, long row, int g, bf16x8 (&xb)[NKS]) {
+  const unsigned short *xr = X + row * D;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const u32x2 lo = *reinterpret_cast<const u32x2 *>(xr + 32 * ks + 4 * g);
+    const u32x2 hi = *reinterpret_cast<const u32x2 *>(xr + 32 * ks + 16 + 4 * g);
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    xb[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x4 &lo, const f32x4 &hi) {
+  const u32x4 v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float group_sum4(float v) {   // over the 4 lane groups holding one token
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void wide_block_kernel(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds[];      // [2][CHUNK_W] + params (floats)
+  unsigned *buf0 = lds, *buf1 = lds + CHUNK_W;
+  float *ps = reinterpret_cast<float *>(lds + 2 * CHUNK_W);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  const long base = (long)blockIdx.x * WG_TOK + wave * WTOK;
+  long row[2];
+  row[0] = min(base + tok, (long)a.M - 1);
+  row[1] = min(base + 16 + tok, (long)a.M - 1);
+  const bool ok[2] = {base + tok < a.M, base + 16 + tok < a.M};
+
+  // parameters of this block into LDS
+  const int nprm = MODE == WB_QKV ? 3 * D : MODE == WB_OUT ? 3 * D : MODE == WB_FFN ? a.F + 3 * D : 2 * a.F + 4;
+  for (int i = tid; i < nprm; i += NTHREADS) {
+    float v;
+    if (MODE == WB_QKV) v = a.prm[i];                                                  // bq | bk | bv
+    else if (MODE == WB_OUT) v = i < D ? a.prm[3 * D + i] : a.prm[4 * D + a.F + D + (i - D)];       // bo | ln1w | ln1b
+    else if (MODE == WB_FFN) v = i < a.F ? a.prm[4 * D + i] : i < a.F + D ? a.prm[4 * D + a.F + (i - a.F)]
+                                 : a.prm[4 * D + a.F + 3 * D + (i - a.F - D)];              // b1 | b2 | ln2w | ln2b
+    else v = a.prm[i];                                                                  // b1a | w2a | b2a
+    ps[i] = v;
+  }
+
+  bf16x8 xb[2][NKS];
+  load_xfrags(a.X, row[0], g, xb[0]);
+  load_xfrags(a.X, row[1], g, xb[1]);
+
+  const int nchunk = MODE == WB_QKV ? 12 : MODE == WB_OUT ? 4 : MODE == WB_FFN ? a.F / 32 : a.F / 64;
+  const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wimg);
+  u32x4 st[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st[i] = wsrc[tid + i * NTHREADS];
+
+  f32x4 y[NMT][2];
+  float plog[2] = {0.f, 0.f};
+  if (MODE != WB_ACQ) {
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) { y[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; y[mt][1] = y[mt][0]; }
+  }
+
+  for (int c = 0; c < nchunk; ++c) {
+    unsigned *buf = (c & 1) ? buf1 : buf0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<u32x4 *>(buf)[tid + i * NTHREADS] = st[i];
+    __syncthreads();
+    if (c + 1 < nchunk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st[i] = wsrc[(long)(c + 1) * (CHUNK_W / 4) + tid + i * NTHREADS];
+    }
+    const bf16x8 *fr = reinterpret_cast<const bf16x8 *>(buf) + lane;        // fragment f at fr[f * 64]
+
+    if (MODE == WB_QKV || MODE == WB_OUT) {
+      // chunk = k-steps 2cc, 2cc+1 of the 16 output tiles
+      const int cc = MODE == WB_QKV ? c & 3 : c;
+#pragma unroll
+      for (int kl = 0; kl < 2; ++kl)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          const bf16x8 A = fr[(kl * 16 + mt) * 64];
+          WMFMA(y[mt][0], A, xb[0][2 * cc + kl]);
+          WMFMA(y[mt][1], A, xb[1][2 * cc + kl]);
+        }
+      if (MODE == WB_QKV && cc == 3) {
+        // end of pass p: bias, store bf16 at column block p, reset the accumulators
+        const int p = c >> 2;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(ps + p * D + 16 * mt + 4 * g);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const f32x4 v = y[mt][ct] + bv;
+            if (ok[ct]) {
+              const u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+              *reinterpret_cast<u32x2 *>(a.Y + row[ct] * (3 * D) + p * D + 16 * mt + 4 * g) = o;
+            }
+            y[mt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    } else if (MODE == WB_FFN) {
+      f32x4 h[2][2];
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(ps + 32 * c + 4 * g);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(ps + 32 * c + 16 + 4 * g);
+        h[0][0] = b0; h[0][1] = b0; h[1][0] = b1; h[1][1] = b1;
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8 A0 = fr[(2 * ks) * 64], A1 = fr[(2 * ks + 1) * 64];
+        WMFMA(h[0][0], A0, xb[0][ks]); WMFMA(h[0][1], A0, xb[1][ks]);
+        WMFMA(h[1][0], A1, xb[0][ks]); WMFMA(h[1][1], A1, xb[1][ks]);
+      }
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[m2][ct][r] = fmaxf(h[m2][ct][r], 0.f);
+      const bf16x8 hb0 = acc_to_frag(h[0][0], h[1][0]), hb1 = acc_to_frag(h[0][1], h[1][1]);
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        const bf16x8 A = fr[(16 + mt) * 64];
+        WMFMA(y[mt][0], A, hb0);
+        WMFMA(y[mt][1], A, hb1);
+      }
+    } else {   // WB_ACQ: two groups of 32 hidden units per chunk
+#pragma unroll
+      for (int grp = 0; grp < 2; ++grp) {
+        const int hbase = 64 * c + 32 * grp;
+        f32x4 h[2][2];
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(ps + hbase + 4 * g);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(ps + hbase + 16 + 4 * g);
+        h[0][0] = b0; h[0][1] = b0; h[1][0] = b1; h[1][1] = b1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8 A0 = fr[(grp * 16 + 2 * ks) * 64], A1 = fr[(grp * 16 + 2 * ks + 1) * 64];
+          WMFMA(h[0][0], A0, xb[0][ks]); WMFMA(h[0][1], A0, xb[1][ks]);
+          WMFMA(h[1][0], A1, xb[0][ks]); WMFMA(h[1][1], A1, xb[1][ks]);
+        }
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(ps + a.F + hbase + 4 * g);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(ps + a.F + hbase + 16 + 4 * g);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            plog[ct] = fmaf(fmaxf(h[0][ct][r], 0.f), w0[r], plog[ct]);
+            plog[ct] = fmaf(fmaxf(h[1][ct][r], 0.f), w1[r], plog[ct]);
+          }
+      }
+    }
+  }
+
+  if (MODE == WB_ACQ) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float v = group_sum4(plog[ct]) + ps[2 * a.F];
+      if (g == 0 && ok[ct]) a.logits[row[ct]] = v;
+    }
+    return;
+  }
+  if (MODE == WB_QKV) return;
+
+  // ---- residual + LayerNorm over the 256 features of each token (fp32), bf16 store ------------------------
+  const float *bo = ps + (MODE == WB_OUT ? 0 : a.F);
+  const float *lw = bo + D, *lb = lw + D;
+  if (MODE == WB_OUT) {     // the residual is the layer input, not this block's A operand
+    load_xfrags(a.Xres, row[0], g, xb[0]);
+    load_xfrags(a.Xres, row[1], g, xb[1]);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bo + 16 * mt + 4 * g);
+      const u32x4 xr = __builtin_bit_cast(u32x4, xb[ct][mt >> 1]);     // features 32 ks + 16 (mt&1) + 4 g + r
+      const unsigned w0 = xr[2 * (mt & 1)], w1 = xr[2 * (mt & 1) + 1];
+      y[mt][ct][0] += bv[0] + bf_lo(w0); y[mt][ct][1] += bv[1] + bf_hi(w0);
+      y[mt][ct][2] += bv[2] + bf_lo(w1); y[mt][ct][3] += bv[3] + bf_hi(w1);
+      s += (y[mt][ct][0] + y[mt][ct][1]) + (y[mt][ct][2] + y[mt][ct][3]);
+    }
+    const float mean = group_sum4(s) * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float t = y[mt][ct][r] - mean; ss = fmaf(t, t, ss); }
+    const float rstd = rsqrtf(group_sum4(ss) * (1.f / D) + 1e-5f);
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+      const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + 16 * mt + 4 * g);
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(lb + 16 * mt + 4 * g);
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (y[mt][ct][r] - mean) * rstd * wv[r] + bv[r];
+      if (ok[ct]) {
+        const u32x2 ov = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+        *reinterpret_cast<u32x2 *>(a.Y + row[ct] * D + 16 * mt + 4 * g) = ov;
+      }
+    }
+  }
+}
+
+// ---- masked set-attention on bf16 Q/K/V rows ([M, 768]) ---------------------------------------------------
+// One workgroup per episode, wave h = head h (head_dim 32 = one MFMA k-step: no zero padding).  The head's
+// K fragments (keys x 32 channels) and V^T fragments (32 channels x keys) live in registers for the whole
+// episode; V^T is built through an LDS transpose of the key rows.  Up to 64 keys.
+constexpr int WNK = 64;
+struct AttnArgs {
+  Geo g;
+  const unsigned short *QKV;     // [B*N, 768]
+  unsigned short *A;             // [B*N, 256]
+};
+
+__global__ __launch_bounds__(NTHREADS) void wide_attention_kernel(AttnArgs a) {
+  __shared__ unsigned short Vs[WNK][D + 8];      // V rows of the key tokens (all heads)
+  __shared__ int keyrow[WNK];
+  __shared__ int wave_cnt[8];
+  __shared__ int s_base, s_nck, s_nak;
+  const Geo &g = a.g;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gg = lane >> 4;
+  const int n_t = g.n_td + g.n_th;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < g.P; c0 += NTHREADS) {
+    const int row = c0 + tid;
+    const bool key = row < g.P && is_ctx(g, b, row);
+    const unsigned long long bal = __ballot(key);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+    if (key && k < WNK) keyrow[k] = row;
+    __syncthreads();
+    if (tid == 0) { int s = 0; for (int w = 0; w < 8; ++w) s += wave_cnt[w]; s_base += s; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int n = min(s_base, WNK);
+    s_nck = n;
+    for (int j = 0; j < n_t; ++j)
+      if ((!g.tmask || g.tmask[j]) && n < WNK) keyrow[n++] = g.P + j;
+    s_nak = n;
+  }
+  __syncthreads();
+  const int n_ck = s_nck, n_ak = s_nak;
+  const long ep = (long)b * g.N;
+  // V rows -> LDS (zero rows beyond n_ak)
+  for (int i = tid; i < WNK * (D / 4); i += NTHREADS) {
+    const int j = i / (D / 4), c4 = (i % (D / 4)) * 4;
+    u32x2 v = {0u, 0u};
+    if (j < n_ak) v = *reinterpret_cast<const u32x2 *>(a.QKV + (ep + keyrow[j]) * (3 * D) + 2 * D + c4);
+    *reinterpret_cast<u32x2 *>(&Vs[j][c4]) = v;
+  }
+  __syncthreads();
+  const int h = wave;
+  const int nkt = (n_ak + 15) >> 4;            // key tiles in use (<= 4)
+  // K fragments of this head: rows = keys 16 kt + tok, k = channel pi(0, g, j)
+  bf16x8 kf[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int j = 16 * kt + tok;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (j < n_ak) {
+      const unsigned short *kr = a.QKV + (ep + keyrow[j]) * (3 * D) + D + HD * h;
+      const u32x2 lo = *reinterpret_cast<const u32x2 *>(kr + 4 * gg);
+      const u32x2 hi = *reinterpret_cast<const u32x2 *>(kr + 16 + 4 * gg);
+      v = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    }
+    kf[kt] = __builtin_bit_cast(bf16x8, v);
+  }
+  // V^T fragments: rows = channel 16 mt + tok, k-step s covers keys 32 s + 16 (j>>2) + 4 g + (j&3)
+  bf16x8 vf[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = Vs[32 * s + 16 * (j >> 2) + 4 * gg + (j & 3)][HD * h + 16 * mt + tok];
+      const u32x4 v = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                       (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      vf[mt][s] = __builtin_bit_cast(bf16x8, v);
+    }
+  const int ntiles = (g.N + 15) >> 4;
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const int row = 16 * ti + tok;
+    const bool valid = row < g.N;
+    const int rr = valid ? row : g.N - 1;
+    const bool isq = rr < g.P && !is_ctx(g, b, rr);
+    const int nv = isq ? n_ak : n_ck;
+    // Q^T fragment of this head (already scaled by log2(e)/sqrt(hd))
+    const unsigned short *qr = a.QKV + (ep + rr) * (3 * D) + HD * h;
+    const u32x2 qlo = *reinterpret_cast<const u32x2 *>(qr + 4 * gg);
+    const u32x2 qhi = *reinterpret_cast<const u32x2 *>(qr + 16 + 4 * gg);
+    const bf16x8 qf = __builtin_bit_cast(bf16x8, (u32x4){qlo[0], qlo[1], qhi[0], qhi[1]});
+    f32x4 s[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[kt][r] = (16 * kt + 4 * gg + r) < nv ? 0.f : -INFINITY;
+      if (kt < nkt) {
+        WMFMA(s[kt], kf[kt], qf);
+        mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+      }
+    }
+    {
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+      r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kt][r] = kt < nkt ? __builtin_amdgcn_exp2f(s[kt][r] - mx) : 0.f;
+        sum += s[kt][r];
+      }
+    const float inv = __builtin_amdgcn_rcpf(group_sum4(sum));
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const bf16x8 p0 = acc_to_frag(s[0], s[1]);
+    WMFMA(o[0], vf[0][0], p0);
+    WMFMA(o[1], vf[1][0], p0);
+    if (nkt > 2) {
+      const bf16x8 p1 = acc_to_frag(s[2], s[3]);
+      WMFMA(o[0], vf[0][1], p1);
+      WMFMA(o[1], vf[1][1], p1);
+    }
+    if (valid) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const u32x2 ov = {pack_bf16(o[mt][0] * inv, o[mt][1] * inv), pack_bf16(o[mt][2] * inv, o[mt][3] * inv)};
+        *reinterpret_cast<u32x2 *>(a.A + (ep + row) * D + HD * h + 16 * mt + 4 * gg) = ov;
+      }
+    }
+  }
+}
+
+}  // namespace wide

@@ -250,16 +250,19 @@ def main():
     ev = HipEvents()
     ro.r.ev_kernel_start, ro.r.ev_kernel_stop = ev.a, ev.b
     kms = []
-    for _ in range(max(3, args.steps)):
+    has_kernel_events = ((args.d_model == 32 and args.d_ff == 128 and args.heads == 4 and args.precision == "f32")
+                         or (args.d_model == 256 and args.heads == 8 and args.precision == "bf16"))
+    for _ in range(max(3, args.steps) if has_kernel_events else 0):
         ro.refresh_uniform()
         ro.run()
         kms.append(ev.elapsed_ms())
     ro.r.ev_kernel_start, ro.r.ev_kernel_stop = None, None
-    kernel_ms = sum(kms) / len(kms)
+    kernel_ms = sum(kms) / len(kms) if kms else 0.0
     fl_ep = algorithmic_flops_per_episode(2, 1, args.d_model, args.d_ff, args.heads, args.layers, 10,
                                           1, args.n_query, 0, 2, 2, args.T, with_query_gmm=False)
     fused = (args.d_model == 32 and args.d_ff == 128 and args.heads == 4 and args.precision == "f32"
              and kernel_ms > 0.0)
+    wide = args.d_model == 256 and args.heads == 8 and args.precision == "bf16" and kernel_ms > 0.0
     extra = {}
     if fused:
         fl_k = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
@@ -286,6 +289,16 @@ def main():
             extra["traffic_source"] = "rocprofv3 PMC (profiles/r01_fused_f32_d32_pmc_traffic.json), not re-measured in this run"
         except Exception:
             traffic = None
+    elif wide:
+        # dominant kernel of the wide path: wide_block_kernel<WB_FFN> (one launch = the whole FFN of one layer
+        # for all B*N token rows; launched L*T times per rollout); events around its last launch.
+        m_rows = args.batch * (1 + args.n_query + 2)
+        per_launch = 4.0 * m_rows * args.d_model * args.d_ff
+        achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
+        kname, peak, traffic = "wide::wide_block_kernel<WB_FFN>", PEAK_BF16_DENSE_TFLOPS, None
+        extra = {"launches_per_rollout": args.layers * args.T,
+                 "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
+                 "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md); FFN = 2/3 of the layer FLOPs at d=256"}
     else:   # generic pipeline: many kernels per step; report the whole graph as a lower bound
         achieved_tflops = fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12
         kname, per_launch, kernel_ms = "whole rollout graph (generic pipeline, all kernels)", fl_ep * args.batch, dev_ms / args.steps
