@@ -8,6 +8,7 @@
 #include "fused_rollout.h"
 #include "fused_side.h"
 #include "wide.h"
+#include "wide_step.h"
 #include "backward.h"
 
 #include <algorithm>
@@ -68,8 +69,9 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   p.Stamps = take(512);   // diagnostic stamps of the fused kernel (8 x 16 x u64)
   p.Ztg = take((size_t)T * B * n_t * d);   // fused rollout: target-row encodings of all steps
   if (T > 0 && m.d == wide::D && m.precision == ALINE_PREC_BF16) {   // wide path (bf16 rows = half a float)
-    p.wX = take(M * d / 2 + 64); p.wX1 = take(M * d / 2 + 64); p.wQKV = take(M * 3 * d / 2 + 64);
-    p.wA = take(M * d / 2 + 64); p.wLog = take(M);
+    const size_t img = (size_t)wide::tile_rows(M) * d / 2;     // one bf16 tile image, in floats
+    p.wX = take(img); p.wX1 = take(img); p.wQKV = take(3 * img);
+    p.wA = take(img); p.wLog = take(M);
     p.wImg = take((size_t)m.L * wide::layer_words(m.F) + wide::head_words(m.F));
     p.wZt = take((size_t)B * n_t * d);
   }
@@ -405,7 +407,7 @@ static int launch_wide_block(const Ctx &c, wide::BlockArgs a) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_block_kernel<MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const unsigned grid = (unsigned)((a.M + wide::WG_TOK - 1) / wide::WG_TOK);
-  hipLaunchKernelGGL(wide::wide_block_kernel<MODE>, dim3(grid), dim3(wide::NTHREADS), smem, c.st, a);
+  hipLaunchKernelGGL(wide::wide_block_kernel<MODE>, dim3(grid), dim3(wide::BTHREADS), smem, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -665,26 +667,46 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
   pa.out = img;
   hipLaunchKernelGGL(wide::pack_kernel, dim3(1024), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
-  unsigned short *X = reinterpret_cast<unsigned short *>(c.at(c.pl.wX));
-  unsigned short *X1 = reinterpret_cast<unsigned short *>(c.at(c.pl.wX1));
-  unsigned short *QKV = reinterpret_cast<unsigned short *>(c.at(c.pl.wQKV));
-  unsigned short *A = reinterpret_cast<unsigned short *>(c.at(c.pl.wA));
+  using wide::u32x4;
+  u32x4 *X = reinterpret_cast<u32x4 *>(c.at(c.pl.wX)), *X1 = reinterpret_cast<u32x4 *>(c.at(c.pl.wX1));
+  u32x4 *QKV = reinterpret_cast<u32x4 *>(c.at(c.pl.wQKV)), *A = reinterpret_cast<u32x4 *>(c.at(c.pl.wA));
+  const long ipc = wide::tile_rows(M) * (wide::D / 8);          // pieces per image
   float *logits = c.at(c.pl.wLog), *Zt = c.at(c.pl.wZt);
   const long lw = wide::layer_words(F);
   const long nfw = (long)wide::layer_chunks(F) * wide::CHUNK_W;
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
-    hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)M * wide::D / 2), dim3(256), 0, c.st, c.g,
+    hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
                        c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X);
     CHECK_LAUNCH();
-    for (int l = 0; l < m->L; ++l) {
+    const bool fused_step = N <= 256 && !getenv("ALINE_WIDE_BLOCKS");
+    if (fused_step) {
+      wide::StepArgs sa{};
+      sa.g = c.g; sa.X0 = X; sa.img = img; sa.L = m->L; sa.F = F; sa.logits = logits;
+      sa.zt = (r->post_mean || r->post_std || r->post_weight || r->target_ll) ? Zt : nullptr;
+      const size_t smem = wide::step_lds_bytes(F);
+      if (smem > 160 * 1024) return ALINE_EUNSUPPORTED;
+      const bool stamped = getenv("ALINE_WIDE_STAMPS") != nullptr;
+      sa.stamps = stamped ? reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps)) : nullptr;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_step_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_step_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      const bool timed = (t == r->T - 1);            // bench.py times this launch of the dominant kernel
+      if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
+      if (stamped) hipLaunchKernelGGL(wide::wide_step_kernel<true>, dim3(r->B), dim3(wide::ST), smem, c.st, sa);
+      else hipLaunchKernelGGL(wide::wide_step_kernel<false>, dim3(r->B), dim3(wide::ST), smem, c.st, sa);
+      if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
+      CHECK_LAUNCH();
+    }
+    for (int l = 0; l < m->L && !fused_step; ++l) {
       const unsigned *li = img + (long)l * lw;
       const float *prm = reinterpret_cast<const float *>(li + nfw);
       wide::BlockArgs b{};
       b.M = M; b.F = F; b.prm = prm;
       b.X = X; b.Y = QKV; b.wimg = li;
       TRY(launch_wide_block<wide::WB_QKV>(c, b));
-      wide::AttnArgs aa{c.g, QKV, A};
+      wide::AttnArgs aa{c.g, QKV, QKV + ipc, QKV + 2 * ipc, A};
       hipLaunchKernelGGL(wide::wide_attention_kernel, dim3(r->B), dim3(wide::NTHREADS), 0, c.st, aa);
       CHECK_LAUNCH();
       b.X = A; b.Xres = X; b.Y = X1; b.wimg = li + 12 * wide::CHUNK_W;
@@ -695,7 +717,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
       TRY(launch_wide_block<wide::WB_FFN>(c, b));
       if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
     }
-    {
+    if (!fused_step) {
       const unsigned *hi = img + (long)m->L * lw;
       wide::BlockArgs b{};
       b.M = M; b.F = F; b.X = X; b.logits = logits; b.wimg = hi;
@@ -717,9 +739,11 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     // posterior of this step first (the selection kernel updates the roles afterwards; order is free)
     if (r->post_mean || r->post_std || r->post_weight || r->target_ll) {
       const long rows = (long)r->B * n_t;
-      hipLaunchKernelGGL(wide::bf16_rows_to_f32_kernel, grid1d((size_t)rows * wide::D), dim3(256), 0, c.st, X, n_t, N,
-                         r->P, rows, Zt);
-      CHECK_LAUNCH();
+      if (!fused_step) {
+        hipLaunchKernelGGL(wide::image_rows_to_f32_kernel, grid1d((size_t)rows * wide::D / 8), dim3(256), 0, c.st, X, n_t, N,
+                           r->P, rows, Zt);
+        CHECK_LAUNCH();
+      }
       const size_t po = (size_t)t * r->B * n_t;
       TRY(do_gmm_rows(c, Zt, (int)rows, r->post_mean ? r->post_mean + po * m->C : nullptr,
                       r->post_std ? r->post_std + po * m->C : nullptr,

@@ -8,7 +8,10 @@
 // 32 KB chunks of 32 fragments go global -> registers -> LDS (double buffered, one barrier per chunk) and
 // are consumed by all 8 waves of the workgroup, each of which keeps 32 tokens (2 column tiles) on chip:
 // its input as 64 VGPRs of bf16 B fragments, its 256-feature output as 128 fp32 accumulator VGPRs.
-// Activations travel between kernels as bf16 rows [M, 256]; LayerNorm, softmax and biases are fp32.
+// Activations travel between kernels as bf16 TILE IMAGES: for every 16 consecutive token rows the 8 B-operand
+// fragments of X^T (k-step ks: 64 lanes x 16 B = 1 KB), i.e. exactly what a wave loads as MFMA operands and
+// exactly what an epilogue holds in its accumulators -- every load/store of a wave is one contiguous KB.
+// Head h of Q/K/V (head_dim 32 = one k-step) is fragment ks = h of a tile.  LayerNorm, softmax, biases: fp32.
 //
 //   wide_block_kernel<WB_QKV>   Q,K,V = in_proj X               (3 passes over the resident input)
 //   wide_attention_kernel       masked set-attention, one workgroup per episode, one wave per head
@@ -24,7 +27,12 @@ namespace wide {
 
 constexpr int D = 256, HD = 32, H = 8, NMT = D / 16, NKS = D / 32;
 constexpr int CHUNK_FRAGS = 32, FRAG_W = 256, CHUNK_W = CHUNK_FRAGS * FRAG_W;   // 32-bit words
-constexpr int WTOK = 32, WG_TOK = 256, NTHREADS = 512;
+constexpr int NTHREADS = 512;             // attention kernel
+#ifndef WIDE_NT
+#define WIDE_NT 2                         // token tiles per wave in the block kernels
+#endif
+constexpr int NT = WIDE_NT, BTHREADS = NT == 2 ? 512 : 256, BWAVES = BTHREADS / 64;
+constexpr int WTOK = 16 * NT, WG_TOK = BWAVES * WTOK, NST = CHUNK_W / 4 / BTHREADS;
 enum { WB_QKV = 0, WB_OUT = 1, WB_FFN = 2, WB_ACQ = 3 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -115,57 +123,69 @@ __global__ void pack_kernel(PackArgs a) {
   }
 }
 
-// X0 (bf16) from the cached fp32 point embeddings: Ex (+ Ey on context rows), theta tokens
+// tile image addressing, in 16-byte pieces: token row -> (tile = row / 16, tok = row % 16); piece (ks, g) of a
+// token holds features 32 ks + 4 g + (0..3) and 32 ks + 16 + 4 g + (0..3)  (the B fragment of lane 16 g + tok)
+__host__ __device__ inline long tile_rows(long M) { return (M + 15) / 16 * 16; }
+__device__ __forceinline__ long piece(long row, int ks, int g) { return ((row >> 4) * NKS + ks) * 64 + g * 16 + (row & 15); }
+
+// X0 (bf16 tile image) from the cached fp32 point embeddings: Ex (+ Ey on context rows), theta tokens
 __global__ void assemble_bf16_kernel(Geo g, const float *__restrict__ Ex, const float *__restrict__ Ey,
                                      int ey_rows, const float *__restrict__ theta_tokens,
-                                     unsigned short *__restrict__ X) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one thread = 2 features
-  long total = (long)g.B * g.N * (D / 2);
-  if (i >= total) return;
-  const int c = (i % (D / 2)) * 2;
-  const long r = i / (D / 2);
-  const int b = r / g.N, row = r % g.N;
-  float v0, v1;
-  if (row < g.P + g.n_td) {
-    const float *e = Ex + ((long)b * (g.P + g.n_td) + row) * D + c;
-    v0 = e[0]; v1 = e[1];
-    if (row < g.P && is_ctx(g, b, row)) { const float *y = Ey + ((long)b * ey_rows + row) * D + c; v0 += y[0]; v1 += y[1]; }
-  } else {
-    const float *t = theta_tokens + (row - g.P - g.n_td) * D + c;
-    v0 = t[0]; v1 = t[1];
+                                     u32x4 *__restrict__ X) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one thread = one 16-byte piece, image order
+  const long M = (long)g.B * g.N;
+  if (i >= tile_rows(M) * (D / 8)) return;
+  const int lane = i & 63, ks = (i >> 6) % NKS, gq = lane >> 4;
+  const long r = (i >> 6) / NKS * 16 + (lane & 15);
+  u32x4 o = {0u, 0u, 0u, 0u};
+  if (r < M) {
+    const int b = r / g.N, row = r % g.N, c = 32 * ks + 4 * gq;
+    f32x4 lo, hi;
+    if (row < g.P + g.n_td) {
+      const float *e = Ex + ((long)b * (g.P + g.n_td) + row) * D + c;
+      lo = *reinterpret_cast<const f32x4 *>(e); hi = *reinterpret_cast<const f32x4 *>(e + 16);
+      if (row < g.P && is_ctx(g, b, row)) {
+        const float *y = Ey + ((long)b * ey_rows + row) * D + c;
+        lo += *reinterpret_cast<const f32x4 *>(y); hi += *reinterpret_cast<const f32x4 *>(y + 16);
+      }
+    } else {
+      const float *t = theta_tokens + (row - g.P - g.n_td) * D + c;
+      lo = *reinterpret_cast<const f32x4 *>(t); hi = *reinterpret_cast<const f32x4 *>(t + 16);
+    }
+    o = (u32x4){pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
   }
-  reinterpret_cast<unsigned *>(X)[i] = pack_bf16(v0, v1);
+  X[i] = o;
 }
 
-__global__ void bf16_rows_to_f32_kernel(const unsigned short *__restrict__ X, int rows_per_ep, int ep_stride,
-                                        int off, long rows, float *__restrict__ out) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * D) return;
-  const long r = i / D;
+// dense fp32 rows out of a tile image: out[r] = token (r / rows_per_ep) * ep_stride + off + r % rows_per_ep
+__global__ void image_rows_to_f32_kernel(const u32x4 *__restrict__ X, int rows_per_ep, int ep_stride,
+                                         int off, long rows, float *__restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one thread = one piece (8 features)
+  if (i >= rows * (D / 8)) return;
+  const long r = i / (D / 8);
+  const int pc = i % (D / 8), ks = pc >> 2, gq = pc & 3;
   const long src = (r / rows_per_ep) * ep_stride + off + (r % rows_per_ep);
-  out[i] = __uint_as_float(((unsigned)X[src * D + (i % D)]) << 16);
+  const u32x4 v = X[piece(src, ks, gq)];
+  float *o = out + r * D + 32 * ks + 4 * gq;
+  *reinterpret_cast<f32x4 *>(o) = (f32x4){bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+  *reinterpret_cast<f32x4 *>(o + 16) = (f32x4){bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
 }
 
 struct BlockArgs {
-  const unsigned short *X;       // [M, 256] bf16 input of the matmul chain
-  const unsigned short *Xres;    // [M, 256] residual (WB_OUT), else unused
-  unsigned short *Y;             // bf16 output rows ([M, 768] for WB_QKV, [M, 256] otherwise)
+  const u32x4 *X;                // tile image of the input of the matmul chain
+  const u32x4 *Xres;             // tile image of the residual (WB_OUT), else unused
+  u32x4 *Y;                      // output tile image (WB_QKV: three images Q | K | V, tile_rows(M) * 32 pieces apart)
   float *logits;                 // [M] (WB_ACQ)
   const unsigned *wimg;          // first chunk of this block's weights
   const float *prm;              // this layer's (or the head's) fp32 parameter block
   int M, F;
 };
 
-// B fragments of 32 tokens from bf16 rows: lane (tok, g) reads features 32 ks + 4 g .. +3 and + 16
-__device__ __forceinline__ void load_xfrags(const unsigned short *X, long row, int g, bf16x8 (&xb)[NKS]) {
-  const unsigned short *xr = X + row * D;
+// B fragments of a 16-token tile: 8 contiguous KB
+__device__ __forceinline__ void load_xfrags(const u32x4 *X, long row, int g, bf16x8 (&xb)[NKS]) {
+  const u32x4 *xr = X + piece(row, 0, g);
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const u32x2 lo = *reinterpret_cast<const u32x2 *>(xr + 32 * ks + 4 * g);
-    const u32x2 hi = *reinterpret_cast<const u32x2 *>(xr + 32 * ks + 16 + 4 * g);
-    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-    xb[ks] = __builtin_bit_cast(bf16x8, v);
-  }
+  for (int ks = 0; ks < NKS; ++ks) xb[ks] = __builtin_bit_cast(bf16x8, xr[ks * 64]);
 }
 __device__ __forceinline__ bf16x8 acc_to_frag(const f32x4 &lo, const f32x4 &hi) {
   const u32x4 v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
@@ -179,20 +199,20 @@ __device__ __forceinline__ float group_sum4(float v) {   // over the 4 lane grou
 }
 
 template <int MODE>
-__global__ __launch_bounds__(NTHREADS, 2) void wide_block_kernel(BlockArgs a) {
+__global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned lds[];      // [2][CHUNK_W] + params (floats)
   unsigned *buf0 = lds, *buf1 = lds + CHUNK_W;
   float *ps = reinterpret_cast<float *>(lds + 2 * CHUNK_W);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
   const long base = (long)blockIdx.x * WG_TOK + wave * WTOK;
-  long row[2];
-  row[0] = min(base + tok, (long)a.M - 1);
-  row[1] = min(base + 16 + tok, (long)a.M - 1);
-  const bool ok[2] = {base + tok < a.M, base + 16 + tok < a.M};
+  long row[NT];
+  bool ok[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) { row[ct] = min(base + 16 * ct + tok, (long)a.M - 1); ok[ct] = base + 16 * ct + tok < a.M; }
 
   // parameters of this block into LDS
   const int nprm = MODE == WB_QKV ? 3 * D : MODE == WB_OUT ? 3 * D : MODE == WB_FFN ? a.F + 3 * D : 2 * a.F + 4;
-  for (int i = tid; i < nprm; i += NTHREADS) {
+  for (int i = tid; i < nprm; i += BTHREADS) {
     float v;
     if (MODE == WB_QKV) v = a.prm[i];                                                  // bq | bk | bv
     else if (MODE == WB_OUT) v = i < D ? a.prm[3 * D + i] : a.prm[4 * D + a.F + D + (i - D)];       // bo | ln1w | ln1b
@@ -202,31 +222,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void wide_block_kernel(BlockArgs a) {
     ps[i] = v;
   }
 
-  bf16x8 xb[2][NKS];
-  load_xfrags(a.X, row[0], g, xb[0]);
-  load_xfrags(a.X, row[1], g, xb[1]);
+  bf16x8 xb[NT][NKS];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) load_xfrags(a.X, row[ct], g, xb[ct]);
 
   const int nchunk = MODE == WB_QKV ? 12 : MODE == WB_OUT ? 4 : MODE == WB_FFN ? a.F / 32 : a.F / 64;
   const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wimg);
-  u32x4 st[4];
+  u32x4 st[NST];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) st[i] = wsrc[tid + i * NTHREADS];
+  for (int i = 0; i < NST; ++i) st[i] = wsrc[tid + i * BTHREADS];
 
-  f32x4 y[NMT][2];
-  float plog[2] = {0.f, 0.f};
+  f32x4 y[NMT][NT];
+  float plog[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) plog[ct] = 0.f;
   if (MODE != WB_ACQ) {
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) { y[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; y[mt][1] = y[mt][0]; }
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) y[mt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
   for (int c = 0; c < nchunk; ++c) {
     unsigned *buf = (c & 1) ? buf1 : buf0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) reinterpret_cast<u32x4 *>(buf)[tid + i * NTHREADS] = st[i];
+    for (int i = 0; i < NST; ++i) reinterpret_cast<u32x4 *>(buf)[tid + i * BTHREADS] = st[i];
     __syncthreads();
     if (c + 1 < nchunk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) st[i] = wsrc[(long)(c + 1) * (CHUNK_W / 4) + tid + i * NTHREADS];
+      for (int i = 0; i < NST; ++i) st[i] = wsrc[(long)(c + 1) * (CHUNK_W / 4) + tid + i * BTHREADS];
     }
     const bf16x8 *fr = reinterpret_cast<const bf16x8 *>(buf) + lane;        // fragment f at fr[f * 64]
 
@@ -238,70 +262,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void wide_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
           const bf16x8 A = fr[(kl * 16 + mt) * 64];
-          WMFMA(y[mt][0], A, xb[0][2 * cc + kl]);
-          WMFMA(y[mt][1], A, xb[1][2 * cc + kl]);
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) WMFMA(y[mt][ct], A, xb[ct][2 * cc + kl]);
         }
       if (MODE == WB_QKV && cc == 3) {
         // end of pass p: bias, store bf16 at column block p, reset the accumulators
         const int p = c >> 2;
+        u32x4 *img = a.Y + (long)p * tile_rows(a.M) * (D / 8);
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) {
-          const f32x4 bv = *reinterpret_cast<const f32x4 *>(ps + p * D + 16 * mt + 4 * g);
+        for (int ks = 0; ks < NKS; ++ks) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(ps + p * D + 32 * ks + 4 * g);
+          const f32x4 b1 = *reinterpret_cast<const f32x4 *>(ps + p * D + 32 * ks + 16 + 4 * g);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const f32x4 v = y[mt][ct] + bv;
-            if (ok[ct]) {
-              const u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-              *reinterpret_cast<u32x2 *>(a.Y + row[ct] * (3 * D) + p * D + 16 * mt + 4 * g) = o;
-            }
-            y[mt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int ct = 0; ct < NT; ++ct) {
+            if (ok[ct])
+              img[piece(row[ct], ks, g)] =
+                  __builtin_bit_cast(u32x4, acc_to_frag(y[2 * ks][ct] + b0, y[2 * ks + 1][ct] + b1));
+            y[2 * ks][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            y[2 * ks + 1][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
       }
     } else if (MODE == WB_FFN) {
-      f32x4 h[2][2];
+      f32x4 h[2][NT];
       {
         const f32x4 b0 = *reinterpret_cast<const f32x4 *>(ps + 32 * c + 4 * g);
         const f32x4 b1 = *reinterpret_cast<const f32x4 *>(ps + 32 * c + 16 + 4 * g);
-        h[0][0] = b0; h[0][1] = b0; h[1][0] = b1; h[1][1] = b1;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) { h[0][ct] = b0; h[1][ct] = b1; }
       }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const bf16x8 A0 = fr[(2 * ks) * 64], A1 = fr[(2 * ks + 1) * 64];
-        WMFMA(h[0][0], A0, xb[0][ks]); WMFMA(h[0][1], A0, xb[1][ks]);
-        WMFMA(h[1][0], A1, xb[0][ks]); WMFMA(h[1][1], A1, xb[1][ks]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) { WMFMA(h[0][ct], A0, xb[ct][ks]); WMFMA(h[1][ct], A1, xb[ct][ks]); }
       }
+      bf16x8 hb[NT];
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
+      for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[m2][ct][r] = fmaxf(h[m2][ct][r], 0.f);
-      const bf16x8 hb0 = acc_to_frag(h[0][0], h[1][0]), hb1 = acc_to_frag(h[0][1], h[1][1]);
+        for (int r = 0; r < 4; ++r) { h[0][ct][r] = fmaxf(h[0][ct][r], 0.f); h[1][ct][r] = fmaxf(h[1][ct][r], 0.f); }
+        hb[ct] = acc_to_frag(h[0][ct], h[1][ct]);
+      }
 #pragma unroll
       for (int mt = 0; mt < NMT; ++mt) {
         const bf16x8 A = fr[(16 + mt) * 64];
-        WMFMA(y[mt][0], A, hb0);
-        WMFMA(y[mt][1], A, hb1);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) WMFMA(y[mt][ct], A, hb[ct]);
       }
     } else {   // WB_ACQ: two groups of 32 hidden units per chunk
 #pragma unroll
       for (int grp = 0; grp < 2; ++grp) {
         const int hbase = 64 * c + 32 * grp;
-        f32x4 h[2][2];
+        f32x4 h[2][NT];
         const f32x4 b0 = *reinterpret_cast<const f32x4 *>(ps + hbase + 4 * g);
         const f32x4 b1 = *reinterpret_cast<const f32x4 *>(ps + hbase + 16 + 4 * g);
-        h[0][0] = b0; h[0][1] = b0; h[1][0] = b1; h[1][1] = b1;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) { h[0][ct] = b0; h[1][ct] = b1; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           const bf16x8 A0 = fr[(grp * 16 + 2 * ks) * 64], A1 = fr[(grp * 16 + 2 * ks + 1) * 64];
-          WMFMA(h[0][0], A0, xb[0][ks]); WMFMA(h[0][1], A0, xb[1][ks]);
-          WMFMA(h[1][0], A1, xb[0][ks]); WMFMA(h[1][1], A1, xb[1][ks]);
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) { WMFMA(h[0][ct], A0, xb[ct][ks]); WMFMA(h[1][ct], A1, xb[ct][ks]); }
         }
         const f32x4 w0 = *reinterpret_cast<const f32x4 *>(ps + a.F + hbase + 4 * g);
         const f32x4 w1 = *reinterpret_cast<const f32x4 *>(ps + a.F + hbase + 16 + 4 * g);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             plog[ct] = fmaf(fmaxf(h[0][ct][r], 0.f), w0[r], plog[ct]);
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wide_block_kernel(BlockArgs a) {
 
   if (MODE == WB_ACQ) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < NT; ++ct) {
       const float v = group_sum4(plog[ct]) + ps[2 * a.F];
       if (g == 0 && ok[ct]) a.logits[row[ct]] = v;
     }
@@ -325,11 +352,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wide_block_kernel(BlockArgs a) {
   const float *bo = ps + (MODE == WB_OUT ? 0 : a.F);
   const float *lw = bo + D, *lb = lw + D;
   if (MODE == WB_OUT) {     // the residual is the layer input, not this block's A operand
-    load_xfrags(a.Xres, row[0], g, xb[0]);
-    load_xfrags(a.Xres, row[1], g, xb[1]);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) load_xfrags(a.Xres, row[ct], g, xb[ct]);
   }
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < NT; ++ct) {
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
@@ -348,29 +375,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void wide_block_kernel(BlockArgs a) {
       for (int r = 0; r < 4; ++r) { const float t = y[mt][ct][r] - mean; ss = fmaf(t, t, ss); }
     const float rstd = rsqrtf(group_sum4(ss) * (1.f / D) + 1e-5f);
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) {
-      const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + 16 * mt + 4 * g);
-      const f32x4 bv = *reinterpret_cast<const f32x4 *>(lb + 16 * mt + 4 * g);
-      float o[4];
+    for (int ks = 0; ks < NKS; ++ks) {
+      f32x4 o[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (y[mt][ct][r] - mean) * rstd * wv[r] + bv[r];
-      if (ok[ct]) {
-        const u32x2 ov = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
-        *reinterpret_cast<u32x2 *>(a.Y + row[ct] * D + 16 * mt + 4 * g) = ov;
+      for (int hf = 0; hf < 2; ++hf) {
+        const int mt = 2 * ks + hf;
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + 16 * mt + 4 * g);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(lb + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[hf][r] = (y[mt][ct][r] - mean) * rstd * wv[r] + bv[r];
       }
+      if (ok[ct]) a.Y[piece(row[ct], ks, g)] = __builtin_bit_cast(u32x4, acc_to_frag(o[0], o[1]));
     }
   }
 }
 
-// ---- masked set-attention on bf16 Q/K/V rows ([M, 768]) ---------------------------------------------------
+// ---- masked set-attention on the Q/K/V tile images -------------------------------------------------------
 // One workgroup per episode, wave h = head h (head_dim 32 = one MFMA k-step: no zero padding).  The head's
 // K fragments (keys x 32 channels) and V^T fragments (32 channels x keys) live in registers for the whole
 // episode; V^T is built through an LDS transpose of the key rows.  Up to 64 keys.
 constexpr int WNK = 64;
 struct AttnArgs {
   Geo g;
-  const unsigned short *QKV;     // [B*N, 768]
-  unsigned short *A;             // [B*N, 256]
+  const u32x4 *Q, *K, *V;        // tile images over the B*N token rows
+  u32x4 *A;                      // tile image of the concatenated head outputs
 };
 
 __global__ __launch_bounds__(NTHREADS) void wide_attention_kernel(AttnArgs a) {
@@ -408,11 +436,12 @@ __global__ __launch_bounds__(NTHREADS) void wide_attention_kernel(AttnArgs a) {
   const int n_ck = s_nck, n_ak = s_nak;
   const long ep = (long)b * g.N;
   // V rows -> LDS (zero rows beyond n_ak)
-  for (int i = tid; i < WNK * (D / 4); i += NTHREADS) {
-    const int j = i / (D / 4), c4 = (i % (D / 4)) * 4;
-    u32x2 v = {0u, 0u};
-    if (j < n_ak) v = *reinterpret_cast<const u32x2 *>(a.QKV + (ep + keyrow[j]) * (3 * D) + 2 * D + c4);
-    *reinterpret_cast<u32x2 *>(&Vs[j][c4]) = v;
+  for (int i = tid; i < WNK * (D / 8); i += NTHREADS) {
+    const int j = i / (D / 8), pc = i % (D / 8), ks = pc >> 2, gq = pc & 3;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (j < n_ak) v = a.V[piece(ep + keyrow[j], ks, gq)];
+    *reinterpret_cast<u32x2 *>(&Vs[j][32 * ks + 4 * gq]) = (u32x2){v[0], v[1]};
+    *reinterpret_cast<u32x2 *>(&Vs[j][32 * ks + 16 + 4 * gq]) = (u32x2){v[2], v[3]};
   }
   __syncthreads();
   const int h = wave;
@@ -423,12 +452,7 @@ __global__ __launch_bounds__(NTHREADS) void wide_attention_kernel(AttnArgs a) {
   for (int kt = 0; kt < 4; ++kt) {
     const int j = 16 * kt + tok;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (j < n_ak) {
-      const unsigned short *kr = a.QKV + (ep + keyrow[j]) * (3 * D) + D + HD * h;
-      const u32x2 lo = *reinterpret_cast<const u32x2 *>(kr + 4 * gg);
-      const u32x2 hi = *reinterpret_cast<const u32x2 *>(kr + 16 + 4 * gg);
-      v = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-    }
+    if (j < n_ak) v = a.K[piece(ep + keyrow[j], h, gg)];
     kf[kt] = __builtin_bit_cast(bf16x8, v);
   }
   // V^T fragments: rows = channel 16 mt + tok, k-step s covers keys 32 s + 16 (j>>2) + 4 g + (j&3)
@@ -452,10 +476,7 @@ __global__ __launch_bounds__(NTHREADS) void wide_attention_kernel(AttnArgs a) {
     const bool isq = rr < g.P && !is_ctx(g, b, rr);
     const int nv = isq ? n_ak : n_ck;
     // Q^T fragment of this head (already scaled by log2(e)/sqrt(hd))
-    const unsigned short *qr = a.QKV + (ep + rr) * (3 * D) + HD * h;
-    const u32x2 qlo = *reinterpret_cast<const u32x2 *>(qr + 4 * gg);
-    const u32x2 qhi = *reinterpret_cast<const u32x2 *>(qr + 16 + 4 * gg);
-    const bf16x8 qf = __builtin_bit_cast(bf16x8, (u32x4){qlo[0], qlo[1], qhi[0], qhi[1]});
+    const bf16x8 qf = __builtin_bit_cast(bf16x8, a.Q[piece(ep + rr, h, gg)]);
     f32x4 s[4];
     float mx = -INFINITY;
 #pragma unroll
@@ -491,13 +512,7 @@ __global__ __launch_bounds__(NTHREADS) void wide_attention_kernel(AttnArgs a) {
       WMFMA(o[0], vf[0][1], p1);
       WMFMA(o[1], vf[1][1], p1);
     }
-    if (valid) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const u32x2 ov = {pack_bf16(o[mt][0] * inv, o[mt][1] * inv), pack_bf16(o[mt][2] * inv, o[mt][3] * inv)};
-        *reinterpret_cast<u32x2 *>(a.A + (ep + row) * D + HD * h + 16 * mt + 4 * gg) = ov;
-      }
-    }
+    if (valid) a.A[piece(ep + row, h, gg)] = __builtin_bit_cast(u32x4, acc_to_frag(o[0] * inv, o[1] * inv));
   }
 }
 
