@@ -103,8 +103,9 @@ __device__ __forceinline__ float group_max4(float v) {
 #endif
 
 // Fragments f = 0..NF-1 of the current chunk (LDS index IDX(f)), NM MFMAs each, in batches of 4: the reads of
-// batch k+1 are issued as one burst in the MIDDLE of batch k's MFMAs, so the s_waitcnt lgkmcnt(0) the compiler
-// puts in front of batch k+1 finds them long complete (one wave per SIMD: nothing else hides LDS latency).
+// batch k+1 are issued as one burst right after the FIRST fragment of batch k, so the s_waitcnt lgkmcnt(0) the
+// compiler puts in front of batch k+1 (with an LDS-DMA pending it never counts) finds them complete three
+// fragments later (one wave per SIMD: nothing else hides LDS latency).
 // Each batch also runs ONE step (P0 + k) of the weight stream.  The sched_group_barriers pin the issue order,
 // the sched_barriers fence the region.
 #define FRAG_PIPE(NF, NM, IDX, P0, BODY)                                 \
@@ -114,16 +115,16 @@ __device__ __forceinline__ float group_max4(float v) {
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) ring_[0][j_] = fr[(IDX(j_)) * 64]; \
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                   \
     _Pragma("unroll") for (int k_ = 0; k_ < NF / 4; ++k_) {              \
-      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { const int f = 4 * k_ + j_; const bf16x8 A = ring_[k_ & 1][j_]; BODY } \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);            \
+      { const int f = 4 * k_; const bf16x8 A = ring_[k_ & 1][0]; BODY }  \
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                \
       if (k_ + 1 < NF / 4) {                                             \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) ring_[(k_ + 1) & 1][j_] = fr[(IDX(4 * (k_ + 1) + j_)) * 64]; \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);               \
       }                                                                  \
       STAGE_STEP((P0) + k_)                                              \
       STAGE_GROUPS                                                       \
-      _Pragma("unroll") for (int j_ = 2; j_ < 4; ++j_) { const int f = 4 * k_ + j_; const bf16x8 A = ring_[k_ & 1][j_]; BODY } \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);            \
+      _Pragma("unroll") for (int j_ = 1; j_ < 4; ++j_) { const int f = 4 * k_ + j_; const bf16x8 A = ring_[k_ & 1][j_]; BODY } \
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * NM, 0);            \
     }                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                   \
   }
@@ -309,6 +310,9 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
     const float *prm = (l & 1) ? pb1 : pb0;           // bq bk bv | bo | b1 | b2 | ln1w ln1b ln2w ln2b
 
     // ---- key rows of X -> LDS (zero rows pad the last key tile) ----------------------------------------------
+    // (the key-row image shares LDS with the X1 copies of the previous layer's FFN, which slower waves may
+    // still be reading in their LN2)
+    if (l > 0) __syncthreads();
 #pragma unroll
     for (int ct = 0; ct < SNT; ++ct) {
       const int r = row0 + 16 * ct;
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < 2; ++half) {               // half 0: fragment 0; half 1: burst + stream step, fragments 1..3
           if (half == 1) {
             if (k + 1 < 8) {
 #pragma unroll
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
             STAGE_GROUPS
           }
 #pragma unroll
-          for (int j = 2 * half; j < 2 * half + 2; ++j) {
+          for (int j = half ? 1 : 0; j < (half ? 4 : 1); ++j) {
             const int f = 4 * k + j;
             const bf16x8 A = rw[k & 1][j];
             if (f < 16) {                                // W1 fragment: k-step f >> 1 (local k-step j >> 1), half f & 1
@@ -586,7 +590,8 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
               for (int ct = 0; ct < SNT; ++ct) WMFMA(y[f - 16][ct], A, hb[ct]);
             }
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+          if (half) __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -290,15 +290,19 @@ def main():
         except Exception:
             traffic = None
     elif wide:
-        # dominant kernel of the wide path: wide_block_kernel<WB_FFN> (one launch = the whole FFN of one layer
-        # for all B*N token rows; launched L*T times per rollout); events around its last launch.
-        m_rows = args.batch * (1 + args.n_query + 2)
-        per_launch = 4.0 * m_rows * args.d_model * args.d_ff
+        # dominant kernel of the wide path: wide::wide_step_kernel -- one launch = the whole encoder stack + the
+        # acquisition head of ONE rollout step for all B episodes (T launches per rollout); the events bracket
+        # the launch of the last step (t = T-1), whose algorithmic FLOPs are those of that step alone.
+        fl_last = (fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
+                   - fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T - 1))
+        per_launch = fl_last * args.batch
         achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
-        kname, peak, traffic = "wide::wide_block_kernel<WB_FFN>", PEAK_BF16_DENSE_TFLOPS, None
-        extra = {"launches_per_rollout": args.layers * args.T,
+        kname, peak, traffic = "wide::wide_step_kernel<false>", PEAK_BF16_DENSE_TFLOPS, None
+        extra = {"launches_per_rollout": args.T,
                  "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
-                 "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md); FFN = 2/3 of the layer FLOPs at d=256"}
+                 "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md).  Algorithmic FLOPs as the reference "
+                              "computes them (K/V for the visible keys only, SURVEY 8-d); the kernel spends MFMA "
+                              "slots on 16 token tiles per episode for 203 tokens (13 tiles used)"}
     else:   # generic pipeline: many kernels per step; report the whole graph as a lower bound
         achieved_tflops = fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12
         kname, per_launch, kernel_ms = "whole rollout graph (generic pipeline, all kernels)", fl_ep * args.batch, dev_ms / args.steps

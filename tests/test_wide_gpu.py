@@ -1,0 +1,76 @@
+"""Wide path (d_model = 256, 8 heads, bf16 MFMA): the fused per-step kernel (wide_step.h) against the generic
+bf16 pipeline, the streamed block kernels, and the fp32 pipeline -- same weights, same forced designs.
+
+Tolerances are bf16 tolerances and are written where they are used: the three bf16 implementations round at
+different places, so they agree with each other to a few 1e-2 in log-likelihood on O(1..10) values, and each
+agrees with fp32 to the bound the committed reference fixture is checked against in test_hip_parity
+(0.6 on max |d NLL| for plain bf16)."""
+import os
+
+import pytest
+import torch
+
+from helpers import native_model
+
+pytestmark = pytest.mark.gpu
+
+DIMS = {"dim_x": 2, "dim_y": 1, "d": 256, "F": 1024, "n_head": 8, "L": 2, "C": 10, "n_theta": 2,
+        "embedding_type": "theta", "time_token": False}
+
+
+def _run(prec, env, B, n_query, T, seed=5, select="forced"):
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        model, _ = native_model(DIMS, 11, prec)
+        torch.manual_seed(seed)
+        task = HiddenLocation(device=torch.device("cuda"), n_query_init=n_query)
+        batch = task.sample_batch(B)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        forced = torch.stack([torch.stack([torch.randint(0, n_query - t, (1,), generator=g)[0] for t in range(T)])
+                              for _ in range(B)]).to("cuda")     # index into the queries remaining at step t
+        ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None).run()
+        torch.cuda.synchronize()
+        return ro.target_ll.float().cpu().clone(), ro.log_prob.float().cpu().clone(), ro.idx.cpu().clone()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("B,n_query,T", [(3, 200, 6), (5, 37, 4), (2, 250, 3), (4, 16, 5)])
+def test_step_kernel_matches_other_bf16_paths(B, n_query, T):
+    """N = 1 + n_query + 2 tokens: 203 (13 tiles, the headline shape), 40 (partial tile), 253 (all 16 tiles),
+    19 (two tiles, one wave idle)."""
+    ll_s, lp_s, _ = _run("bf16", {}, B, n_query, T)
+    ll_b, lp_b, _ = _run("bf16", {"ALINE_WIDE_BLOCKS": "1"}, B, n_query, T)
+    ll_g, lp_g, _ = _run("bf16", {"ALINE_DISABLE_WIDE": "1"}, B, n_query, T)
+    ll_f, lp_f, _ = _run("f32", {}, B, n_query, T)
+    assert torch.isfinite(ll_s).all() and torch.isfinite(lp_s).all()
+    # the two streamed implementations share operand rounding and accumulation order almost everywhere
+    assert (ll_s - ll_b).abs().max() < 5e-2 and (lp_s - lp_b).abs().max() < 5e-3
+    # against the generic bf16 GEMM pipeline and against fp32: bf16 rounding noise only
+    assert (ll_s - ll_g).abs().max() < 0.6 and (lp_s - lp_g).abs().max() < 0.1
+    assert (ll_s - ll_f).abs().max() < 0.6 and (lp_s - lp_f).abs().max() < 0.1
+    # no worse than the generic bf16 pipeline by more than its own error
+    assert (ll_s - ll_f).abs().max() < 2.0 * (ll_g - ll_f).abs().max() + 0.05
+
+
+def test_step_kernel_sampling_and_bookkeeping():
+    """Sampled designs: finite log-probabilities, indices valid for the query set remaining at each step
+    (base_task.py:133-154 removes the chosen query, so step t has n_query - t candidates)."""
+    _, lp, idx = _run("bf16", {}, 6, 60, 8, select="sample")
+    assert lp.shape == (6, 8) and (lp <= 0).all() and torch.isfinite(lp).all()
+    for t in range(8):
+        assert int(idx[:, t].min()) >= 0 and int(idx[:, t].max()) < 60 - t
+
+
+def test_too_many_keys_falls_back_to_generic():
+    """More than 64 visible keys (context + targets) is outside the wide kernels' register layout: the rollout
+    must still run (generic bf16 pipeline) and agree with fp32 to bf16 tolerance."""
+    ll_w, lp_w, _ = _run("bf16", {}, 2, 90, 70)
+    ll_f, lp_f, _ = _run("f32", {}, 2, 90, 70)
+    assert torch.isfinite(ll_w).all()
+    assert (ll_w - ll_f).abs().max() < 1.5 and (lp_w - lp_f).abs().max() < 0.2
