@@ -683,7 +683,9 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     if (fused_step) {
       wide::StepArgs sa{};
       sa.g = c.g; sa.X0 = X; sa.img = img; sa.L = m->L; sa.F = F; sa.logits = logits;
-      sa.zt = (r->post_mean || r->post_std || r->post_weight || r->target_ll) ? Zt : nullptr;
+      // target-row encodings of every step are kept; their GMM heads run once after the loop (large GEMMs)
+      sa.zt = (r->post_mean || r->post_std || r->post_weight || r->target_ll)
+                  ? c.at(c.pl.Ztg) + (size_t)t * r->B * n_t * wide::D : nullptr;
       const size_t smem = wide::step_lds_bytes(F);
       if (smem > 160 * 1024) return ALINE_EUNSUPPORTED;
       const bool stamped = getenv("ALINE_WIDE_STAMPS") != nullptr;
@@ -737,9 +739,9 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     sel.role_out = r->role;
     if (r->P > 1024) return ALINE_EUNSUPPORTED;
     // posterior of this step first (the selection kernel updates the roles afterwards; order is free)
-    if (r->post_mean || r->post_std || r->post_weight || r->target_ll) {
+    if (!fused_step && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
       const long rows = (long)r->B * n_t;
-      if (!fused_step) {
+      {
         hipLaunchKernelGGL(wide::image_rows_to_f32_kernel, grid1d((size_t)rows * wide::D / 8), dim3(256), 0, c.st, X, n_t, N,
                            r->P, rows, Zt);
         CHECK_LAUNCH();
@@ -752,6 +754,15 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     }
     hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
     CHECK_LAUNCH();
+  }
+  if (N <= 256 && !getenv("ALINE_WIDE_BLOCKS") && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
+    const long per_step = (long)r->B * n_t, total = per_step * r->T;
+    for (long r0 = 0; r0 < total; r0 += (long)kGmmChunkRows) {
+      const long nr = std::min<long>((long)kGmmChunkRows, total - r0);
+      TRY(do_gmm_rows(c, c.at(c.pl.Ztg) + r0 * wide::D, (int)nr, r->post_mean ? r->post_mean + r0 * m->C : nullptr,
+                      r->post_std ? r->post_std + r0 * m->C : nullptr, r->post_weight ? r->post_weight + r0 * m->C : nullptr,
+                      r->target_all, r->target_ll ? r->target_ll + r0 : nullptr, r0, per_step));
+    }
   }
   return ALINE_OK;
 }
