@@ -72,6 +72,12 @@ __device__ __forceinline__ f32x4 ldsf4(const float *p) { return *reinterpret_cas
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
 }
+// ReLU on packed bf16: as 16-bit integers the negative values (sign bit set, -0 included) are negative -> max(x, 0)
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+__device__ __forceinline__ bf16x8 relu_frag(bf16x8 f) {
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, f), z));
+}
 __device__ __forceinline__ float group_max4(float v) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -185,6 +191,59 @@ __device__ __forceinline__ void ln_tile(const f32x4 (&yt)[NMT], const bf16x8 (&r
     }
     out[ks] = acc_to_frag(o[0], o[1]);
   }
+}
+
+// Attention of this wave's 4 token tiles against NKT key tiles, head by head: S^T = K Q^T (scores arrive in the
+// exp2 domain, the mask is the accumulator init), softmax over the keys of a token (16 NKT values per lane + one
+// cross-group reduction), O^T = V^T P.  qa[h][ct] goes in as the Q^T fragment and comes out as the fragment of the
+// normalised head output (k-step h of the OUT projection).
+template <int NKT>
+__device__ __forceinline__ void attention_tiles(bf16x8 (&qa)[H][SNT], const bf16x8 *kf, const bf16x8 *vf, const int (&nv)[SNT]) {
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int ct = 0; ct < SNT; ++ct) {
+      int lim = nv[ct];
+      asm volatile("" : "+v"(lim));                   // keep the mask values out of the loop-invariant set
+      f32x4 s[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt][r] = (16 * kt + r) < lim ? 0.f : -INFINITY;
+        IN_VGPR(s[kt]);
+        WMFMA(s[kt], kf[(h * 4 + kt) * 64], qa[h][ct]);
+        IN_VGPR(s[kt]);
+      }
+      float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+      for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+      mx = group_max4(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+          sum += s[kt][r];
+        }
+      const float inv = __builtin_amdgcn_rcpf(group_sum4(sum));
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const bf16x8 p0 = acc_to_frag(s[0], NKT > 1 ? s[NKT > 1 ? 1 : 0] : z4);
+      f32x4 o0 = z4, o1 = z4;
+      IN_VGPR(o0); IN_VGPR(o1);
+      WMFMA(o0, vf[((2 * h) * 2) * 64], p0);
+      WMFMA(o1, vf[((2 * h + 1) * 2) * 64], p0);
+      IN_VGPR(o0); IN_VGPR(o1);
+      if (NKT > 2) {
+        const bf16x8 p1 = acc_to_frag(s[NKT > 2 ? 2 : 0], s[NKT > 2 ? 3 : 0]);
+        WMFMA(o0, vf[((2 * h) * 2 + 1) * 64], p1);
+        WMFMA(o1, vf[((2 * h + 1) * 2 + 1) * 64], p1);
+        IN_VGPR(o0); IN_VGPR(o1);
+      }
+      qa[h][ct] = acc_to_frag(o0 * inv, o1 * inv);
+      IN_VGPR(qa[h][ct]);                             // materialise here (left alone, the normalisation sinks into the OUT chunks)
+      __builtin_amdgcn_sched_barrier(0);              // no interleaving across iterations: it only costs registers
+    }
 }
 
 // Address of the first piece of token row `row` in a tile image, formed at the point of use from a 32-bit piece
@@ -437,47 +496,9 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
         const int r = min(row0 + 16 * ct, G.N - 1);
         nv[ct] = ((r < G.P && keyidx[r] < 0) ? n_ak : n_ck) - 4 * g;   // key 16 kt + 4 g + r is visible iff 16 kt + r < nv
       }
-#pragma unroll
-      for (int h = 0; h < H; ++h)
-#pragma unroll
-        for (int ct = 0; ct < SNT; ++ct) {
-          int lim = nv[ct];
-          asm volatile("" : "+v"(lim));               // keep the mask values out of the loop-invariant set
-          f32x4 s[4];
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] = (16 * kt + r) < lim ? 0.f : -INFINITY;
-            IN_VGPR(s[kt]);
-            WMFMA(s[kt], kf[(h * 4 + kt) * 64], qa[h][ct]);
-            IN_VGPR(s[kt]);
-          }
-          float mx = -INFINITY;
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
-          mx = group_max4(mx);
-          float sum = 0.f;
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-              sum += s[kt][r];
-            }
-          const float inv = __builtin_amdgcn_rcpf(group_sum4(sum));
-          const bf16x8 p0 = acc_to_frag(s[0], s[1]), p1 = acc_to_frag(s[2], s[3]);
-          f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-          IN_VGPR(o0); IN_VGPR(o1);
-          WMFMA(o0, vf[((2 * h) * 2) * 64], p0);
-          WMFMA(o1, vf[((2 * h + 1) * 2) * 64], p0);
-          IN_VGPR(o0); IN_VGPR(o1);
-          WMFMA(o0, vf[((2 * h) * 2 + 1) * 64], p1);
-          WMFMA(o1, vf[((2 * h + 1) * 2 + 1) * 64], p1);
-          IN_VGPR(o0); IN_VGPR(o1);
-          qa[h][ct] = acc_to_frag(o0 * inv, o1 * inv);
-          IN_VGPR(qa[h][ct]);                         // materialise here (left alone, the normalisation sinks into the OUT chunks)
-          __builtin_amdgcn_sched_barrier(0);          // no interleaving across iterations: it only costs registers
-        }
+      if (n_ak <= 16) attention_tiles<1>(qa, kf, vf, nv);          // (wave-uniform: the softmax VALU work scales with
+      else if (n_ak <= 32) attention_tiles<2>(qa, kf, vf, nv);     //  the key tiles; 1 or 2 cover rollouts up to T = 30)
+      else attention_tiles<4>(qa, kf, vf, nv);
     }
 
     WSTAMP(6)   // attention
@@ -541,11 +562,9 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
       const bf16x8 *xl = reinterpret_cast<const bf16x8 *>(Kf + wave * (2 * NKS * 64)) + lane;
       f32x4 hh[2][SNT];
       bf16x8 hb[SNT];
-      {
-        const f32x4 b0 = ldsf4(prm + 4 * D + 32 * c + 4 * g), b1 = ldsf4(prm + 4 * D + 32 * c + 16 + 4 * g);
+      const f32x4 hb0 = ldsf4(prm + 4 * D + 32 * c + 4 * g), hb1 = ldsf4(prm + 4 * D + 32 * c + 16 + 4 * g);
 #pragma unroll
-        for (int ct = 0; ct < SNT; ++ct) { hh[0][ct] = b0; hh[1][ct] = b1; IN_VGPR(hh[0][ct]); IN_VGPR(hh[1][ct]); }
-      }
+      for (int ct = 0; ct < SNT; ++ct) { hh[0][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; hh[1][ct] = hh[0][ct]; }
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 rw[2][4], rx[2][4];                         // W fragments of a batch; X1 fragments [ks local][tile 2..3]
 #pragma unroll
@@ -584,7 +603,7 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
             } else {
               if (f == 16) {
 #pragma unroll
-                for (int ct = 0; ct < SNT; ++ct) { IN_VGPR(hh[0][ct]); IN_VGPR(hh[1][ct]); hb[ct] = acc_to_frag(relu4(hh[0][ct]), relu4(hh[1][ct])); }
+                for (int ct = 0; ct < SNT; ++ct) hb[ct] = relu_frag(acc_to_frag(hh[0][ct] + hb0, hh[1][ct] + hb1));
               }
 #pragma unroll
               for (int ct = 0; ct < SNT; ++ct) WMFMA(y[f - 16][ct], A, hb[ct]);

@@ -49,8 +49,9 @@ def test_step_kernel_matches_other_bf16_paths(B, n_query, T):
     ll_g, lp_g, _ = _run("bf16", {"ALINE_DISABLE_WIDE": "1"}, B, n_query, T)
     ll_f, lp_f, _ = _run("f32", {}, B, n_query, T)
     assert torch.isfinite(ll_s).all() and torch.isfinite(lp_s).all()
-    # the two streamed implementations share operand rounding and accumulation order almost everywhere
-    assert (ll_s - ll_b).abs().max() < 5e-2 and (lp_s - lp_b).abs().max() < 5e-3
+    # the two streamed implementations share operand rounding and accumulation order almost everywhere (the FFN
+    # bias is added before / after the fp32 accumulation, which flips an occasional bf16 rounding)
+    assert (ll_s - ll_b).abs().max() < 0.1 and (lp_s - lp_b).abs().max() < 2e-2
     # against the generic bf16 GEMM pipeline and against fp32: bf16 rounding noise only
     assert (ll_s - ll_g).abs().max() < 0.6 and (lp_s - lp_g).abs().max() < 0.1
     assert (ll_s - ll_f).abs().max() < 0.6 and (lp_s - lp_f).abs().max() < 0.1
