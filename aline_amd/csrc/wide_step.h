@@ -302,7 +302,9 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
   u32x4 stg[4];
   auto begin_chunk = [&]() -> const bf16x8 * {
     if (a.stamps && a.stamps[63]) { WSTAMP(14) }     // (diagnostic split: compute | barrier wait)
+#ifndef WIDE_NO_BARRIER   // (timing experiment only)
     __syncthreads();
+#endif
     if (a.stamps && a.stamps[63]) { WSTAMP(12) }
     nsrc1 = chunk_src(min(q + 1, nq - 1));
     nsrc2 = chunk_src(min(q + 2, nq - 1));
@@ -603,7 +605,11 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
             } else {
               if (f == 16) {
 #pragma unroll
+#ifdef WIDE_NO_PACK   // (timing experiment only)
+                for (int ct = 0; ct < SNT; ++ct) hb[ct] = xb[0][ct];
+#else
                 for (int ct = 0; ct < SNT; ++ct) hb[ct] = relu_frag(acc_to_frag(hh[0][ct] + hb0, hh[1][ct] + hb1));
+#endif
               }
 #pragma unroll
               for (int ct = 0; ct < SNT; ++ct) WMFMA(y[f - 16][ct], A, hb[ct]);
