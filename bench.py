@@ -298,7 +298,13 @@ def main():
         per_launch = fl_last * args.batch
         achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
         kname, peak, traffic = "wide::wide_step_kernel<false>", PEAK_BF16_DENSE_TFLOPS, None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_wide_bf16_d256_pmc_traffic.json")))
+            traffic = tr["hbm_bytes_per_launch"] if args.batch == 1000 and args.T == 30 and args.d_ff == 1024 else None
+        except Exception:
+            traffic = None
         extra = {"launches_per_rollout": args.T,
+                 "traffic_source": "rocprofv3 PMC (profiles/r01_wide_bf16_d256_pmc_traffic.json), average step, not re-measured in this run",
                  "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
                  "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md).  Algorithmic FLOPs as the reference "
                               "computes them (K/V for the visible keys only, SURVEY 8-d); the kernel spends MFMA "
