@@ -27,12 +27,29 @@ __global__ __launch_bounds__(256) void eig_location_step_kernel(const float *__r
                                                                 int K, int D, float noise, float base,
                                                                 float msig) {
   const long total = L1 * B;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int b = i % B;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // (l, b) of element i is carried along the grid-stride loop: no 64-bit division per element
+  int b = (int)(i % B);
+  const int db = (int)(stride % B);
+  if (K == 1 && D == 2) {               // the configured task (location_finding.yaml): theta is one float2 per (l, b)
+    const float2 *th2 = reinterpret_cast<const float2 *>(theta);
+    const float2 *xi2 = reinterpret_cast<const float2 *>(xi);
+    const float inv2n2 = 1.f / (2.f * noise * noise), cst = logf(noise) + LOG_SQRT_2PI;
+    for (; i < total; i += stride) {
+      const float2 t = th2[i], x = xi2[b];
+      const float dx = x.x - t.x, dy = x.y - t.y;
+      const float z = y[b] - logf(base + 1.f / (msig + fmaf(dx, dx, dy * dy)));
+      S[i] += -(z * z) * inv2n2 - cst;
+      b += db; if (b >= B) b -= B;
+    }
+    return;
+  }
+  for (; i < total; i += stride) {
     float x[8];
     for (int c = 0; c < D; ++c) x[c] = xi[b * D + c];
     S[i] += location_ll(theta + i * K * D, x, y[b], K, D, noise, base, msig);
+    b += db; if (b >= B) b -= B;
   }
 }
 
@@ -80,9 +97,11 @@ __global__ __launch_bounds__(256) void eig_ces_step_kernel(const float *__restri
                                                            float noise, float eps, int *nan_flag) {
   const long total = L1 * B;
   bool bad = false;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int b = i % B;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int b = (int)(i0 % B);
+  const int db = (int)(stride % B);
+  for (long i = i0; i < total; i += stride, b = (b + db >= B ? b + db - B : b + db)) {
     const float *th = theta + i * 5;
     const float rho = th[0], a0 = th[1], a1 = th[2], a2 = th[3], u = expf(th[4]);
     float x[6];
@@ -111,13 +130,22 @@ __global__ __launch_bounds__(256) void eig_lse_partial_kernel(const float *__res
   const long l0 = 1 + (long)blockIdx.x * chunk;
   const long l1 = min(L1, l0 + chunk);
   float m = -INFINITY, s = 0.f;
-  if (b < B)
-    for (long l = l0 + ty; l < l1; l += 4) {
+  if (b < B) {
+    long l = l0 + ty;
+    for (; l + 12 < l1; l += 16) {       // four independent loads in flight per thread, one rescale per group
+      const float v0 = S[l * B + b], v1 = S[(l + 4) * B + b], v2 = S[(l + 8) * B + b], v3 = S[(l + 12) * B + b];
+      const float mn = fmaxf(fmaxf(m, fmaxf(v0, v1)), fmaxf(v2, v3));
+      if (mn != -INFINITY)
+        s = s * __expf(m - mn) + ((__expf(v0 - mn) + __expf(v1 - mn)) + (__expf(v2 - mn) + __expf(v3 - mn)));
+      m = mn;
+    }
+    for (; l < l1; l += 4) {
       float v = S[l * B + b];
       float mn = fmaxf(m, v);
       s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + __expf(v - mn);
       m = mn;
     }
+  }
   sm[ty][tx] = m; ss[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && b < B) {
