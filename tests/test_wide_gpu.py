@@ -18,7 +18,7 @@ DIMS = {"dim_x": 2, "dim_y": 1, "d": 256, "F": 1024, "n_head": 8, "L": 2, "C": 1
         "embedding_type": "theta", "time_token": False}
 
 
-def _run(prec, env, B, n_query, T, seed=5, select="forced"):
+def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None):
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
     for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS"):
@@ -29,6 +29,8 @@ def _run(prec, env, B, n_query, T, seed=5, select="forced"):
         torch.manual_seed(seed)
         task = HiddenLocation(device=torch.device("cuda"), n_query_init=n_query)
         batch = task.sample_batch(B)
+        if target_mask is not None:
+            batch.target_mask = torch.tensor(target_mask, dtype=torch.bool, device="cuda")
         g = torch.Generator(device="cpu").manual_seed(seed)
         forced = torch.stack([torch.stack([torch.randint(0, n_query - t, (1,), generator=g)[0] for t in range(T)])
                               for _ in range(B)]).to("cuda")     # index into the queries remaining at step t
@@ -75,3 +77,17 @@ def test_too_many_keys_falls_back_to_generic():
     ll_f, lp_f, _ = _run("f32", {}, 2, 90, 70)
     assert torch.isfinite(ll_w).all()
     assert (ll_w - ll_f).abs().max() < 1.5 and (lp_w - lp_f).abs().max() < 0.2
+
+
+@pytest.mark.parametrize("mask", [[True, False], [False, True], [False, False]])
+def test_step_kernel_with_target_mask(mask):
+    """Queries attend only the selected targets (encoder.py:110-121); the key list of the fused kernel then has
+    n_ctx + (#selected) entries.  An all-False mask leaves the context keys only."""
+    ll_s, lp_s, _ = _run("bf16", {}, 3, 70, 5, target_mask=mask)
+    ll_g, lp_g, _ = _run("bf16", {"ALINE_DISABLE_WIDE": "1"}, 3, 70, 5, target_mask=mask)
+    ll_f, lp_f, _ = _run("f32", {}, 3, 70, 5, target_mask=mask)
+    assert (ll_s - ll_g).abs().max() < 0.6 and (lp_s - lp_g).abs().max() < 0.1
+    assert (ll_s - ll_f).abs().max() < 0.6 and (lp_s - lp_f).abs().max() < 0.1
+    # the mask must matter: a different selection changes the query logits
+    _, lp_other, _ = _run("bf16", {}, 3, 70, 5, target_mask=[not m for m in mask] if any(mask) else [True, True])
+    assert (lp_s - lp_other).abs().max() > 1e-4
