@@ -674,12 +674,14 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
   float *logits = c.at(c.pl.wLog), *Zt = c.at(c.pl.wZt);
   const long lw = wide::layer_words(F);
   const long nfw = (long)wide::layer_chunks(F) * wide::CHUNK_W;
+  // one fused kernel per step when an episode fits a workgroup (<= 16 token tiles, LDS for the parameters);
+  // otherwise the streamed per-block kernels with activations in HBM
+  const bool fused_step = N <= 256 && wide::step_lds_bytes(F) <= 160 * 1024 && !getenv("ALINE_WIDE_BLOCKS");
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
     hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
                        c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X);
     CHECK_LAUNCH();
-    const bool fused_step = N <= 256 && !getenv("ALINE_WIDE_BLOCKS");
     if (fused_step) {
       wide::StepArgs sa{};
       sa.g = c.g; sa.X0 = X; sa.img = img; sa.L = m->L; sa.F = F; sa.logits = logits;
@@ -687,7 +689,6 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
       sa.zt = (r->post_mean || r->post_std || r->post_weight || r->target_ll)
                   ? c.at(c.pl.Ztg) + (size_t)t * r->B * n_t * wide::D : nullptr;
       const size_t smem = wide::step_lds_bytes(F);
-      if (smem > 160 * 1024) return ALINE_EUNSUPPORTED;
       const bool stamped = getenv("ALINE_WIDE_STAMPS") != nullptr;
       sa.stamps = stamped ? reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps)) : nullptr;
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_step_kernel<false>),
@@ -755,7 +756,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
     CHECK_LAUNCH();
   }
-  if (N <= 256 && !getenv("ALINE_WIDE_BLOCKS") && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
+  if (fused_step && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
     const long per_step = (long)r->B * n_t, total = per_step * r->T;
     for (long r0 = 0; r0 < total; r0 += (long)kGmmChunkRows) {
       const long nr = std::min<long>((long)kGmmChunkRows, total - r0);

@@ -91,3 +91,18 @@ def test_step_kernel_with_target_mask(mask):
     # the mask must matter: a different selection changes the query logits
     _, lp_other, _ = _run("bf16", {}, 3, 70, 5, target_mask=[not m for m in mask] if any(mask) else [True, True])
     assert (lp_s - lp_other).abs().max() > 1e-4
+
+
+def test_wide_dims_outside_the_step_kernel_use_block_kernels():
+    """F = 2048: the per-layer parameters no longer fit the step kernel's LDS budget -> streamed block kernels
+    (same tile images); still bf16-close to fp32."""
+    global DIMS
+    saved = dict(DIMS)
+    try:
+        DIMS = dict(DIMS, F=2048, L=1)
+        ll_w, lp_w, _ = _run("bf16", {}, 2, 40, 3)
+        ll_f, lp_f, _ = _run("f32", {}, 2, 40, 3)
+    finally:
+        DIMS = saved
+    assert torch.isfinite(ll_w).all()
+    assert (ll_w - ll_f).abs().max() < 0.6 and (lp_w - lp_f).abs().max() < 0.1
