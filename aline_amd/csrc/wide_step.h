@@ -307,7 +307,8 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
 #endif
     if (a.stamps && a.stamps[63]) { WSTAMP(12) }
     nsrc1 = chunk_src(min(q + 1, nq - 1));
-    nsrc2 = chunk_src(min(q + 2, nq - 1));
+    nsrc2 = chunk_src(min(q + 2, nq - 1));   // (register-staged stream variant only)
+    (void)nsrc2;
     ndst = reinterpret_cast<char *>(((q + 1) & 1) ? wbuf1 : wbuf0);
     const bf16x8 *fr = reinterpret_cast<const bf16x8 *>((q & 1) ? wbuf1 : wbuf0) + lane;
     ++q;
