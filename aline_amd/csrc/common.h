@@ -42,3 +42,12 @@ __device__ __forceinline__ float softplus_f(float x) {
   // torch.nn.functional.softplus(beta=1, threshold=20)
   return x > 20.f ? x : log1pf(expf(x));
 }
+
+// ReLU as ONE integer instruction (v_max_i32): as two's-complement integers the floats with the sign bit set
+// (negative values, -0) are negative, the others keep their order -> max(bits, 0) is relu(x) exactly.  fmaxf(x, 0)
+// is llvm.maxnum, which in IEEE mode first canonicalises its input (a second v_max_f32 per element) -- it matters in
+// kernels that are VALU-issue bound.  (Plain instruction, so the MFMA -> VALU hazards stay with the compiler.)
+__device__ __forceinline__ float relu_nn(float a) {
+  const int b = __builtin_bit_cast(int, a);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}

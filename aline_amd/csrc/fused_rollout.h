@@ -426,7 +426,7 @@ __device__ __forceinline__ void layer_tiles(f32x4 (&x)[NT][2], const float *Wl, 
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { hd[t][0][r] = fmaxf(hd[t][0][r], 0.f); hd[t][1][r] = fmaxf(hd[t][1][r], 0.f); }
+        for (int r = 0; r < 4; ++r) { hd[t][0][r] = relu_nn(hd[t][0][r]); hd[t][1][r] = relu_nn(hd[t][1][r]); }
         const Frag3 hf = split_acc(hd[t][0], hd[t][1]);
         mma6x2(x[t][0], x[t][1], d0, d1, hf);
       }
@@ -456,8 +456,8 @@ __device__ __forceinline__ void acq_tiles(const f32x4 (&z)[NT][2], const float *
       mma6x2(h0, h1, u0, u1, zf[t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[t] = fmaf(fmaxf(h0[r], 0.f), w20[r], p[t]);
-        p[t] = fmaf(fmaxf(h1[r], 0.f), w21[r], p[t]);
+        p[t] = fmaf(relu_nn(h0[r]), w20[r], p[t]);
+        p[t] = fmaf(relu_nn(h1[r]), w21[r], p[t]);
       }
     }
   }

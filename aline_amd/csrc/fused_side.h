@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void embed_points_kernel(EmbedArgs a) {
           const int u = 32 * kb + 16 * mt + 4 * g + r;
           float acc = b1s[u];
           for (int k = 0; k < a.K; ++k) acc = fmaf(xv[k], w1s[u * a.K + k], acc);
-          h[mt][r] = fmaxf(acc, 0.f);
+          h[mt][r] = relu_nn(acc);
         }
       const Frag3 hf = split_acc(h[0], h[1]);
       mma6x2(y[0], y[1], ld_frag3(W2f + (0 * 4 + kb) * FRAG3, lane), ld_frag3(W2f + (1 * 4 + kb) * FRAG3, lane), hf);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gmm_rows_kernel(GmmRowsArgs a) {
       mma6x2(h0, h1, ld_frag3(W1f + (2 * mp) * FRAG3, lane), ld_frag3(W1f + (2 * mp + 1) * FRAG3, lane), zf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float a0 = fmaxf(h0[r], 0.f), a1 = fmaxf(h1[r], 0.f);
+        const float a0 = relu_nn(h0[r]), a1 = relu_nn(h1[r]);
         const int u0 = 32 * mp + 4 * g + r, u1 = u0 + 16;
         p0 = fmaf(a0, w2s[u0], p0); p0 = fmaf(a1, w2s[u1], p0);
         p1 = fmaf(a0, w2s[F + u0], p1); p1 = fmaf(a1, w2s[F + u1], p1);

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { h[0][ct][r] = fmaxf(h[0][ct][r], 0.f); h[1][ct][r] = fmaxf(h[1][ct][r], 0.f); }
+        for (int r = 0; r < 4; ++r) { h[0][ct][r] = relu_nn(h[0][ct][r]); h[1][ct][r] = relu_nn(h[1][ct][r]); }
         hb[ct] = acc_to_frag(h[0][ct], h[1][ct]);
       }
 #pragma unroll
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            plog[ct] = fmaf(fmaxf(h[0][ct][r], 0.f), w0[r], plog[ct]);
-            plog[ct] = fmaf(fmaxf(h[1][ct][r], 0.f), w1[r], plog[ct]);
+            plog[ct] = fmaf(relu_nn(h[0][ct][r]), w0[r], plog[ct]);
+            plog[ct] = fmaf(relu_nn(h[1][ct][r]), w1[r], plog[ct]);
           }
       }
     }

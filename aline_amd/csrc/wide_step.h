@@ -70,7 +70,7 @@ __device__ __forceinline__ void issue_floats(const float *src, float *dst, int n
 
 __device__ __forceinline__ f32x4 ldsf4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
-  return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+  return (f32x4){relu_nn(v[0]), relu_nn(v[1]), relu_nn(v[2]), relu_nn(v[3])};
 }
 // ReLU on packed bf16: as 16-bit integers the negative values (sign bit set, -0 included) are negative -> max(x, 0)
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -674,8 +674,8 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
         for (int ct = 0; ct < SNT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            plog[ct] = fmaf(fmaxf(hh[0][ct][r], 0.f), w0[r], plog[ct]);
-            plog[ct] = fmaf(fmaxf(hh[1][ct][r], 0.f), w1[r], plog[ct]);
+            plog[ct] = fmaf(relu_nn(hh[0][ct][r]), w0[r], plog[ct]);
+            plog[ct] = fmaf(relu_nn(hh[1][ct][r]), w1[r], plog[ct]);
           }
       }
     }
