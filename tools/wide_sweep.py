@@ -1,0 +1,30 @@
+import sys, os, torch, random
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/oracle")
+from helpers import native_model
+from aline_amd.rollout import Rollout
+from aline_amd.tasks import HiddenLocation
+def run(env, dims, B, nq, T, seed, mask):
+    for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS"): os.environ.pop(k, None)
+    os.environ.update(env)
+    model, _ = native_model(dims, 11 + seed, "bf16")
+    torch.manual_seed(seed)
+    batch = HiddenLocation(device=torch.device("cuda"), n_query_init=nq).sample_batch(B)
+    if mask is not None: batch.target_mask = torch.tensor(mask, dtype=torch.bool, device="cuda")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    forced = torch.stack([torch.stack([torch.randint(0, nq - t, (1,), generator=g)[0] for t in range(T)]) for _ in range(B)]).to("cuda")
+    ro = Rollout(model, batch, T, select="forced", forced_idx=forced).run()
+    torch.cuda.synchronize()
+    return ro.target_ll.float().cpu().clone(), ro.log_prob.float().cpu().clone()
+random.seed(0)
+worst = 0
+for it in range(40):
+    L = random.choice([1, 2, 3]); F = random.choice([64, 256, 1024])
+    dims = {"dim_x": 2, "dim_y": 1, "d": 256, "F": F, "n_head": 8, "L": L, "C": 10, "n_theta": 2, "embedding_type": "theta", "time_token": False}
+    nq = random.choice([5, 13, 14, 29, 45, 61, 100, 157, 200, 237, 253]); T = random.randint(1, min(nq - 1, 45)); B = random.randint(1, 7)
+    mask = random.choice([None, None, [True, False], [False, True], [False, False]])
+    a = run({}, dims, B, nq, T, it, mask); a2 = run({}, dims, B, nq, T, it, mask); b = run({"ALINE_WIDE_BLOCKS": "1"}, dims, B, nq, T, it, mask)
+    d1 = float((a[0] - b[0]).abs().max()); d2 = float((a[1] - b[1]).abs().max()); dd = float((a[0] - a2[0]).abs().max()) + float((a[1] - a2[1]).abs().max())
+    bad = (not torch.isfinite(a[0]).all()) or d1 > 0.2 or d2 > 0.05 or dd != 0.0
+    worst = max(worst, d1)
+    print(it, "L", L, "F", F, "N", nq + 3, "T", T, "B", B, "mask", mask, "dLL %.4f dlp %.4f rerun %.1e" % (d1, d2, dd), "BAD" if bad else "", flush=True)
+print("worst dLL", worst)
