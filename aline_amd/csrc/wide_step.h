@@ -159,7 +159,7 @@ template <bool ZT, bool RES>
 __device__ __forceinline__ void ln_tile(const f32x4 (&yt)[NMT], const bf16x8 (&res)[NKS], const float *bias, const float *lw,
                                         const float *lb, int g, float *zrow, bf16x8 (&out)[NKS]) {
   f32x4 v[NMT];
-  float s = 0.f;
+  float s = 0.f, q = 0.f;                             // one pass: sum and sum of squares (fp32, 256 values of O(1..10))
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
     v[mt] = acc_rd4(yt[mt]);
@@ -170,14 +170,12 @@ __device__ __forceinline__ void ln_tile(const f32x4 (&yt)[NMT], const bf16x8 (&r
       v[mt] += (f32x4){bv[0] + bf_lo(w0), bv[1] + bf_hi(w0), bv[2] + bf_lo(w1), bv[3] + bf_hi(w1)};
     }
     s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q = fmaf(v[mt][r], v[mt][r], q);
   }
   const float mean = group_sum4(s) * (1.f / D);
-  float ss = 0.f;
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const float t = v[mt][r] - mean; ss = fmaf(t, t, ss); }
-  const float rstd = rsqrtf(group_sum4(ss) * (1.f / D) + 1e-5f);
+  const float var = fmaxf(group_sum4(q) * (1.f / D) - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + 1e-5f), nmr = -mean * rstd;
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     f32x4 o[2];
@@ -186,7 +184,7 @@ __device__ __forceinline__ void ln_tile(const f32x4 (&yt)[NMT], const bf16x8 (&r
       const int mt = 2 * ks + hf;
       const f32x4 wv = ldsf4(lw + 16 * mt + 4 * g), bv = ldsf4(lb + 16 * mt + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[hf][r] = (v[mt][r] - mean) * rstd * wv[r] + bv[r];
+      for (int r = 0; r < 4; ++r) o[hf][r] = fmaf(fmaf(v[mt][r], rstd, nmr), wv[r], bv[r]);
       if (ZT && zrow) *reinterpret_cast<f32x4 *>(zrow + 16 * mt + 4 * g) = o[hf];
     }
     out[ks] = acc_to_frag(o[0], o[1]);
