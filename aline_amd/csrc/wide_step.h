@@ -197,19 +197,35 @@ __device__ __forceinline__ void ln_tile(const f32x4 (&yt)[NMT], const bf16x8 (&r
 // normalised head output (k-step h of the OUT projection).
 template <int NKT>
 __device__ __forceinline__ void attention_tiles(bf16x8 (&qa)[H][SNT], const bf16x8 *kf, const bf16x8 *vf, const int (&nv)[SNT]) {
+  // the additive key mask of a token tile (0 / -inf per (key tile, r)) is the same for all heads: with 1 or 2 key
+  // tiles it is kept in registers for the whole attention block (8 VGPRs per key tile and token tile) and is the
+  // C operand of the score MFMA; with 4 key tiles it is rebuilt per head (registers)
+  constexpr bool KEEP = NKT <= 2;
+  f32x4 mb[KEEP ? SNT : 1][NKT];
+  if (KEEP) {
+#pragma unroll
+    for (int ct = 0; ct < SNT; ++ct)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mb[ct][kt][r] = (16 * kt + r) < nv[ct] ? 0.f : -INFINITY;
+  }
 #pragma unroll
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int ct = 0; ct < SNT; ++ct) {
-      int lim = nv[ct];
-      asm volatile("" : "+v"(lim));                   // keep the mask values out of the loop-invariant set
       f32x4 s[NKT];
+      if (!KEEP) {
+        int lim = nv[ct];
+        asm volatile("" : "+v"(lim));                 // keep the mask values out of the loop-invariant set
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mb[0][kt][r] = (16 * kt + r) < lim ? 0.f : -INFINITY;
+      }
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[kt][r] = (16 * kt + r) < lim ? 0.f : -INFINITY;
-        IN_VGPR(s[kt]);
-        WMFMA(s[kt], kf[(h * 4 + kt) * 64], qa[h][ct]);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[(h * 4 + kt) * 64], qa[h][ct], mb[KEEP ? ct : 0][kt], 0, 0, 0);
         IN_VGPR(s[kt]);
       }
       float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
