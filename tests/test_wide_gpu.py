@@ -93,9 +93,9 @@ def test_step_kernel_with_target_mask(mask):
     assert (lp_s - lp_other).abs().max() > 1e-4
 
 
-def test_wide_dims_outside_the_step_kernel_use_block_kernels():
-    """F = 2048: the per-layer parameters no longer fit the step kernel's LDS budget -> streamed block kernels
-    (same tile images); still bf16-close to fp32."""
+def test_wide_dims_outside_the_step_kernel_fall_back():
+    """F = 2048: the per-layer parameters no longer fit the step kernel's LDS budget -> generic bf16 pipeline;
+    still bf16-close to fp32."""
     global DIMS
     saved = dict(DIMS)
     try:
@@ -106,3 +106,11 @@ def test_wide_dims_outside_the_step_kernel_use_block_kernels():
         DIMS = saved
     assert torch.isfinite(ll_w).all()
     assert (ll_w - ll_f).abs().max() < 0.6 and (lp_w - lp_f).abs().max() < 0.1
+
+
+def test_step_kernel_is_reproducible():
+    """Same inputs, same bits (the kernel has barriers between every LDS producer and consumer; a missing one
+    showed up as run-to-run differences during development)."""
+    a = _run("bf16", {}, 3, 200, 6)
+    b = _run("bf16", {}, 3, 200, 6)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
