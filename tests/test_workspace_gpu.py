@@ -1,0 +1,45 @@
+"""The C ABI works in a caller-provided workspace it never allocates or clears: no product path may read a byte of
+it that it has not written itself.  Each rollout path is run on a workspace pre-filled with zeros, with 0xFF
+(bf16 / fp32 NaN patterns) and with 0x7F (huge finite values); the outputs must be bit-identical."""
+import os
+
+import pytest
+import torch
+
+from conftest import Fixture
+from helpers import native_model, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fxname, prec, env, fill):
+    from aline_amd.rollout import Rollout
+    for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS", "ALINE_DISABLE_FUSED"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        fx = Fixture(fxname)
+        model, _ = native_model(fx.meta["dims"], fx.meta["wseed"], prec)
+        ro = Rollout(model, to_dev(fx.batch()), fx.meta["T"], select="forced", forced_idx=fx.forced_idx("train"))
+        ro.ws.fill_(fill)
+        ro.run()
+        torch.cuda.synchronize()
+        return ro.target_ll.cpu().clone(), ro.log_prob.cpu().clone()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("name,fxname,prec,env", [
+    ("fused d=32", "cfg2_location_d32", "f32", {}),
+    ("generic d=32", "cfg2_location_d32", "f32", {"ALINE_DISABLE_FUSED": "1"}),
+    ("wide step d=256", "cfg2_location_d256", "bf16", {}),
+    ("generic bf16 d=256", "cfg2_location_d256", "bf16", {"ALINE_DISABLE_WIDE": "1"}),
+    ("generic mix-mode", "cfg3_almix_d2", "f32", {}),
+])
+def test_outputs_do_not_depend_on_workspace_contents(name, fxname, prec, env):
+    ref = _run(fxname, prec, env, 0)
+    for fill in (0xFF, 0x7F):
+        out = _run(fxname, prec, env, fill)
+        assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), (name, hex(fill))
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (name, hex(fill))
