@@ -639,11 +639,6 @@ static bool wide_eligible(const aline_model &m, const aline_rollout &r) {
   if (getenv("ALINE_DISABLE_WIDE")) return false;
   if (m.precision != ALINE_PREC_BF16 || m.d != wide::D || m.H != wide::H || m.F % 64 || m.time_token) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > wide::WNK) return false;
-  // the fused step kernel needs an episode to fit a workgroup (<= 16 token tiles) and the layer parameters to fit its
-  // LDS budget; the streamed per-block kernels (ALINE_WIDE_BLOCKS=1) are a development cross-check only -- their
-  // query logits are not run-to-run reproducible yet -- so everything else takes the generic pipeline
-  const int N = r.P + r.n_target_data + m.n_theta;
-  if (!getenv("ALINE_WIDE_BLOCKS") && (N > 256 || wide::step_lds_bytes(m.F) > 160 * 1024)) return false;
   return true;
 }
 

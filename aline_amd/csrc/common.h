@@ -43,11 +43,8 @@ __device__ __forceinline__ float softplus_f(float x) {
   return x > 20.f ? x : log1pf(expf(x));
 }
 
-// ReLU as ONE integer instruction (v_max_i32): as two's-complement integers the floats with the sign bit set
-// (negative values, -0) are negative, the others keep their order -> max(bits, 0) is relu(x) exactly.  fmaxf(x, 0)
-// is llvm.maxnum, which in IEEE mode first canonicalises its input (a second v_max_f32 per element) -- it matters in
-// kernels that are VALU-issue bound.  (Plain instruction, so the MFMA -> VALU hazards stay with the compiler.)
-__device__ __forceinline__ float relu_nn(float a) {
-  const int b = __builtin_bit_cast(int, a);
-  return __builtin_bit_cast(float, b > 0 ? b : 0);
-}
+// ReLU.  NOT the one-instruction integer form max(bits, 0) (it would save the canonicalising v_max_f32 x, x, x that
+// llvm.maxnum emits in IEEE mode): v_max_i32 applied directly to MFMA results made wide_block_kernel<WB_ACQ> return
+// different logits for a token tile in 1 of 3 runs on gfx950 (ROCm 7.2 hipcc) -- an MFMA -> integer-VALU hazard the
+// compiler's wait states do not cover -- while the float form is reproducible (60 of 60 runs).
+__device__ __forceinline__ float relu_nn(float a) { return fmaxf(a, 0.f); }
