@@ -677,14 +677,21 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
   // one fused kernel per step when an episode fits a workgroup (<= 16 token tiles, LDS for the parameters);
   // otherwise the streamed per-block kernels with activations in HBM
   const bool fused_step = N <= 256 && wide::step_lds_bytes(F) <= 160 * 1024 && !getenv("ALINE_WIDE_BLOCKS");
+  if (fused_step) {   // the input image is assembled once (X1 is free in this mode) and patched row-wise between steps
+    hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
+                       c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X1);
+    CHECK_LAUNCH();
+  }
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
-    hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
-                       c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X);
-    CHECK_LAUNCH();
+    if (!fused_step) {
+      hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
+                         c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X);
+      CHECK_LAUNCH();
+    }
     if (fused_step) {
       wide::StepArgs sa{};
-      sa.g = c.g; sa.X0 = X; sa.img = img; sa.L = m->L; sa.F = F; sa.logits = logits;
+      sa.g = c.g; sa.XIN = X1; sa.X0 = X; sa.img = img; sa.L = m->L; sa.F = F; sa.logits = logits;
       // target-row encodings of every step are kept; their GMM heads run once after the loop (large GEMMs)
       sa.zt = (r->post_mean || r->post_std || r->post_weight || r->target_ll)
                   ? c.at(c.pl.Ztg) + (size_t)t * r->B * n_t * wide::D : nullptr;
@@ -755,6 +762,11 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     }
     hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
     CHECK_LAUNCH();
+    if (fused_step && t + 1 < r->T) {   // the chosen point enters the context: its input row becomes Ex + Ey
+      hipLaunchKernelGGL(wide::patch_context_row_kernel, dim3(r->B), dim3(64), 0, c.st, c.g, r->n_ctx0 + t + 1,
+                         c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, X1);
+      CHECK_LAUNCH();
+    }
   }
   if (fused_step && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
     const long per_step = (long)r->B * n_t, total = per_step * r->T;

@@ -157,6 +157,25 @@ __global__ void assemble_bf16_kernel(Geo g, const float *__restrict__ Ex, const 
   X[i] = o;
 }
 
+// The step's input image changes in ONE row per episode from step to step: the point chosen at step t (role ==
+// order of entry == `order`) becomes a context point, i.e. its row becomes Ex + Ey.  One workgroup per episode.
+__global__ __launch_bounds__(64) void patch_context_row_kernel(Geo g, int order, const float *__restrict__ Ex,
+                                                               const float *__restrict__ Ey, int ey_rows,
+                                                               u32x4 *__restrict__ X) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int slot = -1;
+  for (int p = lane; p < g.P; p += 64)
+    if (g.role[(long)b * g.P + p] == order) slot = p;
+  slot = __reduce_max_sync(~0ull, slot);
+  if (slot < 0 || lane >= D / 8) return;
+  const int ks = lane >> 2, gq = lane & 3, c = 32 * ks + 4 * gq;
+  const float *e = Ex + ((long)b * (g.P + g.n_td) + slot) * D + c, *y = Ey + ((long)b * ey_rows + slot) * D + c;
+  const f32x4 lo = *reinterpret_cast<const f32x4 *>(e) + *reinterpret_cast<const f32x4 *>(y);
+  const f32x4 hi = *reinterpret_cast<const f32x4 *>(e + 16) + *reinterpret_cast<const f32x4 *>(y + 16);
+  X[piece((long)b * g.N + slot, ks, gq)] =
+      (u32x4){pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+}
+
 // dense fp32 rows out of a tile image: out[r] = token (r / rows_per_ep) * ep_stride + off + r % rows_per_ep
 __global__ void image_rows_to_f32_kernel(const u32x4 *__restrict__ X, int rows_per_ep, int ep_stride,
                                          int off, long rows, float *__restrict__ out) {

@@ -25,8 +25,9 @@ constexpr int KX_PIECES = 4 * NKS * 64;          // key-row image [kt][ks]      
 
 struct StepArgs {
   Geo g;
-  u32x4 *X0;              // tile image over the B*N token rows: the assembled input; each layer's output overwrites it
-                          // (the residual of the next layer's attention block is re-read from here)
+  const u32x4 *XIN;       // tile image over the B*N token rows: this step's assembled input (patched in one row per
+                          // episode between steps, not re-assembled)
+  u32x4 *X0;              // scratch tile image: each layer's output (the residual of the next layer's attention block)
   const unsigned *img;    // packed weights: L layer images, then the head image (pack_kernel)
   int L, F;
   float *logits;          // [B*N] acquisition logits
@@ -263,7 +264,8 @@ __device__ __forceinline__ void attention_tiles(bf16x8 (&qa)[H][SNT], const bf16
 // Address of the first piece of token row `row` in a tile image, formed at the point of use from a 32-bit piece
 // index the optimiser cannot see through (hoisted out of the layer loop, the 64-bit addresses of all tiles and
 // k-steps end up in scratch, and every reload serialises the loads behind it).
-__device__ __forceinline__ u32x4 *tile_row(u32x4 *img, long row, int g) {
+template <typename T>
+__device__ __forceinline__ T *tile_row(T *img, long row, int g) {
   unsigned pc = (unsigned)piece(row, 0, g);
   asm volatile("" : "+v"(pc));
   return img + pc;
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
   bf16x8 xb[SNT][NKS];
 #pragma unroll
   for (int ct = 0; ct < SNT; ++ct) {
-    const u32x4 *xr = tile_row(a.X0, ep + min(row0 + 16 * ct, G.N - 1), g);
+    const u32x4 *xr = tile_row(a.XIN, ep + min(row0 + 16 * ct, G.N - 1), g);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) xb[ct][ks] = __builtin_bit_cast(bf16x8, xr[ks * 64]);
   }
@@ -535,14 +537,14 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
     {
       bf16x8 res[2][NKS];                             // the residual rows of the next tile are in flight during a tile's LN
       {
-        const u32x4 *xr = tile_row(a.X0, ep + min(row0, G.N - 1), g);
+        const u32x4 *xr = tile_row(l > 0 ? a.X0 : a.XIN, ep + min(row0, G.N - 1), g);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) res[0][ks] = __builtin_bit_cast(bf16x8, xr[ks * 64]);
       }
 #pragma unroll
       for (int ct = 0; ct < SNT; ++ct) {
         if (ct + 1 < SNT) {
-          const u32x4 *xr = tile_row(a.X0, ep + min(row0 + 16 * (ct + 1), G.N - 1), g);
+          const u32x4 *xr = tile_row(l > 0 ? a.X0 : a.XIN, ep + min(row0 + 16 * (ct + 1), G.N - 1), g);
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks) res[(ct + 1) & 1][ks] = __builtin_bit_cast(bf16x8, xr[ks * 64]);
         }
