@@ -33,7 +33,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -72,8 +72,10 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
     const size_t img = (size_t)wide::tile_rows(M) * d / 2;     // one bf16 tile image, in floats
     p.wX = take(img); p.wX1 = take(img); p.wQKV = take(3 * img);
     p.wA = take(img); p.wLog = take(M);
-    p.wImg = take((size_t)m.L * wide::layer_words(m.F) + wide::head_words(m.F));
+    p.wImg = take((size_t)m.L * wide::layer_words(m.F) + wide::head_words(m.F) + (size_t)Cc * wide::gmm_words(m.F));
     p.wZt = take((size_t)B * n_t * d);
+    p.wZimg = take((size_t)wide::tile_rows((long)T * B * n_t) * d / 2);     // bf16 tile image of all steps' target rows
+    p.wRaw = take((size_t)T * B * n_t * 32);                                 // raw GMM head outputs [row][3 c + j]
   }
   p.total = off;
   return p;
@@ -402,7 +404,7 @@ template <int MODE>
 static int launch_wide_block(const Ctx &c, wide::BlockArgs a) {
   const int F = c.m->F;
   const int nprm = MODE == wide::WB_QKV ? 3 * wide::D : MODE == wide::WB_OUT ? 3 * wide::D
-                   : MODE == wide::WB_FFN ? F + 3 * wide::D : 2 * F + 4;
+                   : MODE == wide::WB_FFN ? F + 3 * wide::D : MODE == wide::WB_GMM ? 4 * F + 4 : 2 * F + 4;
   const size_t smem = (size_t)(2 * wide::CHUNK_W + nprm) * 4;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_block_kernel<MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -663,6 +665,8 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
   }
   pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
+  pa.C = m->C;
+  for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
   unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.wImg));
   pa.out = img;
   hipLaunchKernelGGL(wide::pack_kernel, dim3(1024), dim3(256), 0, c.st, pa);
@@ -693,8 +697,10 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
       wide::StepArgs sa{};
       sa.g = c.g; sa.XIN = X1; sa.X0 = X; sa.img = img; sa.L = m->L; sa.F = F; sa.logits = logits;
       // target-row encodings of every step are kept; their GMM heads run once after the loop (large GEMMs)
-      sa.zt = (r->post_mean || r->post_std || r->post_weight || r->target_ll)
-                  ? c.at(c.pl.Ztg) + (size_t)t * r->B * n_t * wide::D : nullptr;
+      const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
+      sa.zt = nullptr;
+      sa.zimg = want_gmm ? reinterpret_cast<u32x4 *>(c.at(c.pl.wZimg)) : nullptr;
+      sa.zrow0 = (long)t * r->B * n_t;
       const size_t smem = wide::step_lds_bytes(F);
       const bool stamped = getenv("ALINE_WIDE_STAMPS") != nullptr;
       sa.stamps = stamped ? reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps)) : nullptr;
@@ -769,13 +775,25 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     }
   }
   if (fused_step && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
+    // GMM heads of all T * B * n_t target rows: one streamed block kernel per head (hidden layer never leaves the
+    // CU), then the parameter maps + mixture log-likelihood on the 3 C raw outputs per row
     const long per_step = (long)r->B * n_t, total = per_step * r->T;
-    for (long r0 = 0; r0 < total; r0 += (long)kGmmChunkRows) {
-      const long nr = std::min<long>((long)kGmmChunkRows, total - r0);
-      TRY(do_gmm_rows(c, c.at(c.pl.Ztg) + r0 * wide::D, (int)nr, r->post_mean ? r->post_mean + r0 * m->C : nullptr,
-                      r->post_std ? r->post_std + r0 * m->C : nullptr, r->post_weight ? r->post_weight + r0 * m->C : nullptr,
-                      r->target_all, r->target_ll ? r->target_ll + r0 : nullptr, r0, per_step));
+    float *raw = c.at(c.pl.wRaw);
+    const unsigned *gi = img + (long)m->L * lw + wide::head_words(F);
+    for (int k = 0; k < m->C; ++k) {
+      wide::BlockArgs b{};
+      b.M = (int)total; b.F = F; b.X = reinterpret_cast<const u32x4 *>(c.at(c.pl.wZimg)); b.logits = raw;
+      b.out_stride = 32; b.out_off = 3 * k;
+      b.wimg = gi + (long)k * wide::gmm_words(F);
+      b.prm = reinterpret_cast<const float *>(b.wimg + (long)wide::head_chunks(F) * wide::CHUNK_W);
+      TRY(launch_wide_block<wide::WB_GMM>(c, b));
     }
+    wide::GmmRawArgs ga{};
+    ga.raw = raw; ga.raw_stride = 32; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
+    ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
+    ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
+    hipLaunchKernelGGL(wide::gmm_raw_finish_kernel, grid1d((size_t)total), dim3(256), 0, c.st, ga);
+    CHECK_LAUNCH();
   }
   return ALINE_OK;
 }

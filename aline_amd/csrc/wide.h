@@ -19,6 +19,7 @@
 //   wide_block_kernel<WB_FFN>   X  = LN2(X1 + W2 relu(W1 X1 + b1) + b2): the hidden layer never leaves
 //                               the CU (32-unit chunks: 16 fragments of W1, 16 of W2)
 //   wide_block_kernel<WB_ACQ>   acquisition logits = w2 . relu(W1a z + b1a) + b2a
+//   wide_block_kernel<WB_GMM>   one GMM head: raw[0..2] = W2 relu(W1 z + b1) + b2  (same code, 3 outputs per token)
 #pragma once
 #include "common.h"
 #include "kernels.h"
@@ -33,7 +34,7 @@ constexpr int NTHREADS = 512;             // attention kernel
 #endif
 constexpr int NT = WIDE_NT, BTHREADS = NT == 2 ? 512 : 256, BWAVES = BTHREADS / 64;
 constexpr int WTOK = 16 * NT, WG_TOK = BWAVES * WTOK, NST = CHUNK_W / 4 / BTHREADS;
-enum { WB_QKV = 0, WB_OUT = 1, WB_FFN = 2, WB_ACQ = 3 };
+enum { WB_QKV = 0, WB_OUT = 1, WB_FFN = 2, WB_ACQ = 3, WB_GMM = 4 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -54,12 +55,15 @@ __host__ __device__ inline int layer_params(int F) { return 3 * D + D + F + D + 
 __host__ __device__ inline long layer_words(int F) { return (long)layer_chunks(F) * CHUNK_W + layer_params(F); }
 __host__ __device__ inline int head_chunks(int F) { return F / 64; }
 __host__ __device__ inline long head_words(int F) { return (long)head_chunks(F) * CHUNK_W + 2 * F + 4; }   // b1a, w2a, b2a
+__host__ __device__ inline long gmm_words(int F) { return (long)head_chunks(F) * CHUNK_W + 4 * F + 4; }    // b1, w2[3][F], b2[3]
 
 struct PackArgs {
   int L, F;
   const float *in_proj_w[8], *in_proj_b[8], *out_proj_w[8], *out_proj_b[8], *lin1_w[8], *lin1_b[8], *lin2_w[8],
       *lin2_b[8], *n1w[8], *n1b[8], *n2w[8], *n2b[8];
   const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
+  int C;                         // GMM heads packed after the acquisition head (each: F/64 chunks of W1 | b1 | w2[3][F] | b2[3])
+  const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
   unsigned *out;
 };
 
@@ -72,7 +76,7 @@ __device__ __forceinline__ unsigned frag_word(const float *W, int K, int row0, i
 }
 
 __global__ void pack_kernel(PackArgs a) {
-  const long lw = layer_words(a.F), total = a.L * lw + head_words(a.F);
+  const long lw = layer_words(a.F), total = a.L * lw + head_words(a.F) + a.C * gmm_words(a.F);
   const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;   // softmax runs in exp2
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     unsigned v = 0;
@@ -104,6 +108,20 @@ __global__ void pack_kernel(PackArgs a) {
           f = q < D ? a.lin2_b[l][q] : q < 2 * D ? a.n1w[l][q - D] : q < 3 * D ? a.n1b[l][q - 2 * D]
             : q < 4 * D ? a.n2w[l][q - 3 * D] : a.n2b[l][q - 4 * D];
         }
+        v = __float_as_uint(f);
+      }
+    } else if (i >= a.L * lw + head_words(a.F)) {
+      const long og = i - a.L * lw - head_words(a.F);
+      const int c = og / gmm_words(a.F);
+      const long o = og % gmm_words(a.F);
+      const long nfw = (long)head_chunks(a.F) * CHUNK_W;
+      if (o < nfw) {                    // same fragment order as the acquisition head
+        const int chunk = o / CHUNK_W, fid = (o % CHUNK_W) / FRAG_W, e = o % FRAG_W, lane = e >> 2, w = e & 3;
+        const int grp = 2 * chunk + fid / 16, f16 = fid % 16;
+        v = frag_word(a.gmm_w1[c], D, 32 * grp + 16 * (f16 & 1), f16 >> 1, lane, w, 1.f);
+      } else {
+        const int p = o - nfw;
+        const float f = p < a.F ? a.gmm_b1[c][p] : p < 4 * a.F ? a.gmm_w2[c][p - a.F] : p < 4 * a.F + 3 ? a.gmm_b2[c][p - 4 * a.F] : 0.f;
         v = __float_as_uint(f);
       }
     } else {
@@ -194,7 +212,8 @@ struct BlockArgs {
   const u32x4 *X;                // tile image of the input of the matmul chain
   const u32x4 *Xres;             // tile image of the residual (WB_OUT), else unused
   u32x4 *Y;                      // output tile image (WB_QKV: three images Q | K | V, tile_rows(M) * 32 pieces apart)
-  float *logits;                 // [M] (WB_ACQ)
+  float *logits;                 // WB_ACQ: [M]; WB_GMM: raw[row * out_stride + out_off + j], j < 3
+  int out_stride, out_off;
   const unsigned *wimg;          // first chunk of this block's weights
   const float *prm;              // this layer's (or the head's) fp32 parameter block
   int M, F;
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
   for (int ct = 0; ct < NT; ++ct) { row[ct] = min(base + 16 * ct + tok, (long)a.M - 1); ok[ct] = base + 16 * ct + tok < a.M; }
 
   // parameters of this block into LDS
-  const int nprm = MODE == WB_QKV ? 3 * D : MODE == WB_OUT ? 3 * D : MODE == WB_FFN ? a.F + 3 * D : 2 * a.F + 4;
+  const int nprm = MODE == WB_QKV ? 3 * D : MODE == WB_OUT ? 3 * D : MODE == WB_FFN ? a.F + 3 * D : MODE == WB_GMM ? 4 * a.F + 4 : 2 * a.F + 4;
   for (int i = tid; i < nprm; i += BTHREADS) {
     float v;
     if (MODE == WB_QKV) v = a.prm[i];                                                  // bq | bk | bv
@@ -245,17 +264,20 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) load_xfrags(a.X, row[ct], g, xb[ct]);
 
-  const int nchunk = MODE == WB_QKV ? 12 : MODE == WB_OUT ? 4 : MODE == WB_FFN ? a.F / 32 : a.F / 64;
+  const int nchunk = MODE == WB_QKV ? 12 : MODE == WB_OUT ? 4 : MODE == WB_FFN ? a.F / 32 : a.F / 64;   // (WB_ACQ, WB_GMM: 64 hidden units per chunk)
   const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wimg);
   u32x4 st[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) st[i] = wsrc[tid + i * BTHREADS];
 
   f32x4 y[NMT][NT];
-  float plog[NT];
+  constexpr int NOUT = MODE == WB_GMM ? 3 : 1;
+  float plog[NT][NOUT];
 #pragma unroll
-  for (int ct = 0; ct < NT; ++ct) plog[ct] = 0.f;
-  if (MODE != WB_ACQ) {
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) plog[ct][j] = 0.f;
+  if (MODE != WB_ACQ && MODE != WB_GMM) {
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) WMFMA(y[mt][ct], A, hb[ct]);
       }
-    } else {   // WB_ACQ: two groups of 32 hidden units per chunk
+    } else {   // WB_ACQ / WB_GMM: two groups of 32 hidden units per chunk
 #pragma unroll
       for (int grp = 0; grp < 2; ++grp) {
         const int hbase = 64 * c + 32 * grp;
@@ -344,25 +366,33 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
 #pragma unroll
           for (int ct = 0; ct < NT; ++ct) { WMFMA(h[0][ct], A0, xb[ct][ks]); WMFMA(h[1][ct], A1, xb[ct][ks]); }
         }
-        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(ps + a.F + hbase + 4 * g);
-        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(ps + a.F + hbase + 16 + 4 * g);
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
+        for (int j = 0; j < NOUT; ++j) {
+          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(ps + (1 + j) * a.F + hbase + 4 * g);
+          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(ps + (1 + j) * a.F + hbase + 16 + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            plog[ct] = fmaf(relu_nn(h[0][ct][r]), w0[r], plog[ct]);
-            plog[ct] = fmaf(relu_nn(h[1][ct][r]), w1[r], plog[ct]);
-          }
+          for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              plog[ct][j] = fmaf(relu_nn(h[0][ct][r]), w0[r], plog[ct][j]);
+              plog[ct][j] = fmaf(relu_nn(h[1][ct][r]), w1[r], plog[ct][j]);
+            }
+        }
       }
     }
   }
 
-  if (MODE == WB_ACQ) {
+  if (MODE == WB_ACQ || MODE == WB_GMM) {
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-      const float v = group_sum4(plog[ct]) + ps[2 * a.F];
-      if (g == 0 && ok[ct]) a.logits[row[ct]] = v;
-    }
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const float v = group_sum4(plog[ct][j]) + ps[(1 + NOUT) * a.F + j];
+        if (g == 0 && ok[ct]) {
+          if (MODE == WB_ACQ) a.logits[row[ct]] = v;
+          else a.logits[row[ct] * a.out_stride + a.out_off + j] = v;
+        }
+      }
     return;
   }
   if (MODE == WB_QKV) return;
@@ -406,6 +436,40 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
       }
       if (ok[ct]) a.Y[piece(row[ct], ks, g)] = __builtin_bit_cast(u32x4, acc_to_frag(o[0], o[1]));
     }
+  }
+}
+
+// GMM parameter maps + mixture log-likelihood from the raw head outputs raw[row][3 c + j] (model/head.py:152-186,
+// 251-266; utils/eval.py:200-207): mean_c = raw[c][0], std_c = softplus(raw[c][1]) + std_min, weight = softmax_c(raw[c][2])
+struct GmmRawArgs {
+  const float *raw; int raw_stride; long rows; int C; float std_min;
+  float *mean, *sd, *wgt;                        // [rows, C] or null
+  const float *value; long value_mod;            // value[row % value_mod] or null
+  float *ll;                                     // [rows] or null
+};
+__global__ void gmm_raw_finish_kernel(GmmRawArgs a) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.rows) return;
+  const float *r = a.raw + row * a.raw_stride;
+  float mxw = -INFINITY;
+  for (int c = 0; c < a.C; ++c) mxw = fmaxf(mxw, r[3 * c + 2]);
+  float sw = 0.f;
+  for (int c = 0; c < a.C; ++c) sw += __expf(r[3 * c + 2] - mxw);
+  const float v = (a.ll && a.value) ? a.value[row % a.value_mod] : 0.f;
+  float mx2 = -INFINITY, lps[16];
+  for (int c = 0; c < a.C; ++c) {
+    const float mean = r[3 * c], sd = softplus_f(r[3 * c + 1]) + a.std_min, w = __expf(r[3 * c + 2] - mxw) / sw;
+    if (a.mean) a.mean[row * a.C + c] = mean;
+    if (a.sd) a.sd[row * a.C + c] = sd;
+    if (a.wgt) a.wgt[row * a.C + c] = w;
+    const float zz = (v - mean) / sd;
+    lps[c] = -0.5f * zz * zz - logf(sd) - 0.91893853320467274178f + logf(w);
+    mx2 = fmaxf(mx2, lps[c]);
+  }
+  if (a.ll && a.value) {
+    float se = 0.f;
+    for (int c = 0; c < a.C; ++c) se += __expf(lps[c] - mx2);
+    a.ll[row] = mx2 + logf(se);
   }
 }
 

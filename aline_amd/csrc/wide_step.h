@@ -32,6 +32,8 @@ struct StepArgs {
   int L, F;
   float *logits;          // [B*N] acquisition logits
   float *zt;              // [B, n_t, 256] fp32 encodings of the target rows (last layer), or null
+  u32x4 *zimg; long zrow0;   // tile image of the same rows in bf16 (row zrow0 + b * n_t + j), or null: the input of the
+                          // post-loop GMM head kernels
   unsigned long long *stamps;   // diagnostic instantiation only: per-phase s_memtime sums [4 waves x 16]
 };
 
@@ -658,6 +660,11 @@ __global__ __launch_bounds__(ST) void wide_step_kernel(StepArgs a) {
         asm volatile("" : "+v"(po));
         const float *pt = prm + po;
         ln_tile<true, true>(yt, res, pt + 4 * D + F, pt + 4 * D + F + 3 * D, pt + 4 * D + F + 4 * D, g, zrow, xb[ct]);
+        if (last && a.zimg && r >= G.P && r < G.N) {
+          u32x4 *zo = tile_row(a.zimg, a.zrow0 + (long)b * n_t + (r - G.P), g);
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) zo[ks * 64] = __builtin_bit_cast(u32x4, xb[ct][ks]);
+        }
         if (!last && r < G.N) {                       // next layer's residual
           u32x4 *xo = tile_row(a.X0, ep + r, g);
 #pragma unroll
