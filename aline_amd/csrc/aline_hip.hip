@@ -72,7 +72,8 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
     const size_t img = (size_t)wide::tile_rows(M) * d / 2;     // one bf16 tile image, in floats
     p.wX = take(img); p.wX1 = take(img); p.wQKV = take(3 * img);
     p.wA = take(img); p.wLog = take(M);
-    p.wImg = take((size_t)m.L * wide::layer_words(m.F) + wide::head_words(m.F) + (size_t)Cc * wide::gmm_words(m.F));
+    p.wImg = take((size_t)m.L * wide::layer_words(m.F) + wide::head_words(m.F) + (size_t)Cc * wide::gmm_words(m.F) +
+                  2 * (size_t)wide::emb_words(m.F));
     p.wZt = take((size_t)B * n_t * d);
     p.wZimg = take((size_t)wide::tile_rows((long)T * B * n_t) * d / 2);     // bf16 tile image of all steps' target rows
     p.wRaw = take((size_t)T * B * n_t * 32);                                 // raw GMM head outputs [row][3 c + j]
@@ -651,8 +652,6 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
   const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, M = r->B * N, F = m->F;
   hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B, r->P, r->n_ctx0);
   CHECK_LAUNCH();
-  Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
-  TRY(do_embed_points(c, xs, r->point_y, r->P));
   // weights -> streamed bf16 fragment images (once per rollout)
   wide::PackArgs pa{};
   pa.L = m->L; pa.F = F;
@@ -665,12 +664,31 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
   }
   pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
-  pa.C = m->C;
+  pa.C = m->C; pa.emb_w2[0] = m->x_w2; pa.emb_w2[1] = m->y_w2;
   for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
   unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.wImg));
   pa.out = img;
   hipLaunchKernelGGL(wide::pack_kernel, dim3(1024), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
+  {   // point embeddings (step-invariant): Ex over the point (+ target-data) rows, Ey over the point rows
+    if (m->dim_x > 8 || m->dim_y > 8) return ALINE_EUNSUPPORTED;
+    const unsigned *ei = img + (long)m->L * wide::layer_words(F) + wide::head_words(F) + (long)m->C * wide::gmm_words(F);
+    wide::EmbedArgs ea{};
+    ea.B = r->B; ea.F = F; ea.out = c.at(c.pl.Ex);
+    ea.src = Src3{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}}; ea.rows_per_ep = r->P + r->n_target_data;
+    ea.K = m->dim_x; ea.w1 = m->x_w1; ea.b1 = m->x_b1; ea.b2 = m->x_b2; ea.wimg = ei;
+    for (int pass = 0; pass < 2; ++pass) {
+      const size_t smem = (size_t)(2 * wide::CHUNK_W + F * ea.K + F + wide::D) * 4;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_embed_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      const long rows = (long)ea.B * ea.rows_per_ep;
+      hipLaunchKernelGGL(wide::wide_embed_kernel, dim3((unsigned)((rows + wide::WG_TOK - 1) / wide::WG_TOK)), dim3(wide::BTHREADS),
+                         smem, c.st, ea);
+      CHECK_LAUNCH();
+      ea.src = Src3{{r->point_y, nullptr, nullptr}, {r->P, 0, 0}}; ea.rows_per_ep = r->P; ea.out = c.at(c.pl.Ey);
+      ea.K = m->dim_y; ea.w1 = m->y_w1; ea.b1 = m->y_b1; ea.b2 = m->y_b2; ea.wimg = ei + wide::emb_words(F);
+    }
+  }
   using wide::u32x4;
   u32x4 *X = reinterpret_cast<u32x4 *>(c.at(c.pl.wX)), *X1 = reinterpret_cast<u32x4 *>(c.at(c.pl.wX1));
   u32x4 *QKV = reinterpret_cast<u32x4 *>(c.at(c.pl.wQKV)), *A = reinterpret_cast<u32x4 *>(c.at(c.pl.wA));

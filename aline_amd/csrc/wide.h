@@ -56,6 +56,7 @@ __host__ __device__ inline long layer_words(int F) { return (long)layer_chunks(F
 __host__ __device__ inline int head_chunks(int F) { return F / 64; }
 __host__ __device__ inline long head_words(int F) { return (long)head_chunks(F) * CHUNK_W + 2 * F + 4; }   // b1a, w2a, b2a
 __host__ __device__ inline long gmm_words(int F) { return (long)head_chunks(F) * CHUNK_W + 4 * F + 4; }    // b1, w2[3][F], b2[3]
+__host__ __device__ inline long emb_words(int F) { return (long)head_chunks(F) * CHUNK_W; }               // W2 [256, F] of a point embedder
 
 struct PackArgs {
   int L, F;
@@ -64,6 +65,7 @@ struct PackArgs {
   const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
   int C;                         // GMM heads packed after the acquisition head (each: F/64 chunks of W1 | b1 | w2[3][F] | b2[3])
   const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
+  const float *emb_w2[2];        // second layers of the x / y point embedders, packed last (chunk c: hidden groups 2c, 2c+1 x 16 output tiles)
   unsigned *out;
 };
 
@@ -76,7 +78,7 @@ __device__ __forceinline__ unsigned frag_word(const float *W, int K, int row0, i
 }
 
 __global__ void pack_kernel(PackArgs a) {
-  const long lw = layer_words(a.F), total = a.L * lw + head_words(a.F) + a.C * gmm_words(a.F);
+  const long lw = layer_words(a.F), total = a.L * lw + head_words(a.F) + a.C * gmm_words(a.F) + 2 * emb_words(a.F);
   const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;   // softmax runs in exp2
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     unsigned v = 0;
@@ -110,6 +112,12 @@ __global__ void pack_kernel(PackArgs a) {
         }
         v = __float_as_uint(f);
       }
+    } else if (i >= a.L * lw + head_words(a.F) + a.C * gmm_words(a.F)) {
+      const long oe = i - (a.L * lw + head_words(a.F) + a.C * gmm_words(a.F));
+      const int which = oe / emb_words(a.F);
+      const long o = oe % emb_words(a.F);
+      const int chunk = o / CHUNK_W, fid = (o % CHUNK_W) / FRAG_W, e = o % FRAG_W, lane = e >> 2, w = e & 3;
+      v = frag_word(a.emb_w2[which], a.F, 16 * (fid % 16), 2 * chunk + fid / 16, lane, w, 1.f);   // (mt, k-step = hidden group)
     } else if (i >= a.L * lw + head_words(a.F)) {
       const long og = i - a.L * lw - head_words(a.F);
       const int c = og / gmm_words(a.F);
@@ -437,6 +445,93 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
       if (ok[ct]) a.Y[piece(row[ct], ks, g)] = __builtin_bit_cast(u32x4, acc_to_frag(o[0], o[1]));
     }
   }
+}
+
+// ---- point embedder  E[row] = W2 relu(W1 x[row] + b1) + b2  (model/embedder.py:47-57), d = 256 --------------
+// K = dim_x / dim_y <= 8 inputs: the hidden units are FMA work done directly in the B-fragment layout (lane =
+// token, 8 hidden units per lane and 32-unit group), the second layer runs on the streamed W2 fragments.  The
+// [rows, F] hidden activations of the generic path (0.8 GB at the headline shape) never exist.  fp32 rows out.
+struct EmbedArgs {
+  Src3 src; int rows_per_ep, B, K, F;
+  const float *w1, *b1, *b2;                     // [F, K], [F], [256]
+  const unsigned *wimg;                          // packed W2
+  float *out;                                    // [B * rows_per_ep, 256]
+};
+__global__ __launch_bounds__(BTHREADS) void wide_embed_kernel(EmbedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds[];      // [2][CHUNK_W] | w1 [F * K] | b1 [F] | b2 [256]
+  unsigned *buf0 = lds, *buf1 = lds + CHUNK_W;
+  float *w1s = reinterpret_cast<float *>(lds + 2 * CHUNK_W), *b1s = w1s + a.F * a.K, *b2s = b1s + a.F;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  const long M = (long)a.B * a.rows_per_ep, base = (long)blockIdx.x * WG_TOK + wave * WTOK;
+  for (int i = tid; i < a.F * a.K; i += BTHREADS) w1s[i] = a.w1[i];
+  for (int i = tid; i < a.F; i += BTHREADS) b1s[i] = a.b1[i];
+  for (int i = tid; i < D; i += BTHREADS) b2s[i] = a.b2[i];
+  float xv[NT][8];
+  long row[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    row[ct] = base + 16 * ct + tok;
+    const long r = min(row[ct], M - 1);
+    const int b = r / a.rows_per_ep, p = r % a.rows_per_ep;
+    const float *x;
+    if (p < a.src.n[0]) x = a.src.p[0] + ((long)b * a.src.n[0] + p) * a.K;
+    else if (p < a.src.n[0] + a.src.n[1]) x = a.src.p[1] + ((long)b * a.src.n[1] + (p - a.src.n[0])) * a.K;
+    else x = a.src.p[2] + ((long)b * a.src.n[2] + (p - a.src.n[0] - a.src.n[1])) * a.K;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[ct][k] = k < a.K ? x[k] : 0.f;
+  }
+  const int nchunk = a.F / 64;
+  const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(a.wimg);
+  u32x4 st[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) st[i] = wsrc[tid + i * BTHREADS];
+  f32x4 y[NMT][NT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) y[mt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < nchunk; ++c) {
+    unsigned *buf = (c & 1) ? buf1 : buf0;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) reinterpret_cast<u32x4 *>(buf)[tid + i * BTHREADS] = st[i];
+    __syncthreads();
+    if (c + 1 < nchunk) {
+#pragma unroll
+      for (int i = 0; i < NST; ++i) st[i] = wsrc[(long)(c + 1) * (CHUNK_W / 4) + tid + i * BTHREADS];
+    }
+    const bf16x8 *fr = reinterpret_cast<const bf16x8 *>(buf) + lane;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      const int hbase = 64 * c + 32 * grp;
+      bf16x8 hb[NT];                                 // hidden units hbase + 4 g + (0..3) and hbase + 16 + 4 g + (0..3)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        float h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int u = hbase + 16 * (j >> 2) + 4 * g + (j & 3);
+          float acc = b1s[u];
+          for (int k = 0; k < a.K; ++k) acc = fmaf(xv[ct][k], w1s[u * a.K + k], acc);
+          h[j] = relu_nn(acc);
+        }
+        const u32x4 v = {pack_bf16(h[0], h[1]), pack_bf16(h[2], h[3]), pack_bf16(h[4], h[5]), pack_bf16(h[6], h[7])};
+        hb[ct] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        const bf16x8 A = fr[(grp * 16 + mt) * 64];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) WMFMA(y[mt][ct], A, hb[ct]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+    if (row[ct] < M) {
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+        *reinterpret_cast<f32x4 *>(a.out + row[ct] * D + 16 * mt + 4 * g) = y[mt][ct] + *reinterpret_cast<const f32x4 *>(b2s + 16 * mt + 4 * g);
+    }
 }
 
 // GMM parameter maps + mixture log-likelihood from the raw head outputs raw[row][3 c + j] (model/head.py:152-186,
