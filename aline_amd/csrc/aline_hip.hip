@@ -186,6 +186,21 @@ int launch_attention(const Ctx &c, const float *qkv, float *out, int max_keys) {
   return ALINE_OK;
 }
 
+// out = LayerNorm(a + b) * w + bias, optionally saving the pre-norm sum (narrow rows: d = 32 / 64)
+static int launch_add_layernorm(hipStream_t st, const float *a, const float *b, const float *w, const float *bias,
+                                float *out, long M, int d, float *usave) {
+  if (d == 32 || d == 64) {
+    const int rpb = d == 32 ? 32 : 16;
+    const unsigned grid = (unsigned)std::min<long>((M + rpb - 1) / rpb, 256 * 32);
+    if (d == 32) hipLaunchKernelGGL(add_layernorm_narrow_kernel<8>, dim3(grid), dim3(256), 0, st, a, b, w, bias, out, M, usave);
+    else hipLaunchKernelGGL(add_layernorm_narrow_kernel<16>, dim3(grid), dim3(256), 0, st, a, b, w, bias, out, M, usave);
+  } else {
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, a, b, w, bias, out, M, d, usave);
+  }
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
 // Encoder.forward: L post-norm layers (model/encoder.py:128-141)
 int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
   const aline_model &m = *c.m;
@@ -210,9 +225,7 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
     TRY(launch_gemm(m.precision, gemm_args(A, d, m.out_proj_w[l], m.out_proj_b[l], d, Tm, d, M, d, d,
                                            false), 1, c.st));
     CHECK_LAUNCH();
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, c.st, cur, Tm,
-                       m.norm1_w[l], m.norm1_b[l], X1, (long)M, d);
-    CHECK_LAUNCH();
+    TRY(launch_add_layernorm(c.st, cur, Tm, m.norm1_w[l], m.norm1_b[l], X1, (long)M, d, nullptr));
     TRY(launch_gemm(m.precision, gemm_args(X1, d, m.lin1_w[l], m.lin1_b[l], d, Hid, F, M, F, d, true),
                     1, c.st));
     CHECK_LAUNCH();
@@ -220,9 +233,7 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
                     1, c.st));
     CHECK_LAUNCH();
     float *dst = (l == m.L - 1 && x_out) ? x_out : X;
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, c.st, X1, Tm,
-                       m.norm2_w[l], m.norm2_b[l], dst, (long)M, d);
-    CHECK_LAUNCH();
+    TRY(launch_add_layernorm(c.st, X1, Tm, m.norm2_w[l], m.norm2_b[l], dst, (long)M, d, nullptr));
     cur = dst;
   }
   return ALINE_OK;
@@ -642,6 +653,7 @@ static bool wide_eligible(const aline_model &m, const aline_rollout &r) {
   if (getenv("ALINE_DISABLE_WIDE")) return false;
   if (m.precision != ALINE_PREC_BF16 || m.d != wide::D || m.H != wide::H || m.F % 64 || m.time_token) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > wide::WNK) return false;
+  if (m.dim_x > 8 || m.dim_y > 8) return false;      // wide_embed_kernel keeps one input row in 8 registers
   return true;
 }
 
@@ -671,7 +683,6 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
   hipLaunchKernelGGL(wide::pack_kernel, dim3(1024), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
   {   // point embeddings (step-invariant): Ex over the point (+ target-data) rows, Ey over the point rows
-    if (m->dim_x > 8 || m->dim_y > 8) return ALINE_EUNSUPPORTED;
     const unsigned *ei = img + (long)m->L * wide::layer_words(F) + wide::head_words(F) + (long)m->C * wide::gmm_words(F);
     wide::EmbedArgs ea{};
     ea.B = r->B; ea.F = F; ea.out = c.at(c.pl.Ex);
@@ -958,11 +969,12 @@ int transpose_to(const BCtx &c, const float *W, int rows, int cols, float *dst) 
 
 // dX[M, K] (+)= dY[M, N] . W[N, K]   (W in PyTorch layout [N, K]); Wt scratch holds W^T [K, N]
 int gemm_dx(const BCtx &c, const float *dY, int ldy, const float *W, int N, int K, float *dX, int ldx, int M,
-            bool accum) {
+            bool accum, const float *relu_of = nullptr) {
   float *Wt = c.at(c.pl.Wt);
   TRY(transpose_to(c, W, N, K, Wt));
   GemmArgs a = gemm_args(dY, ldy, Wt, nullptr, N, dX, ldx, M, K, N, false);
   a.accum = accum ? 1 : 0;
+  a.mask = relu_of; a.ldmask = ldx;      // gradient through the ReLU whose output is `relu_of` [M, K]
   TRY(launch_gemm(ALINE_PREC_F32, a, 1, c.st));
   CHECK_LAUNCH();
   return ALINE_OK;
@@ -977,14 +989,26 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
   a.X = X; a.ldx = ldx; a.Rx = Rx; a.Gx = Gx; a.offx = offx;
   a.dW = dW; a.ldw = K; a.db = db; a.M = M; a.N = N; a.K = K;
   a.mchunk = 4096;
-  dim3 grid((unsigned)((M + a.mchunk - 1) / a.mchunk), N / 32, K / 32);
-  hipLaunchKernelGGL(gemm_tn_atomic_kernel, grid, dim3(256), 0, c.st, a);
+  const unsigned gx = (unsigned)((M + a.mchunk - 1) / a.mchunk);
+  if (N % 128 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3(gx, N / 128, K / 32), dim3(256), 0, c.st, a);
+  else if (N % 96 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<6>, dim3(gx, N / 96, K / 32), dim3(256), 0, c.st, a);
+  else if (N % 64 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<4>, dim3(gx, N / 64, K / 32), dim3(256), 0, c.st, a);
+  else hipLaunchKernelGGL(gemm_tn_block_kernel<2>, dim3(gx, N / 32, K / 32), dim3(256), 0, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
 
 int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float *dU, float *dw, float *db,
            long rows) {
+  const int d = c.m->d;
+  if (d == 32 || d == 64) {
+    const int rows_per_pass = d == 32 ? 32 : 16;
+    const unsigned grid = (unsigned)std::min<long>((rows + rows_per_pass - 1) / rows_per_pass, 256 * 8);
+    if (d == 32) hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<8>, dim3(grid), dim3(256), 0, c.st, dY, U, w, dU, dw, db, rows);
+    else hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<16>, dim3(grid), dim3(256), 0, c.st, dY, U, w, dU, dw, db, rows);
+    CHECK_LAUNCH();
+    return ALINE_OK;
+  }
   const int rpb = 64;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
                      (size_t)2 * c.m->d * sizeof(float), c.st, dY, U, w, dU, dw, db, rows, c.m->d, rpb);
@@ -1090,14 +1114,10 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
         default: return ALINE_EUNSUPPORTED;
       }
       TRY(launch_gemm(0, gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));
-      hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c.st, Xs(l), dTmp,
-                         m->norm1_w[l], m->norm1_b[l], X1l(l), M, d, U1l(l));
-      CHECK_LAUNCH();
+      TRY(launch_add_layernorm(c.st, Xs(l), dTmp, m->norm1_w[l], m->norm1_b[l], X1l(l), M, d, U1l(l)));
       TRY(launch_gemm(0, gemm_args(X1l(l), d, m->lin1_w[l], m->lin1_b[l], d, Hidl(l), F, (int)M, F, d, true), 1, c.st));
       TRY(launch_gemm(0, gemm_args(Hidl(l), F, m->lin2_w[l], m->lin2_b[l], F, dTmp, d, (int)M, d, F, false), 1, c.st));
-      hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, c.st, X1l(l), dTmp,
-                         m->norm2_w[l], m->norm2_b[l], Xs(l + 1), M, d, U2l(l));
-      CHECK_LAUNCH();
+      TRY(launch_add_layernorm(c.st, X1l(l), dTmp, m->norm2_w[l], m->norm2_b[l], Xs(l + 1), M, d, U2l(l)));
     }
     const float *Z = Xs(L);
     float *HidA = c.at(c.pl.HidA), *HidG = c.at(c.pl.HidG);
@@ -1165,9 +1185,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       TRY(ln_bwd(c, dX, U2l(l), m->norm2_w[l], dTmp, gr->norm2_w[l], gr->norm2_b[l], M));   // dTmp = dU2
       // FFN
       TRY(gemm_dw(c, dTmp, d, Hidl(l), F, gr->lin2_w[l], gr->lin2_b[l], M, d, F));
-      TRY(gemm_dx(c, dTmp, d, m->lin2_w[l], d, F, dHid, F, (int)M, false));
-      hipLaunchKernelGGL(relu_mask_kernel, grid1d((size_t)M * F), dim3(256), 0, c.st, dHid, Hidl(l), M * F);
-      CHECK_LAUNCH();
+      TRY(gemm_dx(c, dTmp, d, m->lin2_w[l], d, F, dHid, F, (int)M, false, Hidl(l)));
       TRY(gemm_dw(c, dHid, F, X1l(l), d, gr->lin1_w[l], gr->lin1_b[l], M, F, d));
       TRY(gemm_dx(c, dHid, F, m->lin1_w[l], F, d, dTmp, d, (int)M, true));                      // dTmp = dX1
       // LN1
@@ -1199,14 +1217,12 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
   {
     float *dEx = c.at(c.pl.dEx), *dEy = c.at(c.pl.dEy), *dH = c.at(c.pl.dHid);
     TRY(gemm_dw(c, dEx, d, EHx, F, gr->x_w2, gr->x_b2, rows_x, d, F));
-    TRY(gemm_dx(c, dEx, d, m->x_w2, d, F, dH, F, rows_x, false));
-    hipLaunchKernelGGL(relu_mask_kernel, grid1d((size_t)rows_x * F), dim3(256), 0, c.st, dH, EHx, (long)rows_x * F);
+    TRY(gemm_dx(c, dEx, d, m->x_w2, d, F, dH, F, rows_x, false, EHx));
     hipLaunchKernelGGL(embed_first_bwd_kernel, dim3((rows_x + 255) / 256), dim3(128), 0, c.st, xs, P + n_td, B,
                        m->dim_x, F, dH, gr->x_w1, gr->x_b1, 256);
     CHECK_LAUNCH();
     TRY(gemm_dw(c, dEy, d, EHy, F, gr->y_w2, gr->y_b2, rows_y, d, F));
-    TRY(gemm_dx(c, dEy, d, m->y_w2, d, F, dH, F, rows_y, false));
-    hipLaunchKernelGGL(relu_mask_kernel, grid1d((size_t)rows_y * F), dim3(256), 0, c.st, dH, EHy, (long)rows_y * F);
+    TRY(gemm_dx(c, dEy, d, m->y_w2, d, F, dH, F, rows_y, false, EHy));
     hipLaunchKernelGGL(embed_first_bwd_kernel, dim3((rows_y + 255) / 256), dim3(128), 0, c.st, ys, P, B, m->dim_y,
                        F, dH, gr->y_w1, gr->y_b1, 256);
     CHECK_LAUNCH();

@@ -75,6 +75,73 @@ __global__ __launch_bounds__(256) void gemm_tn_atomic_kernel(GemmTnArgs a) {
   }
 }
 
+// Same product with one workgroup owning a [16 TN x 32] block of dW for its row chunk (TN = 8, 6, 4, 2 by the
+// divisibility of N): a row of dY is read once per 32 columns of X instead of once per 32 x 32 tile, 2 TN MFMAs
+// per (TN + 2) loads, four row groups in flight per wave.
+template <int TN>
+__global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
+  constexpr int BN = 16 * TN;
+  __shared__ float red[BN][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.y * BN, k0 = blockIdx.z * 32;
+  const long m_lo = (long)blockIdx.x * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
+  for (int e = threadIdx.x; e < BN * 33; e += 256) (&red[0][0])[e] = 0.f;
+  f32x4 acc[TN][2];
+  float bsum[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bsum[i] = 0.f;
+  }
+  constexpr int UN = 4;                  // row groups (of 4 rows) in flight per wave
+  for (long mb = m_lo + 4 * UN * wave; mb < m_hi; mb += 16 * UN) {
+    float av[UN][TN], bv[UN][2];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long m = mb + 4 * u + fg;
+      const bool ok = m < m_hi;
+      const long mm = ok ? m : m_lo;
+      const float *py = a.dY + ((mm / a.Ry) * a.Gy + a.offy + (mm % a.Ry)) * a.ldy + n0 + fr;
+      const float *px = a.X + ((mm / a.Rx) * a.Gx + a.offx + (mm % a.Rx)) * a.ldx + k0 + fr;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) av[u][i] = ok ? py[16 * i] : 0.f;
+      bv[u][0] = ok ? px[0] : 0.f;
+      bv[u][1] = ok ? px[16] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        bsum[i] += av[u][i];
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][1], acc[i][1], 0, 0, 0);
+      }
+  }
+  __syncthreads();
+  // acc[i][j][r]: n = 16 i + 4 fg + r, k = 16 j + fr
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[16 * i + 4 * fg + r][16 * j + fr], acc[i][j][r]);
+  __syncthreads();
+  for (int e = threadIdx.x; e < BN * 32; e += 256) {
+    const int n = e >> 5, k = e & 31;
+    atomicAdd(a.dW + (long)(n0 + n) * a.ldw + k0 + k, red[n][k]);
+  }
+  if (a.db && blockIdx.z == 0) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      float s = bsum[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (fg == 0) atomicAdd(a.db + n0 + 16 * i + fr, s);
+    }
+  }
+}
+
 // LayerNorm backward (post-norm block): y = LN(u) * w + b.
 //   dU = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dY * w;  dw += dY * xhat;  db += dY
 // One wave per row; per-workgroup partial dw/db through LDS, then one atomic per feature.
@@ -120,6 +187,45 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
   for (int c = lane; c < d; c += 64, ++n) { atomicAdd(&sdw[c], pdw[n]); atomicAdd(&sdb[c], pdb[n]); }
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += 256) { atomicAdd(dw + c, sdw[c]); atomicAdd(db + c, sdb[c]); }
+}
+
+// Narrow-row variant of the above (d = 4 * LPR, see add_layernorm_narrow_kernel): 64 / LPR rows per wave step,
+// dw / db partials in registers per lane (4 features), reduced over the workgroup's row lanes through LDS.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const float *__restrict__ dY,
+                                                                   const float *__restrict__ U,
+                                                                   const float *__restrict__ w, float *__restrict__ dU,
+                                                                   float *dw, float *db, long rows) {
+  constexpr int d = 4 * LPR, RPB = 256 / LPR;
+  __shared__ float red[2][RPB][d + 4];
+  const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const float4 wv = *reinterpret_cast<const float4 *>(w + 4 * sub);
+  float4 pdw = {0.f, 0.f, 0.f, 0.f}, pdb = {0.f, 0.f, 0.f, 0.f};
+  for (long row = (long)blockIdx.x * RPB + rl; row < rows; row += (long)gridDim.x * RPB) {
+    float4 u = *reinterpret_cast<const float4 *>(U + row * d + 4 * sub);
+    const float4 gy = *reinterpret_cast<const float4 *>(dY + row * d + 4 * sub);
+    const float mean = row_sum<LPR>(u.x + u.y + u.z + u.w) * (1.f / d);
+    u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
+    const float rstd = rsqrtf(row_sum<LPR>(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.f / d) + 1e-5f);
+    const float4 xh = {u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd};
+    const float4 g = {gy.x * wv.x, gy.y * wv.y, gy.z * wv.z, gy.w * wv.w};
+    pdw.x += gy.x * xh.x; pdw.y += gy.y * xh.y; pdw.z += gy.z * xh.z; pdw.w += gy.w * xh.w;
+    pdb.x += gy.x; pdb.y += gy.y; pdb.z += gy.z; pdb.w += gy.w;
+    const float mg = row_sum<LPR>(g.x + g.y + g.z + g.w) * (1.f / d);
+    const float mgx = row_sum<LPR>(g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w) * (1.f / d);
+    const float4 o = {rstd * (g.x - mg - xh.x * mgx), rstd * (g.y - mg - xh.y * mgx), rstd * (g.z - mg - xh.z * mgx),
+                      rstd * (g.w - mg - xh.w * mgx)};
+    *reinterpret_cast<float4 *>(dU + row * d + 4 * sub) = o;
+  }
+  *reinterpret_cast<float4 *>(&red[0][rl][4 * sub]) = pdw;
+  *reinterpret_cast<float4 *>(&red[1][rl][4 * sub]) = pdb;
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * d; e += 256) {
+    const int which = e / d, c = e % d;
+    float s = 0.f;
+    for (int r = 0; r < RPB; ++r) s += red[which][r][c];
+    atomicAdd((which ? db : dw) + c, s);
+  }
 }
 
 // elementwise helpers

@@ -12,6 +12,7 @@
 // blockIdx.z selects a weight group (the C independent GMM heads run as one grouped launch).
 #pragma once
 #include "common.h"
+#include <cstdint>
 
 #define GEMM_MAX_GROUPS 16
 
@@ -21,6 +22,7 @@ struct GemmArgs {
   float *Y; int ldy; int R_out, G_out, off_out; int col_per_group;
   int M, N, K; int relu; int accum;   // accum: Y += result
   const float *tscalar; const float *tcol; int tcol_stride;  // optional rank-1 term (time token)
+  const float *mask; int ldmask;   // optional ReLU gate of a backward product: Y[m, n] = 0 where mask[m, n] <= 0
 };
 
 constexpr int GEMM_BK = 32;
@@ -160,27 +162,52 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     }
   }
 
-  // epilogue: C/D fragment layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  // epilogue: C/D fragment layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.  The tile goes
+  // through LDS 32 rows at a time so that bias / ReLU / gate / accumulate and the store run on whole output rows
+  // (float4 per lane, BN * 4 contiguous bytes per row) instead of 64-byte column segments.
+  constexpr int LDC = BN + 4;
+  static_assert(32 * LDC * sizeof(float) <= sizeof(smem), "epilogue tile must fit the operand buffers");
+  float *Cs = reinterpret_cast<float *>(smem);
   const float *bias = a.bias[grp];
   const float tsc = a.tscalar ? a.tscalar[0] : 0.f;
+  constexpr int C4 = BN / 4, PER_T = 32 * C4 / 256;       // float4 per thread and pass (BN = 32: 1, 64: 2, 128: 4)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 16 + fr;
-    float add = bias ? bias[n] : 0.f;
-    if (a.tscalar) add += tsc * a.tcol[(long)n * a.tcol_stride];
+  for (int q = 0; q < BM / 32; ++q) {
+    __syncthreads();                                       // fragment reads / previous pass done
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int rbase = wm * WM + 16 * i;
+      if (rbase / 32 == q) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * WM + i * 16 + fg * 4 + r;
-        if (m < a.M) {
-          float v = acc[i][j][r] + add;
-          if (a.relu) v = fmaxf(v, 0.f);
-          long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
-          float *yp = a.Y + dst * a.ldy + grp * a.col_per_group + n;
-          *yp = a.accum ? *yp + v : v;
-        }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(rbase % 32 + fg * 4 + r) * LDC + wn * WN + 16 * j + fr] = acc[i][j][r];
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER_T; ++e) {
+      const int idx = tid + e * 256, row = idx / C4, c4 = idx % C4;
+      const int m = m0 + 32 * q + row, n = n0 + 4 * c4;
+      if (m >= a.M) continue;
+      float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * c4);
+      if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+      if (a.tscalar) {
+        v.x += tsc * a.tcol[(long)n * a.tcol_stride]; v.y += tsc * a.tcol[(long)(n + 1) * a.tcol_stride];
+        v.z += tsc * a.tcol[(long)(n + 2) * a.tcol_stride]; v.w += tsc * a.tcol[(long)(n + 3) * a.tcol_stride];
+      }
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (a.mask) {
+        const float4 g = *reinterpret_cast<const float4 *>(a.mask + (long)m * a.ldmask + n);
+        if (!(g.x > 0.f)) v.x = 0.f;
+        if (!(g.y > 0.f)) v.y = 0.f;
+        if (!(g.z > 0.f)) v.z = 0.f;
+        if (!(g.w > 0.f)) v.w = 0.f;
+      }
+      const long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
+      float4 *yp = reinterpret_cast<float4 *>(a.Y + dst * a.ldy + grp * a.col_per_group + n);
+      if (a.accum) { const float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *yp = v;
     }
   }
 }
@@ -188,6 +215,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 template <int PREC>
 static int launch_gemm_prec(const GemmArgs &a, int groups, hipStream_t st) {
   if (a.K % GEMM_BK != 0 || a.N % 32 != 0 || a.M <= 0) return -2;
+  // the epilogue moves float4: 16-byte aligned output rows (and gate rows)
+  if (a.ldy % 4 || a.col_per_group % 4 || (reinterpret_cast<uintptr_t>(a.Y) & 15)) return -2;
+  if (a.mask && (a.ldmask % 4 || (reinterpret_cast<uintptr_t>(a.mask) & 15))) return -2;
   dim3 block(256);
   if (a.N % 128 == 0) {
     dim3 grid((a.M + 127) / 128, a.N / 128, groups);

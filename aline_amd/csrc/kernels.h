@@ -170,6 +170,38 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
   for (int c = lane; c < d; c += 64, ++n) out[row * d + c] = (v[n] - mean) * rstd * w[c] + bias[c];
 }
 
+// Narrow-row variant (d = 4 * LPR, LPR = 8 or 16 lanes per row, float4 per lane): a wave normalises 64 / LPR
+// rows at a time and the row statistics are LPR-lane xor reductions.  At d = 32 the one-wave-per-row kernel above
+// leaves half of the lanes idle and runs at ~1 TB/s; this one is HBM-bound.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void add_layernorm_narrow_kernel(const float *__restrict__ a,
+                                                                   const float *__restrict__ b2,
+                                                                   const float *__restrict__ w,
+                                                                   const float *__restrict__ bias,
+                                                                   float *__restrict__ out, long rows,
+                                                                   float *__restrict__ usave) {
+  constexpr int d = 4 * LPR, RPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const float4 wv = *reinterpret_cast<const float4 *>(w + 4 * sub), bv = *reinterpret_cast<const float4 *>(bias + 4 * sub);
+  for (long row = (long)blockIdx.x * RPB + threadIdx.x / LPR; row < rows; row += (long)gridDim.x * RPB) {
+    const float4 x = *reinterpret_cast<const float4 *>(a + row * d + 4 * sub);
+    const float4 y = *reinterpret_cast<const float4 *>(b2 + row * d + 4 * sub);
+    float4 v = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
+    if (usave) *reinterpret_cast<float4 *>(usave + row * d + 4 * sub) = v;
+    const float mean = row_sum<LPR>(v.x + v.y + v.z + v.w) * (1.f / d);
+    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+    const float rstd = rsqrtf(row_sum<LPR>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / d) + 1e-5f);
+    float4 o = {v.x * rstd * wv.x + bv.x, v.y * rstd * wv.y + bv.y, v.z * rstd * wv.z + bv.z, v.w * rstd * wv.w + bv.w};
+    *reinterpret_cast<float4 *>(out + row * d + 4 * sub) = o;
+  }
+}
+
 // ---- G7/G8 (+G11): acquisition softmax over the remaining queries, design selection, and (rollout
 // API) the role update that replaces Task.update_batch (tasks/base_task.py:133-154).
 // hid [B*P, F] = relu(z_q W1^T + b1) from the GEMM; logits = hid . w2 + b2 (model/head.py:27-33).
