@@ -989,11 +989,18 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
   a.X = X; a.ldx = ldx; a.Rx = Rx; a.Gx = Gx; a.offx = offx;
   a.dW = dW; a.ldw = K; a.db = db; a.M = M; a.N = N; a.K = K;
   a.mchunk = 4096;
+  // the block kernel reads its wide operand once per 32 columns of the other one: let the wider matrix be the wide one
+  if (K > N && K % 64 == 0) {
+    std::swap(a.dY, a.X); std::swap(a.ldy, a.ldx); std::swap(a.Ry, a.Rx); std::swap(a.Gy, a.Gx); std::swap(a.offy, a.offx);
+    std::swap(a.N, a.K);
+    a.swap = 1;
+  }
+  const int Nw = a.N, Kn = a.K;
   const unsigned gx = (unsigned)((M + a.mchunk - 1) / a.mchunk);
-  if (N % 128 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3(gx, N / 128, K / 32), dim3(256), 0, c.st, a);
-  else if (N % 96 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<6>, dim3(gx, N / 96, K / 32), dim3(256), 0, c.st, a);
-  else if (N % 64 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<4>, dim3(gx, N / 64, K / 32), dim3(256), 0, c.st, a);
-  else hipLaunchKernelGGL(gemm_tn_block_kernel<2>, dim3(gx, N / 32, K / 32), dim3(256), 0, c.st, a);
+  if (Nw % 128 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3(gx, Nw / 128, Kn / 32), dim3(256), 0, c.st, a);
+  else if (Nw % 96 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<6>, dim3(gx, Nw / 96, Kn / 32), dim3(256), 0, c.st, a);
+  else if (Nw % 64 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<4>, dim3(gx, Nw / 64, Kn / 32), dim3(256), 0, c.st, a);
+  else hipLaunchKernelGGL(gemm_tn_block_kernel<2>, dim3(gx, Nw / 32, Kn / 32), dim3(256), 0, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -1018,7 +1025,7 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 
 template <int HD>
 int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys) {
-  size_t smem = (size_t)max_keys * (2 * HD * sizeof(float) + sizeof(int)) +
+  size_t smem = (size_t)max_keys * (4 * HD * sizeof(float) + sizeof(int)) +
                 (size_t)c.g.N * (2 * HD + 4) * sizeof(float);
   if (smem > 160 * 1024 - 1024) return ALINE_EUNSUPPORTED;
   if (smem > 48 * 1024)
@@ -1159,7 +1166,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       a.g_mean = g_pm ? g_pm + (size_t)tA * B * n_t * C : nullptr;
       a.g_std = g_ps ? g_ps + (size_t)tA * B * n_t * C : nullptr;
       a.g_wgt = g_pw ? g_pw + (size_t)tA * B * n_t * C : nullptr;
-      hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, c.st, a);
+      hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();
       float *Wt = c.at(c.pl.Wt);   // [d, C*F]: column block k = W1_k^T
       for (int k = 0; k < C; ++k) {

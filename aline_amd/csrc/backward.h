@@ -7,77 +7,20 @@
 #include "kernels.h"
 
 // dW[n, k] += sum_m dY[m, n] * X[m, k]   and (optionally) db[n] += sum_m dY[m, n]
-// "TN" product over a very tall M.  One workgroup = one 32x32 output tile x one chunk of rows; its 4
-// waves take interleaved row groups, accumulate with exact-fp32 16x16x4 MFMAs (A = dY^T: lane n holds
-// dY[m, n], k index = row m), are summed through LDS and added to global memory with float atomics.
+// "TN" product over a very tall M.  One workgroup = one block of dW x one chunk of rows; its 4 waves take
+// interleaved row groups, accumulate with exact-fp32 16x16x4 MFMAs (A = dY^T: lane n holds dY[m, n],
+// k index = row m), are summed through LDS and added to global memory with float atomics.
 struct GemmTnArgs {
   const float *dY; int ldy; int Ry, Gy, offy;   // row maps as in gemm.h
   const float *X; int ldx; int Rx, Gx, offx;
   float *dW; int ldw;                            // [N, K]
   float *db;                                     // [N] or null
   long M; int N, K; long mchunk;
+  int swap;                                      // block kernel: roles exchanged (dY is the 32-wide operand), see gemm_dw
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_atomic_kernel(GemmTnArgs a) {
-  __shared__ float red[4][32][33];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.y * 32, k0 = blockIdx.z * 32;
-  const long m_lo = (long)blockIdx.x * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
-  // wave w handles row groups of 4: m = m_lo + 4 * (w + 4 * it) + fg
-  for (long mb = m_lo + 4 * wave; mb < m_hi; mb += 16) {
-    const long m = mb + fg;
-    float av[2] = {0.f, 0.f}, bv[2] = {0.f, 0.f};
-    if (m < m_hi) {
-      const long ry = (m / a.Ry) * a.Gy + a.offy + (m % a.Ry);
-      const long rx = (m / a.Rx) * a.Gx + a.offx + (m % a.Rx);
-      av[0] = a.dY[ry * a.ldy + n0 + fr];
-      av[1] = a.dY[ry * a.ldy + n0 + 16 + fr];
-      bv[0] = a.X[rx * a.ldx + k0 + fr];
-      bv[1] = a.X[rx * a.ldx + k0 + 16 + fr];
-    }
-    bsum[0] += av[0];
-    bsum[1] += av[1];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-  }
-  // acc[i][j][r]: n = 16 i + 4 fg + r, k = 16 j + fr
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][16 * i + 4 * fg + r][16 * j + fr] = acc[i][j][r];
-  __syncthreads();
-  for (int e = threadIdx.x; e < 32 * 32; e += 256) {
-    const int n = e >> 5, k = e & 31;
-    const float v = red[0][n][k] + red[1][n][k] + red[2][n][k] + red[3][n][k];
-    atomicAdd(a.dW + (long)(n0 + n) * a.ldw + k0 + k, v);
-  }
-  if (a.db && blockIdx.z == 0) {
-    // column sums of dY: lanes (fr, fg) hold partial sums of column 16 i + fr
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float s = bsum[i];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (fg == 0) atomicAdd(a.db + n0 + 16 * i + fr, s);
-    }
-  }
-}
-
-// Same product with one workgroup owning a [16 TN x 32] block of dW for its row chunk (TN = 8, 6, 4, 2 by the
-// divisibility of N): a row of dY is read once per 32 columns of X instead of once per 32 x 32 tile, 2 TN MFMAs
-// per (TN + 2) loads, four row groups in flight per wave.
+// The workgroup owns a [16 TN x 32] block of dW for its row chunk (TN = 8, 6, 4, 2 by the divisibility of N):
+// a row of dY is read once per 32 columns of X, 2 TN MFMAs per (TN + 2) loads, four row groups in flight per wave.
 template <int TN>
 __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
   constexpr int BN = 16 * TN;
@@ -88,7 +31,7 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
   const long m_lo = (long)blockIdx.x * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
   for (int e = threadIdx.x; e < BN * 33; e += 256) (&red[0][0])[e] = 0.f;
   f32x4 acc[TN][2];
-  float bsum[TN];
+  float bsum[TN], bsum2[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -110,6 +53,11 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
       bv[u][1] = ok ? px[16] : 0.f;
     }
 #pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      bsum2[0] += bv[u][0];
+      bsum2[1] += bv[u][1];
+    }
+#pragma unroll
     for (int u = 0; u < UN; ++u)
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -127,17 +75,34 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(&red[16 * i + 4 * fg + r][16 * j + fr], acc[i][j][r]);
   __syncthreads();
-  for (int e = threadIdx.x; e < BN * 32; e += 256) {
-    const int n = e >> 5, k = e & 31;
-    atomicAdd(a.dW + (long)(n0 + n) * a.ldw + k0 + k, red[n][k]);
-  }
-  if (a.db && blockIdx.z == 0) {
+  if (!a.swap) {
+    for (int e = threadIdx.x; e < BN * 32; e += 256) {
+      const int n = e >> 5, k = e & 31;
+      atomicAdd(a.dW + (long)(n0 + n) * a.ldw + k0 + k, red[n][k]);
+    }
+    if (a.db && blockIdx.z == 0) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      float s = bsum[i];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (fg == 0) atomicAdd(a.db + n0 + 16 * i + fr, s);
+      for (int i = 0; i < TN; ++i) {
+        float s = bsum[i];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (fg == 0) atomicAdd(a.db + n0 + 16 * i + fr, s);
+      }
+    }
+  } else {
+    // the wide operand is X: this block holds dW^T[n0.., k0..]; dW is [K_args, N_args] = [32-wide index, wide index]
+    for (int e = threadIdx.x; e < BN * 32; e += 256) {
+      const int k = e / BN, n = e % BN;
+      atomicAdd(a.dW + (long)(k0 + k) * a.ldw + n0 + n, red[n][k]);
+    }
+    if (a.db && blockIdx.y == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float s = bsum2[j];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (fg == 0) atomicAdd(a.db + k0 + 16 * j + fr, s);
+      }
     }
   }
 }
@@ -229,10 +194,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const float *
 }
 
 // elementwise helpers
-__global__ void relu_mask_kernel(float *__restrict__ g, const float *__restrict__ act, long n) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && !(act[i] > 0.f)) g[i] = 0.f;
-}
 __global__ void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] += b[i];
@@ -260,7 +221,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   float *Qs = Vs + (size_t)max_keys * HD;                          // [N][HD]  scaled queries
   float *Gs = Qs + (size_t)g.N * HD;                               // [N][HD]  dO
   float *St = Gs + (size_t)g.N * HD;                               // [N][4]   max, 1/l, delta, #keys
-  int *keyrow = reinterpret_cast<int *>(St + (size_t)g.N * 4);     // [max_keys]
+  float *dKV = St + (size_t)g.N * 4;                               // [max_keys][2 HD]  dK | dV sums
+  int *keyrow = reinterpret_cast<int *>(dKV + (size_t)max_keys * 2 * HD);     // [max_keys]
   __shared__ int wave_cnt[4];
   __shared__ int s_base;
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -297,6 +259,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
     Ks[j * HD + c] = src[d];
     Vs[j * HD + c] = src[2 * d];
+    dKV[j * 2 * HD + c] = 0.f;
+    dKV[j * 2 * HD + HD + c] = 0.f;
   }
   __syncthreads();
   const float scale = rsqrtf((float)HD);
@@ -319,50 +283,57 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
       for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j * HD + c], s);
       mx = fmaxf(mx, s);
     }
-    float l = 0.f, delta = 0.f;
+    // dq = sum_j p_j (dp_j - delta) k_j = (sum_j e_j dp_j k_j - delta sum_j e_j k_j) / l  in one pass over the keys
+    float l = 0.f, delta = 0.f, pk[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) pk[c] = 0.f;
     for (int j = 0; j < nk; ++j) {
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
-      const float p = __expf(s - mx);
-      l += p;
-      delta += p * dp;
+      const float e = __expf(s - mx), edp = e * dp;
+      l += e;
+      delta += edp;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) { dq[c] = fmaf(edp, Ks[j * HD + c], dq[c]); pk[c] = fmaf(e, Ks[j * HD + c], pk[c]); }
     }
     const float inv = 1.f / l;
     delta *= inv;
-    for (int j = 0; j < nk; ++j) {
-      float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
-      const float ds = __expf(s - mx) * inv * (dp - delta);
-#pragma unroll
-      for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, Ks[j * HD + c], dq[c]);
-    }
+    for (int c = 0; c < HD; ++c) dq[c] = (dq[c] - delta * pk[c]) * inv;
     St[row * 4 + 0] = mx; St[row * 4 + 1] = inv; St[row * 4 + 2] = delta; St[row * 4 + 3] = (float)nk;
     float *out = dQKV + (ep + row) * 3 * d + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; ++c) { out[c] = dq[c] * scale; out[d + c] = 0.f; out[2 * d + c] = 0.f; }
   }
   __syncthreads();
-  // phase 2: thread = (key j, channel c); loops over the token rows that see key j
-  for (int e = tid; e < n_ak * HD; e += 256) {
-    const int j = e / HD, c = e % HD;
-    float kj[HD], vj[HD];
+  // phase 2: thread = (key j, slice of the token rows): softmax weight and score gradient once per (row, key),
+  // partial dK / dV rows in registers, summed per key through LDS
+  const int nsl = max(1, 256 / max(n_ak, 1));
+  for (int w = tid; w < n_ak * nsl; w += 256) {
+    const int j = w % n_ak, sl = w / n_ak;
+    float kj[HD], vj[HD], dk[HD], dv[HD];
 #pragma unroll
-    for (int cc = 0; cc < HD; ++cc) { kj[cc] = Ks[j * HD + cc]; vj[cc] = Vs[j * HD + cc]; }
-    float dk = 0.f, dv = 0.f;
-    for (int row = 0; row < g.N; ++row) {
+    for (int c = 0; c < HD; ++c) { kj[c] = Ks[j * HD + c]; vj[c] = Vs[j * HD + c]; dk[c] = 0.f; dv[c] = 0.f; }
+    for (int row = sl; row < g.N; row += nsl) {
       if ((float)j >= St[row * 4 + 3]) continue;      // key not visible to this row
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < HD; ++cc) { s = fmaf(Qs[row * HD + cc], kj[cc], s); dp = fmaf(Gs[row * HD + cc], vj[cc], dp); }
+      for (int c = 0; c < HD; ++c) { s = fmaf(Qs[row * HD + c], kj[c], s); dp = fmaf(Gs[row * HD + c], vj[c], dp); }
       const float p = __expf(s - St[row * 4 + 0]) * St[row * 4 + 1];
-      dv = fmaf(p, Gs[row * HD + c], dv);
-      dk = fmaf(p * (dp - St[row * 4 + 2]), Qs[row * HD + c], dk);
+      const float ds = p * (dp - St[row * 4 + 2]);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) { dv[c] = fmaf(p, Gs[row * HD + c], dv[c]); dk[c] = fmaf(ds, Qs[row * HD + c], dk[c]); }
     }
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { atomicAdd(&dKV[j * 2 * HD + c], dk[c]); atomicAdd(&dKV[j * 2 * HD + HD + c], dv[c]); }
+  }
+  __syncthreads();
+  for (int e = tid; e < n_ak * HD; e += 256) {
+    const int j = e / HD, c = e % HD;
     float *dst = dQKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
-    dst[d] = dk;            // Qs already carries the 1/sqrt(hd)
-    dst[2 * d] = dv;
+    dst[d] = dKV[j * 2 * HD + c];            // Qs already carries the 1/sqrt(hd)
+    dst[2 * d] = dKV[j * 2 * HD + HD + c];
   }
 }
 
@@ -421,15 +392,25 @@ __global__ __launch_bounds__(256) void acq_bwd_kernel(AcqBwdArgs a) {
   dbl = wave_sum(dbl);
   if (lane == 0) atomicAdd(a.db2, dbl);
   __syncthreads();
+  float pw[8], w2r[8];                      // lane owns features lane + 64 n  (F <= 512)
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { pw[n] = 0.f; w2r[n] = lane + 64 * n < F ? a.w2[lane + 64 * n] : 0.f; }
   for (int p = wave; p < P; p += 4) {
     float *hp = a.hid + ((long)i * P + p) * F;
     const float dl = logit[p];
-    for (int f = lane; f < F; f += 64) {
-      const float hv = hp[f];
-      if (dl != 0.f) atomicAdd(&sdw[f], dl * hv);
-      hp[f] = hv > 0.f ? dl * a.w2[f] : 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int f = lane + 64 * n;
+      if (f < F) {
+        const float hv = hp[f];
+        pw[n] = fmaf(dl, hv, pw[n]);
+        hp[f] = hv > 0.f ? dl * w2r[n] : 0.f;
+      }
     }
   }
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+    if (lane + 64 * n < F) atomicAdd(&sdw[lane + 64 * n], pw[n]);
   __syncthreads();
   for (int f = tid; f < F; f += 256) atomicAdd(a.dw2 + f, sdw[f]);
 }
@@ -446,64 +427,109 @@ struct GmmBwdArgs {
   const float *g_ll;                           // [rows] dLoss/d ll, or null
   const float *g_mean, *g_std, *g_wgt;         // [rows, C] dLoss/d mixture_{means,stds,weights}, or null
 };
+constexpr int GMM_BWD_ROWS = 64;   // rows per workgroup (16 per wave): weight-gradient partials stay in registers
 __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
-  float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;
-  for (int c = 0; c < a.C; ++c) {
-    const float *hp = a.hid + (row * a.C + c) * a.F;
-    const float *w = a.w2[c];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int f = lane; f < a.F; f += 64) {
-      const float hv = hp[f];
-      s0 = fmaf(hv, w[f], s0); s1 = fmaf(hv, w[a.F + f], s1); s2 = fmaf(hv, w[2 * a.F + f], s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r_lo = (long)blockIdx.x * GMM_BWD_ROWS, r_hi = min(a.rows, r_lo + GMM_BWD_ROWS);
+  // lane owns hidden units lane, lane + 64 (F <= 128 here; wider heads fall back to per-row atomics below)
+  const bool wide_f = a.F > 128;
+  float pw[16][3][2];
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int o = 0; o < 3; ++o) pw[c][o][0] = pw[c][o][1] = 0.f;
+  float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;      // lane c: bias gradients of component c
+  for (long row = r_lo + wave; row < r_hi; row += 4) {
+    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      const float *hp = a.hid + (row * a.C + c) * a.F;
+      const float *w = a.w2[c];
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      for (int f = lane; f < a.F; f += 64) {
+        const float hv = hp[f];
+        s0 = fmaf(hv, w[f], s0); s1 = fmaf(hv, w[a.F + f], s1); s2 = fmaf(hv, w[2 * a.F + f], s2);
+      }
+      s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+      if (lane == c) { raw0 = s0 + a.b2[c][0]; raw1 = s1 + a.b2[c][1]; raw2 = s2 + a.b2[c][2]; }
     }
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == c) { raw0 = s0 + a.b2[c][0]; raw1 = s1 + a.b2[c][1]; raw2 = s2 + a.b2[c][2]; }
-  }
-  const bool act = lane < a.C;
-  const float mean = raw0, sd = softplus_f(raw1) + a.std_min;
-  const float mxw = wave_max(act ? raw2 : -INFINITY);
-  const float ew = act ? __expf(raw2 - mxw) : 0.f;
-  const float wgt = ew / wave_sum(ew);
-  const float v = a.value[row % a.value_mod];
-  const float z = (v - mean) / sd;
-  const float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
-  const float m2 = wave_max(lp);
-  const float er = act ? __expf(lp - m2) : 0.f;
-  const float resp = er / wave_sum(er);          // responsibilities
-  const float gl = a.g_ll ? a.g_ll[row] : 0.f;
-  // d ll / d raw
-  float d0 = act ? gl * resp * z / sd : 0.f;                                        // mean
-  float dsd = act ? gl * resp * (z * z - 1.f) / sd : 0.f;                           // sigma
-  float d2 = act ? gl * (resp - wgt) : 0.f;                                         // mixture logits
-  // direct upstream gradients of the GMM parameters (autograd through the caller's own compute_ll)
-  if (a.g_mean && act) d0 += a.g_mean[row * a.C + lane];
-  if (a.g_std && act) dsd += a.g_std[row * a.C + lane];
-  if (a.g_wgt) {
-    const float gw = act ? a.g_wgt[row * a.C + lane] : 0.f;
-    const float dot = wave_sum(gw * wgt);
-    if (act) d2 += wgt * (gw - dot);                                                // softmax backward
-  }
-  const float d1 = dsd * (1.f / (1.f + __expf(-raw1)));                             // softplus'
-  for (int c = 0; c < a.C; ++c) {
-    const float g0 = __shfl(d0, c, 64), g1 = __shfl(d1, c, 64), g2 = __shfl(d2, c, 64);
-    float *hp = a.hid + (row * a.C + c) * a.F;
-    const float *w = a.w2[c];
-    for (int f = lane; f < a.F; f += 64) {
-      const float hv = hp[f];
-      if (hv > 0.f) {
-        atomicAdd(a.dw2[c] + f, g0 * hv);
-        atomicAdd(a.dw2[c] + a.F + f, g1 * hv);
-        atomicAdd(a.dw2[c] + 2 * a.F + f, g2 * hv);
-        hp[f] = g0 * w[f] + g1 * w[a.F + f] + g2 * w[2 * a.F + f];
-      } else {
-        hp[f] = 0.f;
+    const bool act = lane < a.C;
+    const float mean = raw0, sd = softplus_f(raw1) + a.std_min;
+    const float mxw = wave_max(act ? raw2 : -INFINITY);
+    const float ew = act ? __expf(raw2 - mxw) : 0.f;
+    const float wgt = ew / wave_sum(ew);
+    const float v = a.value[row % a.value_mod];
+    const float z = (v - mean) / sd;
+    const float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
+    const float m2 = wave_max(lp);
+    const float er = act ? __expf(lp - m2) : 0.f;
+    const float resp = er / wave_sum(er);          // responsibilities
+    const float gl = a.g_ll ? a.g_ll[row] : 0.f;
+    // d ll / d raw
+    float d0 = act ? gl * resp * z / sd : 0.f;                                        // mean
+    float dsd = act ? gl * resp * (z * z - 1.f) / sd : 0.f;                           // sigma
+    float d2 = act ? gl * (resp - wgt) : 0.f;                                         // mixture logits
+    // direct upstream gradients of the GMM parameters (autograd through the caller's own compute_ll)
+    if (a.g_mean && act) d0 += a.g_mean[row * a.C + lane];
+    if (a.g_std && act) dsd += a.g_std[row * a.C + lane];
+    if (a.g_wgt) {
+      const float gw = act ? a.g_wgt[row * a.C + lane] : 0.f;
+      const float dot = wave_sum(gw * wgt);
+      if (act) d2 += wgt * (gw - dot);                                                // softmax backward
+    }
+    const float d1 = dsd * (1.f / (1.f + __expf(-raw1)));                             // softplus'
+    pb0 += d0; pb1 += d1; pb2 += d2;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < a.C) {
+        const float g0 = __shfl(d0, c, 64), g1 = __shfl(d1, c, 64), g2 = __shfl(d2, c, 64);
+        float *hp = a.hid + (row * a.C + c) * a.F;
+        const float *w = a.w2[c];
+        if (wide_f) {
+          for (int f = lane; f < a.F; f += 64) {
+            const float hv = hp[f];
+            if (hv > 0.f) {
+              atomicAdd(a.dw2[c] + f, g0 * hv);
+              atomicAdd(a.dw2[c] + a.F + f, g1 * hv);
+              atomicAdd(a.dw2[c] + 2 * a.F + f, g2 * hv);
+              hp[f] = g0 * w[f] + g1 * w[a.F + f] + g2 * w[2 * a.F + f];
+            } else {
+              hp[f] = 0.f;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const int f = lane + 64 * n;
+            if (f < a.F) {
+              const float hv = hp[f];
+              if (hv > 0.f) {
+                pw[c][0][n] = fmaf(g0, hv, pw[c][0][n]);
+                pw[c][1][n] = fmaf(g1, hv, pw[c][1][n]);
+                pw[c][2][n] = fmaf(g2, hv, pw[c][2][n]);
+                hp[f] = g0 * w[f] + g1 * w[a.F + f] + g2 * w[2 * a.F + f];
+              } else {
+                hp[f] = 0.f;
+              }
+            }
+          }
+        }
       }
     }
-    if (lane == 0) { atomicAdd(a.db2[c] + 0, g0); atomicAdd(a.db2[c] + 1, g1); atomicAdd(a.db2[c] + 2, g2); }
   }
+  if (!wide_f) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int f = lane + 64 * n;
+        if (c < a.C && f < a.F) {
+#pragma unroll
+          for (int o = 0; o < 3; ++o) atomicAdd(a.dw2[c] + o * a.F + f, pw[c][o][n]);
+        }
+      }
+    }
+  }
+  if (lane < a.C) { atomicAdd(a.db2[lane] + 0, pb0); atomicAdd(a.db2[lane] + 1, pb1); atomicAdd(a.db2[lane] + 2, pb2); }
 }
 
 // Gradient of the step-invariant embeddings: X0[(t,b), row] = Ex[b, row] (+ Ey[b, p] while p is context),
