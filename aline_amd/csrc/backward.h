@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   int *keyrow = reinterpret_cast<int *>(dKV + (size_t)max_keys * 2 * HD);     // [max_keys]
   __shared__ int wave_cnt[4];
   __shared__ int s_base;
-  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // workgroup id -> (episode, head) as in attention_kernel: the heads of an episode share an XCD's L2
+  const int H = d / HD, b = (blockIdx.x / (8 * H)) * 8 + blockIdx.x % 8, h = (blockIdx.x / 8) % H;
+  if (b >= g.B) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_t = g.n_td + g.n_th;
   if (tid == 0) s_base = 0;
   __syncthreads();
@@ -271,10 +274,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     const float *qp = QKV + (ep + row) * 3 * d + h * HD;
     const float *gp = dA + (ep + row) * d + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) {
-      q[c] = qp[c] * scale; go[c] = gp[c]; dq[c] = 0.f;
-      Qs[row * HD + c] = q[c];
-      Gs[row * HD + c] = go[c];
+    for (int c = 0; c < HD; c += 4) {          // rows are 16-byte aligned (d, HD multiples of 4): 128-bit moves
+      const float4 qv = *reinterpret_cast<const float4 *>(qp + c), gv = *reinterpret_cast<const float4 *>(gp + c);
+      q[c] = qv.x * scale; q[c + 1] = qv.y * scale; q[c + 2] = qv.z * scale; q[c + 3] = qv.w * scale;
+      go[c] = gv.x; go[c + 1] = gv.y; go[c + 2] = gv.z; go[c + 3] = gv.w;
+      dq[c] = dq[c + 1] = dq[c + 2] = dq[c + 3] = 0.f;
+      *reinterpret_cast<float4 *>(Qs + row * HD + c) = make_float4(q[c], q[c + 1], q[c + 2], q[c + 3]);
+      *reinterpret_cast<float4 *>(Gs + row * HD + c) = gv;
     }
     float mx = -INFINITY;
     for (int j = 0; j < nk; ++j) {
@@ -301,10 +307,14 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     delta *= inv;
 #pragma unroll
     for (int c = 0; c < HD; ++c) dq[c] = (dq[c] - delta * pk[c]) * inv;
-    St[row * 4 + 0] = mx; St[row * 4 + 1] = inv; St[row * 4 + 2] = delta; St[row * 4 + 3] = (float)nk;
+    *reinterpret_cast<float4 *>(St + row * 4) = make_float4(mx, inv, delta, (float)nk);
     float *out = dQKV + (ep + row) * 3 * d + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) { out[c] = dq[c] * scale; out[d + c] = 0.f; out[2 * d + c] = 0.f; }
+    for (int c = 0; c < HD; c += 4) {
+      *reinterpret_cast<float4 *>(out + c) = make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale);
+      *reinterpret_cast<float4 *>(out + d + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(out + 2 * d + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   __syncthreads();
   // phase 2: thread = (key j, slice of the token rows): softmax weight and score gradient once per (row, key),

@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const floa
   int *keyrow = reinterpret_cast<int *>(Vs + (size_t)max_keys * HD);   // [max_keys]
   __shared__ int wave_cnt[4];
   __shared__ int s_base;
-  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the H heads of an episode read interleaved pieces of the same QKV rows: give them workgroup ids 8 apart so that
+  // they run on the same XCD at about the same time and share the lines in its L2 (ids go round-robin over 8 XCDs)
+  const int H = d / HD, b = (blockIdx.x / (8 * H)) * 8 + blockIdx.x % 8, h = (blockIdx.x / 8) % H;
+  if (b >= g.B) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_t = g.n_td + g.n_th;
   // ordered compaction of the key rows: context points in slot order, then selected targets
   if (tid == 0) s_base = 0;
@@ -127,7 +131,11 @@ __global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const floa
     float q[HD], o[HD];
     const float *qp = QKV + (ep + row) * 3 * d + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) { q[c] = qp[c] * scale; o[c] = 0.f; }
+    for (int c = 0; c < HD; c += 4) {            // rows are 16-byte aligned (d, HD multiples of 4)
+      const float4 qv = *reinterpret_cast<const float4 *>(qp + c);
+      q[c] = qv.x * scale; q[c + 1] = qv.y * scale; q[c + 2] = qv.z * scale; q[c + 3] = qv.w * scale;
+      o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
+    }
     float mx = -INFINITY, l = 0.f;
     for (int j = 0; j < nk; ++j) {
       float s = 0.f;
@@ -143,7 +151,8 @@ __global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const floa
     float inv = 1.f / l;
     float *op = Aout + (ep + row) * d + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) op[c] = o[c] * inv;
+    for (int c = 0; c < HD; c += 4)
+      *reinterpret_cast<float4 *>(op + c) = make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
   }
 }
 
