@@ -876,16 +876,26 @@ int aline_eig_ces_step(const float *theta, const float *xi, const float *y, floa
   if (!theta || !xi || !y || !S || L1 < 2 || B <= 0) return ALINE_EINVAL;
   const size_t total = (size_t)L1 * B;
   unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(eig_ces_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     theta, xi, y, S, (long)L1, B, noise_scale, epsilon, nan_flag);
+  const size_t tab_bytes = (size_t)B * CES_ROW * sizeof(float);
+  if (tab_bytes <= 48 * 1024 && !getenv("ALINE_CES_GENERIC"))
+    hipLaunchKernelGGL(eig_ces_step_table_kernel, dim3(blocks), dim3(256), tab_bytes, static_cast<hipStream_t>(stream),
+                       theta, xi, y, S, (long)L1, B, noise_scale, epsilon, nan_flag);
+  else
+    hipLaunchKernelGGL(eig_ces_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       theta, xi, y, S, (long)L1, B, noise_scale, epsilon, nan_flag);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
 
-static const long kEigChunk = 4096;
+// rows of S per partial-logsumexp workgroup: about 2048 chunks over L (enough workgroups to fill the chip at the
+// small outer batches of the evaluation protocol), 256 .. 4096 rows
+static long eig_chunk_rows(int64_t L1) {
+  const long want = ((L1 - 1 + 2047) / 2048 + 63) / 64 * 64;
+  return std::min<long>(4096, std::max<long>(256, want));
+}
 
 size_t aline_eig_finalize_workspace_bytes(int64_t L1, int B) {
-  long nchunk = (L1 - 1 + kEigChunk - 1) / kEigChunk;
+  const long ch = eig_chunk_rows(L1), nchunk = (L1 - 1 + ch - 1) / ch;
   return (size_t)std::max<long>(nchunk, 1) * B * 2 * sizeof(float);
 }
 
@@ -893,13 +903,14 @@ int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc
                        size_t ws_bytes, void *stream) {
   if (!S || L1 < 2 || B <= 0 || !ws) return ALINE_EINVAL;
   if (ws_bytes < aline_eig_finalize_workspace_bytes(L1, B)) return ALINE_EWORKSPACE;
+  const long kEigChunk = eig_chunk_rows(L1);
   const int nchunk = (int)((L1 - 1 + kEigChunk - 1) / kEigChunk);
   float *part = static_cast<float *>(ws);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(eig_lse_partial_kernel, dim3(nchunk, (B + 63) / 64), dim3(256), 0, st, S, (long)L1,
                      B, kEigChunk, part);
   CHECK_LAUNCH();
-  hipLaunchKernelGGL(eig_lse_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, st, S, part, nchunk,
+  hipLaunchKernelGGL(eig_lse_combine_kernel, dim3(B), dim3(256), 0, st, S, part, nchunk,
                      (long)L1, B, pce, nmc);
   CHECK_LAUNCH();
   return ALINE_OK;

@@ -120,37 +120,110 @@ __global__ __launch_bounds__(256) void eig_ces_step_kernel(const float *__restri
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
+// Same step with everything that depends on the design / outcome of episode b only (clamped design, its log2, the
+// noise scale (1 + |x_a - x_b|) * noise, logit(y) and the softplus terms) tabulated in LDS once per workgroup, and
+// x^rho = exp2(rho * log2 x), s^(1/rho) = exp2(log2 s / rho) on the native exp2 / log2 units:
+//   lp = -z^2 / 2 - log(sd) - c + softplus(-x) + softplus(x),  z = (logit(y) - (U1 - U2) u) / sd,  sd = dn * u,
+//   log(sd) = log(dn) + theta_4 exactly (u = exp(theta_4)).
+// 11 transcendentals per (l, b) instead of 8 powf + ~12 more; censored outcomes (y at eps / 1 - eps) take the
+// general csn_log_prob.  Table row = 20 floats; used when B * 80 bytes fits 48 KB.
+constexpr int CES_ROW = 20;
+__global__ __launch_bounds__(256) void eig_ces_step_table_kernel(const float *__restrict__ theta,
+                                                                 const float *__restrict__ xi,
+                                                                 const float *__restrict__ y,
+                                                                 float *__restrict__ S, long L1, int B,
+                                                                 float noise, float eps, int *nan_flag) {
+  extern __shared__ float tab[];        // [B][CES_ROW]: x[6] | log2 x[6] | 1/dn | cst | logit(y) | kind | dn | y
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float *r = tab + b * CES_ROW;
+    float x[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { x[c] = fminf(fmaxf(xi[b * 6 + c], 0.01f), 100.f); r[c] = x[c]; r[6 + c] = log2f(x[c]); }
+    const float dd0 = x[0] - x[3], dd1 = x[1] - x[4], dd2 = x[2] - x[5];
+    const float dn = (1.f + sqrtf(dd0 * dd0 + dd1 * dd1 + dd2 * dd2)) * noise;
+    const float v = y[b], lo = eps, hi = 1.f - eps;
+    const int kind = (v > hi || v < lo) ? 3 : (v == hi || v == lo) ? 1 : 0;
+    const float xl = logit_clamped(v);
+    r[12] = 1.f / dn;
+    r[13] = softplus_t(-xl) + softplus_t(xl) - LOG_SQRT_2PI - logf(dn);
+    r[14] = xl;
+    r[15] = __int_as_float(kind);
+    r[16] = dn;
+    r[17] = v;
+  }
+  __syncthreads();
+  const long total = L1 * B;
+  bool bad = false;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int b = (int)(i0 % B);
+  const int db = (int)(stride % B);
+  for (long i = i0; i < total; i += stride, b = (b + db >= B ? b + db - B : b + db)) {
+    const float *th = theta + i * 5;
+    const float rho = th[0], a0 = th[1], a1 = th[2], a2 = th[3], t4 = th[4];
+    const float *r = tab + b * CES_ROW;
+    const int kind = __float_as_int(r[15]);
+    float lp;
+    if (kind == 0) {
+      const float ir = 1.f / rho;
+      const float s1 = a0 * __builtin_amdgcn_exp2f(rho * r[6]) + a1 * __builtin_amdgcn_exp2f(rho * r[7]) +
+                       a2 * __builtin_amdgcn_exp2f(rho * r[8]);
+      const float s2 = a0 * __builtin_amdgcn_exp2f(rho * r[9]) + a1 * __builtin_amdgcn_exp2f(rho * r[10]) +
+                       a2 * __builtin_amdgcn_exp2f(rho * r[11]);
+      const float u1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(s1) * ir);
+      const float u2 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(s2) * ir);
+      // z = (logit(y) - (u1 - u2) u) / (dn u)
+      const float z = (r[14] * __expf(-t4) - (u1 - u2)) * r[12];
+      lp = -0.5f * z * z - t4 + r[13];
+    } else if (kind == 3) {
+      lp = -INFINITY;
+    } else {
+      const float u = expf(t4), ir = 1.f / rho;
+      const float u1 = powf(a0 * powf(r[0], rho) + a1 * powf(r[1], rho) + a2 * powf(r[2], rho), ir);
+      const float u2 = powf(a0 * powf(r[3], rho) + a1 * powf(r[4], rho) + a2 * powf(r[5], rho), ir);
+      lp = csn_log_prob(r[17], (u1 - u2) * u, r[16] * u, eps, 1.f - eps);
+    }
+    bad |= (lp != lp) || isinf(lp);
+    S[i] += lp;
+  }
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
+}
+
 // ---- EIGStepLoss.forward: logsumexp over l (loss/eig.py:195-209) ---------------------------------
 // pass 1: per chunk of rows l in [1 + c*CH, ...) an online (max, sumexp) per column b
 __global__ __launch_bounds__(256) void eig_lse_partial_kernel(const float *__restrict__ S, long L1, int B,
                                                               long chunk, float *__restrict__ part) {
-  __shared__ float sm[4][64], ss[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int b = blockIdx.y * 64 + tx;
+  // a workgroup covers cols = min(B, 64) columns x rows = 256 / cols rows per pass: for the small outer batches of
+  // the evaluation protocol (B = 20, README.md:50) 240 of 256 lanes stay busy and a pass reads contiguous memory
+  __shared__ float sm[256], ss[256];
+  const int cols = min(B, 64), rows = 256 / cols;
+  const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+  const int b = blockIdx.y * cols + tx;
   const long l0 = 1 + (long)blockIdx.x * chunk;
   const long l1 = min(L1, l0 + chunk);
   float m = -INFINITY, s = 0.f;
-  if (b < B) {
+  if (b < B && ty < rows) {
     long l = l0 + ty;
-    for (; l + 12 < l1; l += 16) {       // four independent loads in flight per thread, one rescale per group
-      const float v0 = S[l * B + b], v1 = S[(l + 4) * B + b], v2 = S[(l + 8) * B + b], v3 = S[(l + 12) * B + b];
+    const long r1 = rows, r2 = 2 * rows, r3 = 3 * rows;
+    for (; l + r3 < l1; l += 4 * rows) {       // four independent loads in flight per thread, one rescale per group
+      const float v0 = S[l * B + b], v1 = S[(l + r1) * B + b], v2 = S[(l + r2) * B + b], v3 = S[(l + r3) * B + b];
       const float mn = fmaxf(fmaxf(m, fmaxf(v0, v1)), fmaxf(v2, v3));
       if (mn != -INFINITY)
         s = s * __expf(m - mn) + ((__expf(v0 - mn) + __expf(v1 - mn)) + (__expf(v2 - mn) + __expf(v3 - mn)));
       m = mn;
     }
-    for (; l < l1; l += 4) {
+    for (; l < l1; l += rows) {
       float v = S[l * B + b];
       float mn = fmaxf(m, v);
       s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + __expf(v - mn);
       m = mn;
     }
   }
-  sm[ty][tx] = m; ss[ty][tx] = s;
+  sm[threadIdx.x] = m; ss[threadIdx.x] = s;
   __syncthreads();
   if (ty == 0 && b < B) {
-    for (int j = 1; j < 4; ++j) {
-      float m2 = sm[j][tx], s2 = ss[j][tx];
+    for (int j = 1; j < rows; ++j) {
+      float m2 = sm[j * cols + tx], s2 = ss[j * cols + tx];
       float mn = fmaxf(m, m2);
       if (mn != -INFINITY) s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
       m = mn;
@@ -159,25 +232,40 @@ __global__ __launch_bounds__(256) void eig_lse_partial_kernel(const float *__res
     part[((long)blockIdx.x * B + b) * 2 + 1] = s;
   }
 }
-// pass 2: combine the chunks; bounds of utils/eval.py:77-78
-__global__ void eig_lse_combine_kernel(const float *__restrict__ S, const float *__restrict__ part,
-                                       int nchunk, long L1, int B, float *pce, float *nmc) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// pass 2: combine the chunks (one workgroup per column b); bounds of utils/eval.py:77-78
+__global__ __launch_bounds__(256) void eig_lse_combine_kernel(const float *__restrict__ S, const float *__restrict__ part,
+                                                              int nchunk, long L1, int B, float *pce, float *nmc) {
+  __shared__ float sm[256], ss[256];
+  const int b = blockIdx.x;
   float m = -INFINITY, s = 0.f;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
     float m2 = part[((long)c * B + b) * 2], s2 = part[((long)c * B + b) * 2 + 1];
     float mn = fmaxf(m, m2);
     if (mn != -INFINITY) s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
     m = mn;
   }
-  const float s0 = S[b];
-  const float lse1 = m + logf(s);                 // l >= 1
-  const float mx = fmaxf(lse1, s0);
-  const float lse0 = mx + logf(__expf(lse1 - mx) + __expf(s0 - mx));   // l >= 0
-  const float L = (float)(L1 - 1);
-  if (pce) pce[b] = logf(L + 1.f) - (lse0 - s0);
-  if (nmc) nmc[b] = logf(L) - (lse1 - s0);
+  sm[threadIdx.x] = m; ss[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      const float m2 = sm[threadIdx.x + w], s2 = ss[threadIdx.x + w];
+      const float m1 = sm[threadIdx.x], s1 = ss[threadIdx.x];
+      const float mn = fmaxf(m1, m2);
+      sm[threadIdx.x] = mn;
+      ss[threadIdx.x] = (mn == -INFINITY) ? 0.f : s1 * __expf(m1 - mn) + s2 * __expf(m2 - mn);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    m = sm[0]; s = ss[0];
+    const float s0 = S[b];
+    const float lse1 = m + logf(s);                 // l >= 1
+    const float mx = fmaxf(lse1, s0);
+    const float lse0 = mx + logf(__expf(lse1 - mx) + __expf(s0 - mx));   // l >= 0
+    const float L = (float)(L1 - 1);
+    if (pce) pce[b] = logf(L + 1.f) - (lse0 - s0);
+    if (nmc) nmc[b] = logf(L) - (lse1 - s0);
+  }
 }
 
 
