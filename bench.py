@@ -91,9 +91,13 @@ class HipEvents:
         assert self.hip.hipEventCreate(C.byref(self.b)) == 0
 
     def elapsed_ms(self):
+        """None when the library never recorded the pair (the launch took a path without a dominant kernel, e.g.
+        ALINE_DISABLE_FUSED=1): the caller then reports the whole graph instead."""
         ms = self.C.c_float()
-        assert self.hip.hipEventSynchronize(self.b) == 0
-        assert self.hip.hipEventElapsedTime(self.C.byref(ms), self.a, self.b) == 0
+        if self.hip.hipEventSynchronize(self.b) != 0:
+            return None
+        if self.hip.hipEventElapsedTime(self.C.byref(ms), self.a, self.b) != 0:
+            return None
         return float(ms.value)
 
 
@@ -255,7 +259,12 @@ def main():
     for _ in range(max(3, args.steps) if has_kernel_events else 0):
         ro.refresh_uniform()
         ro.run()
-        kms.append(ev.elapsed_ms())
+        torch.cuda.synchronize(device)
+        ms = ev.elapsed_ms()
+        if ms is None:
+            kms = []
+            break
+        kms.append(ms)
     ro.r.ev_kernel_start, ro.r.ev_kernel_stop = None, None
     kernel_ms = sum(kms) / len(kms) if kms else 0.0
     fl_ep = algorithmic_flops_per_episode(2, 1, args.d_model, args.d_ff, args.heads, args.layers, 10,
