@@ -180,7 +180,8 @@ int launch_attention(const Ctx &c, const float *qkv, float *out, int max_keys) {
   if (smem > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<HD>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(attention_kernel<HD>, dim3((unsigned)((c.g.B + 7) / 8 * 8 * c.m->H)), dim3(256), smem, c.st, c.g, c.m->d,
+  const unsigned nthr = (unsigned)std::min(512, std::max(256, (c.g.N + 63) / 64 * 64));   // one token row per thread when N <= 512
+  hipLaunchKernelGGL(attention_kernel<HD>, dim3((unsigned)((c.g.B + 7) / 8 * 8 * c.m->H)), dim3(nthr), smem, c.st, c.g, c.m->d,
                      qkv, out, max_keys);
   CHECK_LAUNCH();
   return ALINE_OK;
@@ -249,59 +250,48 @@ struct HeadIO {
 };
 
 // GMM head on `rows_per_ep` token rows starting at `row_off` of every episode in [b0, b0+nb)
+// GMMTargetHead (model/head.py:152-186): C grouped first layers on the matrix cores with the [3, F] second layers
+// reduced in the GEMM epilogue (raw[row][3 c + j]; the hidden activations are never stored), then the parameter
+// maps / mixture log-likelihood per row.
+static int gmm_heads(const Ctx &c, GemmArgs a, int rows, float *mean, float *sd, float *wgt, const float *value,
+                     float *ll, long value_row0, long value_mod) {
+  const aline_model &m = *c.m;
+  float *raw = c.at(c.pl.Hid);
+  const int stride = (3 * m.C + 3) / 4 * 4;
+  a.col_per_group = 0;
+  for (int k = 0; k < m.C; ++k) { a.W[k] = m.gmm_w1[k]; a.bias[k] = m.gmm_b1[k]; a.red_w[k] = m.gmm_w2[k]; a.red_b[k] = m.gmm_b2[k]; }
+  a.red_nout = 3; a.red_out = raw; a.red_stride = stride; a.red_block_stride = (long)rows * stride;
+  TRY(launch_gemm(m.precision, a, m.C, c.st));
+  CHECK_LAUNCH();
+  wide::GmmRawArgs f{};
+  f.raw = raw; f.raw_stride = stride; f.rows = rows; f.C = m.C; f.std_min = m.std_min;
+  f.nblk = gemm_col_blocks(m.F); f.blk_stride = (long)rows * stride;
+  f.mean = mean; f.sd = sd; f.wgt = wgt;
+  f.value = value; f.ll = (ll && value) ? ll : nullptr; f.value_row0 = value_row0; f.value_mod = value_mod;
+  hipLaunchKernelGGL(wide::gmm_raw_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, c.st, f);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
 int do_gmm(const Ctx &c, const float *Z, int b0, int nb, int row_off, int rows_per_ep, float *mean,
            float *sd, float *wgt, const float *value, float *ll) {
   const aline_model &m = *c.m;
   const int rows = nb * rows_per_ep;
   if (rows <= 0) return ALINE_OK;
-  float *hid = c.at(c.pl.Hid);
-  GemmArgs a = gemm_args(Z + (size_t)b0 * c.g.N * m.d, m.d, nullptr, nullptr, m.d, hid, m.C * m.F, rows,
+  GemmArgs a = gemm_args(Z + (size_t)b0 * c.g.N * m.d, m.d, nullptr, nullptr, m.d, nullptr, m.C * m.F, rows,
                          m.F, m.d, true);
   a.R_in = rows_per_ep; a.G_in = c.g.N; a.off_in = row_off;
-  a.col_per_group = m.F;
-  for (int k = 0; k < m.C; ++k) { a.W[k] = m.gmm_w1[k]; a.bias[k] = m.gmm_b1[k]; }
-  TRY(launch_gemm(m.precision, a, m.C, c.st));
-  CHECK_LAUNCH();
-  GmmFinishArgs f{};
-  f.hid = hid; f.rows = rows; f.C = m.C; f.F = m.F; f.std_min = m.std_min;
-  for (int k = 0; k < m.C; ++k) { f.w2[k] = m.gmm_w2[k]; f.b2[k] = m.gmm_b2[k]; }
   const size_t o = (size_t)b0 * rows_per_ep;
-  f.mean = mean ? mean + o * m.C : nullptr;
-  f.std = sd ? sd + o * m.C : nullptr;
-  f.weight = wgt ? wgt + o * m.C : nullptr;
-  f.R_out = 1; f.G_out = 1; f.off_out = 0;
-  f.value = value ? value + o : nullptr;
-  f.ll = (ll && value) ? ll + o : nullptr;
-  hipLaunchKernelGGL(gmm_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, c.st, f);
-  CHECK_LAUNCH();
-  return ALINE_OK;
+  return gmm_heads(c, a, rows, mean ? mean + o * m.C : nullptr, sd ? sd + o * m.C : nullptr,
+                   wgt ? wgt + o * m.C : nullptr, value ? value + o : nullptr, ll ? ll + o : nullptr, 0, rows);
 }
-
-// GMM head on a dense [rows, d] matrix of token encodings; `value` (if any) is indexed modulo
-// value_mod (the same targets are scored at every step of a rollout).
 int do_gmm_rows(const Ctx &c, const float *Zrows, int rows, float *mean, float *sd, float *wgt,
                 const float *value, float *ll, long row0, long value_mod) {
   const aline_model &m = *c.m;
   if (rows <= 0) return ALINE_OK;
-  float *hid = c.at(c.pl.Hid);
-  GemmArgs a = gemm_args(Zrows, m.d, nullptr, nullptr, m.d, hid, m.C * m.F, rows, m.F, m.d, true);
-  a.col_per_group = m.F;
-  for (int k = 0; k < m.C; ++k) { a.W[k] = m.gmm_w1[k]; a.bias[k] = m.gmm_b1[k]; }
-  TRY(launch_gemm(m.precision, a, m.C, c.st));
-  CHECK_LAUNCH();
-  GmmFinishArgs f{};
-  f.hid = hid; f.rows = rows; f.C = m.C; f.F = m.F; f.std_min = m.std_min;
-  for (int k = 0; k < m.C; ++k) { f.w2[k] = m.gmm_w2[k]; f.b2[k] = m.gmm_b2[k]; }
-  f.mean = mean; f.std = sd; f.weight = wgt;
-  f.R_out = 1; f.G_out = 1; f.off_out = 0;
-  f.value = value; f.ll = (ll && value) ? ll : nullptr;
-  f.value_row0 = row0; f.value_mod = value_mod;
-  hipLaunchKernelGGL(gmm_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, c.st, f);
-  CHECK_LAUNCH();
-  return ALINE_OK;
+  GemmArgs a = gemm_args(Zrows, m.d, nullptr, nullptr, m.d, nullptr, m.C * m.F, rows, m.F, m.d, true);
+  return gmm_heads(c, a, rows, mean, sd, wgt, value, ll, value_mod > 0 ? row0 : 0, value_mod > 0 ? value_mod : rows);
 }
-
-// AcquisitionHead + design selection (model/head.py:27-33, :347-362)
 int do_acquisition(const Ctx &c, const float *Z, HeadIO io) {
   const aline_model &m = *c.m;
   const Geo &g = c.g;
@@ -315,13 +305,18 @@ int do_acquisition(const Ctx &c, const float *Z, HeadIO io) {
     CHECK_LAUNCH();
     w1 = c.at(c.pl.Wacq);
   }
-  float *hid = c.at(c.pl.Hid);
-  GemmArgs a = gemm_args(Z, m.d, w1, m.acq_b1, ldw, hid, m.F, g.B * g.P, m.F, m.d, true);
+  // the [F] -> 1 second layer is reduced in the GEMM epilogue: logits[b * P + p], no hidden activations in memory
+  float *logits = c.at(c.pl.Hid);
+  GemmArgs a = gemm_args(Z, m.d, w1, m.acq_b1, ldw, nullptr, m.F, g.B * g.P, m.F, m.d, true);
   a.R_in = g.P; a.G_in = g.N; a.off_in = 0;
   if (m.time_token) { a.tscalar = io.time_t; a.tcol = m.acq_w1 + m.d; a.tcol_stride = m.d + 1; }
+  a.red_w[0] = m.acq_w2; a.red_b[0] = m.acq_b2; a.red_nout = 1; a.red_out = logits; a.red_stride = 1;
+  a.red_block_stride = (long)g.B * g.P;
   TRY(launch_gemm(m.precision, a, 1, c.st));
   CHECK_LAUNCH();
-  io.sel.g = g; io.sel.F = m.F; io.sel.hid = hid; io.sel.w2 = m.acq_w2; io.sel.b2 = m.acq_b2;
+  io.sel.g = g; io.sel.F = m.F; io.sel.hid = nullptr; io.sel.w2 = m.acq_w2; io.sel.b2 = m.acq_b2;
+  io.sel.logits = logits; io.sel.logit_stride = g.P;
+  io.sel.logit_nblk = gemm_col_blocks(m.F); io.sel.logit_blk_stride = (long)g.B * g.P;
   if (g.P > 1024) return ALINE_EUNSUPPORTED;
   hipLaunchKernelGGL(acq_select_kernel, dim3(g.B), dim3(256), (size_t)g.P * 8, c.st, io.sel);
   CHECK_LAUNCH();

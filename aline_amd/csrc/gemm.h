@@ -23,6 +23,13 @@ struct GemmArgs {
   int M, N, K; int relu; int accum;   // accum: Y += result
   const float *tscalar; const float *tcol; int tcol_stride;  // optional rank-1 term (time token)
   const float *mask; int ldmask;   // optional ReLU gate of a backward product: Y[m, n] = 0 where mask[m, n] <= 0
+  // optional fused second layer of a two-layer head: instead of storing Y, reduce it against red_w[grp] [red_nout, N]
+  //   red_out[row * red_stride + grp * red_nout + j] (+)= sum_n Y[row, n] * red_w[grp][j, n]  (+ red_b[grp][j] once)
+  // (hidden activations of the acquisition / GMM heads never reach memory; red_nout <= 3).  With more than one
+  // column block per row (gemm_col_blocks(N) > 1) block y writes its partial sums at red_out + y * red_block_stride
+  // and the consumer adds the blocks in order (no atomics: results stay bit-reproducible).
+  const float *red_w[GEMM_MAX_GROUPS]; const float *red_b[GEMM_MAX_GROUPS]; int red_nout; float *red_out; int red_stride;
+  long red_block_stride;
 };
 
 constexpr int GEMM_BK = 32;
@@ -185,6 +192,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       }
     }
     __syncthreads();
+    if (a.red_out) {
+      // fused second layer: SEGS = BN / 16 consecutive lanes own one row of the pass, 16 columns each
+      constexpr int SEGS = BN / 16;
+      const int row = tid / SEGS, seg = tid % SEGS;
+      const int m = m0 + 32 * q + row;
+      if (row < 32 && m < a.M) {
+        float pj[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = n0 + 16 * seg + 4 * i;
+          float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 16 * seg + 4 * i);
+          if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+          if (a.tscalar) {
+            v.x += tsc * a.tcol[(long)n * a.tcol_stride]; v.y += tsc * a.tcol[(long)(n + 1) * a.tcol_stride];
+            v.z += tsc * a.tcol[(long)(n + 2) * a.tcol_stride]; v.w += tsc * a.tcol[(long)(n + 3) * a.tcol_stride];
+          }
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (j < a.red_nout) {
+              const float *w = a.red_w[grp] + (long)j * a.N + n;
+              pj[j] += v.x * w[0] + v.y * w[1] + v.z * w[2] + v.w * w[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int o = SEGS / 2; o > 0; o >>= 1) pj[j] += __shfl_xor(pj[j], o, 64);
+        if (seg == 0) {
+          const long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
+          float *op = a.red_out + blockIdx.y * a.red_block_stride + dst * a.red_stride + grp * a.red_nout;
+          for (int j = 0; j < a.red_nout; ++j) op[j] = pj[j] + (blockIdx.y == 0 && a.red_b[grp] ? a.red_b[grp][j] : 0.f);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < PER_T; ++e) {
       const int idx = tid + e * 256, row = idx / C4, c4 = idx % C4;
@@ -212,11 +255,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   }
 }
 
+// column blocks per output row for N outputs (tile width 128 / 64 / 32 by divisibility): a fused second layer
+// (red_*) leaves that many partial sums per output
+static inline int gemm_col_blocks(int N) { return N / (N % 128 == 0 ? 128 : N % 64 == 0 ? 64 : 32); }
+
 template <int PREC>
-static int launch_gemm_prec(const GemmArgs &a, int groups, hipStream_t st) {
+static int launch_gemm_prec(const GemmArgs &a_in, int groups, hipStream_t st) {
+  const GemmArgs &a = a_in;
   if (a.K % GEMM_BK != 0 || a.N % 32 != 0 || a.M <= 0) return -2;
   // the epilogue moves float4: 16-byte aligned output rows (and gate rows)
-  if (a.ldy % 4 || a.col_per_group % 4 || (reinterpret_cast<uintptr_t>(a.Y) & 15)) return -2;
+  if (!a.red_out && (a.ldy % 4 || a.col_per_group % 4 || (reinterpret_cast<uintptr_t>(a.Y) & 15))) return -2;
+  if (a.red_out && (a.red_nout < 1 || a.red_nout > 3)) return -2;
   if (a.mask && (a.ldmask % 4 || (reinterpret_cast<uintptr_t>(a.mask) & 15))) return -2;
   dim3 block(256);
   if (a.N % 128 == 0) {

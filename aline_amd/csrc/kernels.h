@@ -75,24 +75,24 @@ __global__ void assemble_kernel(Geo g, int d, const float *__restrict__ Ex, cons
 // One workgroup per (episode, head): K_h, V_h of the key rows are staged in LDS once, every
 // thread then owns token rows and runs an online softmax over the keys.
 template <int HD>
-__global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const float *__restrict__ QKV,
+__global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const float *__restrict__ QKV,
                                                         float *__restrict__ Aout, int max_keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *Ks = reinterpret_cast<float *>(smem_raw);          // [max_keys][HD]
   float *Vs = Ks + (size_t)max_keys * HD;                   // [max_keys][HD]
   int *keyrow = reinterpret_cast<int *>(Vs + (size_t)max_keys * HD);   // [max_keys]
-  __shared__ int wave_cnt[4];
+  __shared__ int wave_cnt[8];      // blockDim.x = 256 .. 512: the smallest multiple of 64 covering the N token rows
   __shared__ int s_base;
   // the H heads of an episode read interleaved pieces of the same QKV rows: give them workgroup ids 8 apart so that
   // they run on the same XCD at about the same time and share the lines in its L2 (ids go round-robin over 8 XCDs)
   const int H = d / HD, b = (blockIdx.x / (8 * H)) * 8 + blockIdx.x % 8, h = (blockIdx.x / 8) % H;
   if (b >= g.B) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   const int n_t = g.n_td + g.n_th;
   // ordered compaction of the key rows: context points in slot order, then selected targets
   if (tid == 0) s_base = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < g.N; c0 += 256) {
+  for (int c0 = 0; c0 < g.N; c0 += nthr) {
     int row = c0 + tid;
     bool key = false;
     if (row < g.P) key = is_ctx(g, b, row);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const floa
     for (int w = 0; w < wave; ++w) off += wave_cnt[w];
     if (key) keyrow[off + __popcll(bal & ((1ull << lane) - 1ull))] = row;
     __syncthreads();
-    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (tid == 0) for (int w = 0; w < nwave; ++w) s_base += wave_cnt[w];
     __syncthreads();
   }
   const int n_ck = s_base;   // context keys
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const floa
   __syncthreads();
   const int n_ak = s_base;   // all keys (queries see these)
   const long ep = (long)b * g.N;
-  for (int i = tid; i < n_ak * HD; i += 256) {
+  for (int i = tid; i < n_ak * HD; i += nthr) {
     int j = i / HD, c = i % HD;
     const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
     Ks[j * HD + c] = src[d];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const floa
   }
   __syncthreads();
   const float scale = rsqrtf((float)HD);
-  for (int row = tid; row < g.N; row += 256) {
+  for (int row = tid; row < g.N; row += nthr) {
     const bool isq = row < g.P && !is_ctx(g, b, row);
     const int nk = isq ? n_ak : n_ck;
     float q[HD], o[HD];
@@ -220,7 +220,8 @@ struct SelectArgs {
   Geo g;
   int F;
   const float *hid, *w2, *b2;
-  const float *logits; int logit_stride;   // precomputed logits[b * logit_stride + p] (wide path), or null
+  const float *logits; int logit_stride;   // precomputed logits[b * logit_stride + p] (wide path / fused head GEMM), or null
+  int logit_nblk; long logit_blk_stride;   // ... as the sum of logit_nblk partial arrays logit_blk_stride apart
   int mode;                      // ALINE_SELECT_*
   const float *uniform;          // [B]
   const int64_t *forced; int forced_stride;   // forced[b * stride]
@@ -244,7 +245,11 @@ __global__ __launch_bounds__(256) void acq_select_kernel(SelectArgs a) {
   const int P = a.g.P;
   // logits: one wave per row, lanes over F (or precomputed by the wide path)
   if (a.logits) {
-    for (int p = tid; p < P; p += 256) logit[p] = a.logits[(long)b * a.logit_stride + p];
+    for (int p = tid; p < P; p += 256) {
+      float s = a.logits[(long)b * a.logit_stride + p];
+      for (int k = 1; k < a.logit_nblk; ++k) s += a.logits[k * a.logit_blk_stride + (long)b * a.logit_stride + p];
+      logit[p] = s;
+    }
   } else
   for (int p = wave; p < P; p += 4) {
     const float *hp = a.hid + ((long)b * P + p) * a.F;
@@ -355,60 +360,9 @@ __global__ __launch_bounds__(256) void acq_select_kernel(SelectArgs a) {
   }
 }
 
-// ---- G9/G10 epilogue: second layer of the C GMM heads + parameter maps + optional log-lik.
-// hid [rows, C*F] (grouped GEMM output, ReLU applied).  Output raw[c][j] = hid_c . w2_c[j] + b2_c[j];
-// after the reference's stack/movedim/flatten/chunk (head.py:264-265) with dim_y == 1:
-// mean_c = raw[c][0], std_c = softplus(raw[c][1]) + std_min, weight = softmax_c(raw[c][2]).
-// One wave per row.
-struct GmmFinishArgs {
-  const float *hid; long rows; int C, F;
-  const float *w2[16]; const float *b2[16];
-  float std_min;
-  float *mean, *std, *weight;            // [rows, C] (row-mapped)
-  int R_out, G_out, off_out;             // output row map (rows per episode etc.)
-  const float *value; float *ll;         // optional compute_ll, same row map
-  long value_row0, value_mod;            // value index = (value_row0 + orow) % value_mod when value_mod > 0
-};
-
-__global__ __launch_bounds__(256) void gmm_finish_kernel(GmmFinishArgs a) {
-  const int lane = threadIdx.x & 63;
-  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
-  float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;   // lane c holds component c's three outputs
-  for (int c = 0; c < a.C; ++c) {
-    const float *hp = a.hid + (row * a.C + c) * a.F;
-    const float *w = a.w2[c];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int f = lane; f < a.F; f += 64) {
-      float hv = hp[f];
-      s0 = fmaf(hv, w[f], s0);
-      s1 = fmaf(hv, w[a.F + f], s1);
-      s2 = fmaf(hv, w[2 * a.F + f], s2);
-    }
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == c) { raw0 = s0 + a.b2[c][0]; raw1 = s1 + a.b2[c][1]; raw2 = s2 + a.b2[c][2]; }
-  }
-  const bool act = lane < a.C;
-  float mean = raw0, sd = softplus_f(raw1) + a.std_min;
-  float mx = wave_max(act ? raw2 : -INFINITY);
-  float e = act ? __expf(raw2 - mx) : 0.f;
-  float wgt = e / wave_sum(e);
-  long orow = (row / a.R_out) * a.G_out + a.off_out + (row % a.R_out);
-  if (act) {
-    if (a.mean) a.mean[orow * a.C + lane] = mean;
-    if (a.std) a.std[orow * a.C + lane] = sd;
-    if (a.weight) a.weight[orow * a.C + lane] = wgt;
-  }
-  if (a.ll) {
-    // compute_ll (utils/eval.py:200-207): logsumexp_c( Normal(mean, sd).log_prob(v) + log w )
-    float v = a.value[a.value_mod > 0 ? (a.value_row0 + orow) % a.value_mod : orow];
-    float z = (v - mean) / sd;
-    float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
-    float m2 = wave_max(lp);
-    float se = wave_sum(act ? __expf(lp - m2) : 0.f);
-    if (lane == 0) a.ll[orow] = m2 + logf(se);
-  }
-}
+// (G9/G10: the second layers of the C GMM heads are reduced in the GEMM epilogue, gemm.h `red_*`; the parameter
+// maps mean_c = raw[c][0], std_c = softplus(raw[c][1]) + std_min, weight = softmax_c(raw[c][2]) -- the reference's
+// stack/movedim/flatten/chunk, head.py:264-265, with dim_y == 1 -- and compute_ll are wide::gmm_raw_finish_kernel.)
 
 // compute_ll on caller-provided GMM parameters (utils/eval.py:200-207).  One wave per row.
 __global__ __launch_bounds__(256) void compute_ll_kernel(const float *__restrict__ value,

@@ -538,19 +538,26 @@ __global__ __launch_bounds__(BTHREADS) void wide_embed_kernel(EmbedArgs a) {
 // 251-266; utils/eval.py:200-207): mean_c = raw[c][0], std_c = softplus(raw[c][1]) + std_min, weight = softmax_c(raw[c][2])
 struct GmmRawArgs {
   const float *raw; int raw_stride; long rows; int C; float std_min;
+  int nblk; long blk_stride;                     // raw = sum of nblk partial arrays blk_stride apart (0 / 1: a single one)
   float *mean, *sd, *wgt;                        // [rows, C] or null
-  const float *value; long value_mod;            // value[row % value_mod] or null
+  const float *value; long value_mod;            // value[(value_row0 + row) % value_mod] or null
+  long value_row0;
   float *ll;                                     // [rows] or null
 };
 __global__ void gmm_raw_finish_kernel(GmmRawArgs a) {
   const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= a.rows) return;
-  const float *r = a.raw + row * a.raw_stride;
+  float r[48];
+  for (int e = 0; e < 3 * a.C; ++e) {
+    float s = a.raw[row * a.raw_stride + e];
+    for (int k = 1; k < a.nblk; ++k) s += a.raw[k * a.blk_stride + row * a.raw_stride + e];
+    r[e] = s;
+  }
   float mxw = -INFINITY;
   for (int c = 0; c < a.C; ++c) mxw = fmaxf(mxw, r[3 * c + 2]);
   float sw = 0.f;
   for (int c = 0; c < a.C; ++c) sw += __expf(r[3 * c + 2] - mxw);
-  const float v = (a.ll && a.value) ? a.value[row % a.value_mod] : 0.f;
+  const float v = (a.ll && a.value) ? a.value[(a.value_row0 + row) % a.value_mod] : 0.f;
   float mx2 = -INFINITY, lps[16];
   for (int c = 0; c < a.C; ++c) {
     const float mean = r[3 * c], sd = softplus_f(r[3 * c + 1]) + a.std_min, w = __expf(r[3 * c + 2] - mxw) / sw;

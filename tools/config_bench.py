@@ -1,0 +1,92 @@
+"""Rollout throughput on the five BASELINE.json configs, one JSON object per config:
+   python tools/config_bench.py [--configs 1,2,3,5] [--steps 3]
+cfg1 al_mix dx=1 B=8 T=5 nq=32 | cfg2 location B=1000 T=30 nq=200 (d=32 and d=256/F=1024/H=8 bf16) |
+cfg3 al_mix dx=2 B=512 (one GPU's share of 4096) T=50 nq=200, split mask | cfg5 psychometric d=512 H=8 predefined
+mask T=30 nq=200 (F=128 literal config and F=2048).  cfg4 (CES EIG) is tools/eig_bench.py.
+Random-init weights, synthetic task data, sampled designs, HIP-graph replay; which kernel path ran is reported."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from aline_amd import Aline, Embedder, Encoder, OutputHead  # noqa: E402
+from aline_amd.rollout import Rollout  # noqa: E402
+from aline_amd.tasks import GPTask, HiddenLocation, PsychometricTask  # noqa: E402
+from aline_amd.utils import create_target_mask  # noqa: E402
+
+
+def build(dx, d, F, H, n_theta, emb, precision):
+    m = Aline(Embedder(dx, 1, d, F, n_theta, emb), Encoder(d, F, H, 0.0, 3), OutputHead(dx, 1, d, F)).cuda()
+    return m.set_precision(precision).train()
+
+
+def path_of(d, F, H, emb, precision, keys):
+    if precision == "f32" and (d, F, H) == (32, 128, 4) and emb == "theta":
+        return "fused::rollout_f32_kernel"
+    if precision == "bf16" and d == 256 and H == 8 and F % 64 == 0 and keys <= 64:
+        return "wide::wide_step_kernel"
+    return "generic pipeline"
+
+
+def run(name, model, batch, T, steps, meta):
+    ro = Rollout(model, batch, T, select="sample", keep_zt=False, keep_posterior=True)
+    ro.run()
+    torch.cuda.synchronize()
+    ro.capture()
+    ro.refresh_uniform(); ro.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ro.refresh_uniform()
+        ro.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    B, nq = ro.B, ro.n_q0
+    out = {"config": name, "ms_per_rollout": dt * 1e3, "designs_per_s": B * T * nq / dt, "B": B, "T": T,
+           "n_query_init": nq, "n_tokens": ro.P + ro.n_t, **meta}
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="1,2,3,5")
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    want = set(args.configs.split(","))
+    dev = torch.device("cuda")
+    torch.manual_seed(123)
+    if "1" in want:
+        task = GPTask(dim_x=1, embedding_type="mix", n_context_init=1, n_query_init=32, n_target_theta=2,
+                      n_target_data=100, device=dev)
+        m = build(1, 32, 128, 4, 2, "mix", "f32")
+        run("cfg1 al_mix dx=1 B=8 T=5", m, task.sample_batch(8), 5, args.steps,
+            {"d": 32, "precision": "f32", "path": path_of(32, 128, 4, "mix", "f32", 0)})
+    if "2" in want:
+        task = HiddenLocation(n_query_init=200, device=dev)
+        batch = task.sample_batch(1000)
+        run("cfg2 location_finding B=1000 T=30 d=32", build(2, 32, 128, 4, 2, "theta", "f32"), batch, 30, args.steps,
+            {"d": 32, "precision": "f32", "path": path_of(32, 128, 4, "theta", "f32", 32)})
+        run("cfg2 location_finding B=1000 T=30 d=256 F=1024 H=8", build(2, 256, 1024, 8, 2, "theta", "bf16"), batch, 30,
+            args.steps, {"d": 256, "precision": "bf16", "path": path_of(256, 1024, 8, "theta", "bf16", 32)})
+    if "3" in want:
+        task = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=200, n_target_theta=3,
+                      n_target_data=100, device=dev)
+        batch = task.sample_batch(512)
+        batch["target_mask"] = create_target_mask("split", "mix", 100, 3, None, None, None, None, "data")
+        run("cfg3 al_mix dx=2 B=512 (of 4096 over 8 GPUs) T=50, split mask (data)", build(2, 32, 128, 4, 3, "mix", "f32"),
+            batch, 50, args.steps, {"d": 32, "precision": "f32", "path": path_of(32, 128, 4, "mix", "f32", 0)})
+    if "5" in want:
+        task = PsychometricTask(n_query_init=200, n_context_init=1, device=dev)
+        batch = task.sample_batch(256)
+        batch["target_mask"] = torch.tensor([False, False, True, True])
+        for F in (128, 2048):
+            run(f"cfg5 psychometric B=256 T=30 d=512 F={F} H=8, predefined mask", build(1, 512, F, 8, 4, "theta", "bf16"),
+                batch, 30, args.steps, {"d": 512, "precision": "bf16", "path": path_of(512, F, 8, "theta", "bf16", 0)})
+
+
+if __name__ == "__main__":
+    main()
