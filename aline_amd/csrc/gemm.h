@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   }
 
   const int fr = lane & 15, fg = lane >> 4;
-  for (int k0 = 0; k0 < a.K; k0 += GEMM_BK) {
-    float4 av[A_IT], bv[B_IT];
+  // software pipeline: the global loads of k-step s + 1 are issued before the MFMAs of step s and land while they
+  // run (one LDS buffer, two barriers per step; the operands of the next step wait in registers)
+  float4 av[A_IT], bv[B_IT];
+  auto load_step = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
       av[i] = aok[i] ? *reinterpret_cast<const float4 *>(arow[i] + k0) : make_float4(0, 0, 0, 0);
@@ -110,6 +112,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       int idx = tid + i * 256, row = idx >> 3;
       bv[i] = *reinterpret_cast<const float4 *>(W + (long)(n0 + row) * a.ldw + k0 + (idx & 7) * 4);
     }
+  };
+  load_step(0);
+  for (int k0 = 0; k0 < a.K; k0 += GEMM_BK) {
     __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       lds_store4<PREC>(Bs, B_ELEMS, idx >> 3, (idx & 7) * 4, bv[i]);
     }
     __syncthreads();
+    if (k0 + GEMM_BK < a.K) load_step(k0 + GEMM_BK);
 
     if constexpr (PREC == 0) {
 #pragma unroll
