@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
     Vs[j * HD + c] = src[2 * d];
   }
   __syncthreads();
-  const float scale = rsqrtf((float)HD);
+  const float scale = rsqrtf((float)HD) * 1.44269504088896340736f;   // 1/sqrt(hd) * log2(e)
   for (int row = tid; row < g.N; row += nthr) {
     const bool isq = row < g.P && !is_ctx(g, b, row);
     const int nk = isq ? n_ak : n_ck;
@@ -136,16 +136,43 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
       q[c] = qv.x * scale; q[c + 1] = qv.y * scale; q[c + 2] = qv.z * scale; q[c + 3] = qv.w * scale;
       o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
     }
+    // online softmax over the keys in groups of four: one running-max rescale per group, exponentials in base 2
+    // (log2(e) is folded into the query scale)
     float mx = -INFINITY, l = 0.f;
-    for (int j = 0; j < nk; ++j) {
-      float s = 0.f;
+    int j = 0;
+    for (; j + 4 <= nk; j += 4) {
+      float sc[4];
 #pragma unroll
-      for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j * HD + c], s);
-      float mn = fmaxf(mx, s);
-      float corr = __expf(mx - mn), p = __expf(s - mn);
-      l = l * corr + p;
+      for (int u = 0; u < 4; ++u) {
+        float t = 0.f;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) o[c] = fmaf(p, Vs[j * HD + c], o[c] * corr);
+        for (int c = 0; c < HD; ++c) t = fmaf(q[c], Ks[(j + u) * HD + c], t);
+        sc[u] = t;
+      }
+      const float mn = fmaxf(fmaxf(mx, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
+      const float corr = exp2f(mx - mn);
+      float pr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pr[u] = exp2f(sc[u] - mn);
+      l = l * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        float acc = o[c] * corr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = fmaf(pr[u], Vs[(j + u) * HD + c], acc);
+        o[c] = acc;
+      }
+      mx = mn;
+    }
+    for (; j < nk; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) t = fmaf(q[c], Ks[j * HD + c], t);
+      const float mn = fmaxf(mx, t);
+      const float corr = exp2f(mx - mn), pw = exp2f(t - mn);
+      l = l * corr + pw;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(pw, Vs[j * HD + c], o[c] * corr);
       mx = mn;
     }
     float inv = 1.f / l;
