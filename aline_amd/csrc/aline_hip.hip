@@ -7,6 +7,7 @@
 #include "eig.h"
 #include "fused_rollout.h"
 #include "fused_side.h"
+#include "fused_tail.h"
 #include "wide.h"
 #include "wide_step.h"
 #include "backward.h"
@@ -210,6 +211,26 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
         *Tm = c.at(c.pl.Tm), *Hid = c.at(c.pl.Hid);
   const float *cur = x_in;
   const int hd = d / m.H;
+  // small-width model in reference precision: the token-local tail of a layer (out-projection, LN1, FFN, LN2) is
+  // one kernel on the packed layer images of the fused path (fused_tail.h)
+  const bool tail = m.precision == ALINE_PREC_F32 && d == fused::D && F == fused::F && !getenv("ALINE_NO_LAYER_TAIL");
+  float *wimg = c.at(c.pl.Wpack);
+  if (tail) {
+    fused::PackArgs pa{};
+    pa.L = m.L; pa.layers_only = 1; pa.out = wimg;
+    for (int l = 0; l < m.L; ++l) {
+      pa.in_proj_w[l] = m.in_proj_w[l]; pa.in_proj_b[l] = m.in_proj_b[l];
+      pa.out_proj_w[l] = m.out_proj_w[l]; pa.out_proj_b[l] = m.out_proj_b[l];
+      pa.lin1_w[l] = m.lin1_w[l]; pa.lin1_b[l] = m.lin1_b[l];
+      pa.lin2_w[l] = m.lin2_w[l]; pa.lin2_b[l] = m.lin2_b[l];
+      pa.n1w[l] = m.norm1_w[l]; pa.n1b[l] = m.norm1_b[l];
+      pa.n2w[l] = m.norm2_w[l]; pa.n2b[l] = m.norm2_b[l];
+    }
+    hipLaunchKernelGGL(fused::pack_weights_kernel, dim3(64), dim3(256), 0, c.st, pa);
+    CHECK_LAUNCH();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::layer_tail_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fused::LAYER_FLOATS * sizeof(float)));
+  }
   for (int l = 0; l < m.L; ++l) {
     TRY(launch_gemm(m.precision, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, 3 * d, M,
                                            3 * d, d, false), 1, c.st));
@@ -222,6 +243,17 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
       case 64: TRY(launch_attention<64>(c, QKV, A, max_keys)); break;
       case 128: TRY(launch_attention<128>(c, QKV, A, max_keys)); break;
       default: return ALINE_EUNSUPPORTED;
+    }
+    if (tail) {
+      float *dst = (l == m.L - 1 && x_out) ? x_out : X;
+      fused::TailArgs ta{A, cur, dst, (long)M, wimg + (size_t)l * fused::LAYER_FLOATS};
+      const long groups = ((long)M + 31) / 32;
+      const unsigned grid = (unsigned)std::min<long>((groups + 7) / 8, 512);     // 2 workgroups per CU, each loops
+      hipLaunchKernelGGL(fused::layer_tail_kernel, dim3(grid), dim3(fused::TAIL_THREADS),
+                         fused::LAYER_FLOATS * sizeof(float), c.st, ta);
+      CHECK_LAUNCH();
+      cur = dst;
+      continue;
     }
     TRY(launch_gemm(m.precision, gemm_args(A, d, m.out_proj_w[l], m.out_proj_b[l], d, Tm, d, M, d, d,
                                            false), 1, c.st));
