@@ -92,7 +92,6 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void layer_tail_kernel(TailArgs a)
         x[t][0] = b0 + x1[t][0]; x[t][1] = b1 + x1[t][1];
         x1f[t] = split_acc(x1[t][0], x1[t][1]);
       }
-#ifndef TAIL_SKIP_FFN
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         const Frag3 u0 = ld_frag3(Wf + (F1 + 2 * kb) * FRAG3, lane), u1 = ld_frag3(Wf + (F1 + 2 * kb + 1) * FRAG3, lane);
@@ -109,7 +108,6 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void layer_tail_kernel(TailArgs a)
           mma6x2(x[t][0], x[t][1], d0, d1, hf);
         }
       }
-#endif
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
