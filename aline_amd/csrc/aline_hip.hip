@@ -288,6 +288,26 @@ struct HeadIO {
 static int gmm_heads(const Ctx &c, GemmArgs a, int rows, float *mean, float *sd, float *wgt, const float *value,
                      float *ll, long value_row0, long value_mod) {
   const aline_model &m = *c.m;
+  if (m.precision == ALINE_PREC_F32 && m.d == fused::D && m.F == fused::F && !getenv("ALINE_NO_LAYER_TAIL")) {
+    // small-width model: all C heads, the parameter maps and compute_ll in one kernel on the transposed register
+    // scheme of the fused path (fused_side.h), first layers as packed split-bf16 fragments
+    float *side = c.at(c.pl.Wpack) + (size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS;
+    fused::PackArgs pa{};
+    pa.layers_only = 2; pa.C = m.C; pa.out = side;
+    for (int k = 0; k < m.C; ++k) pa.gmm_w1[k] = m.gmm_w1[k];
+    hipLaunchKernelGGL(fused::pack_weights_kernel, dim3(60), dim3(256), 0, c.st, pa);
+    CHECK_LAUNCH();
+    fused::GmmRowsArgs ga{};
+    ga.z = a.X; ga.rows = rows; ga.zR = a.R_in; ga.zG = a.G_in; ga.zoff = a.off_in;
+    ga.C = m.C; ga.std_min = m.std_min; ga.w1img = side;
+    for (int k = 0; k < m.C; ++k) { ga.b1[k] = m.gmm_b1[k]; ga.w2[k] = m.gmm_w2[k]; ga.b2[k] = m.gmm_b2[k]; }
+    ga.mean = mean; ga.sd = sd; ga.wgt = wgt;
+    ga.value = value; ga.value_row0 = value_row0; ga.value_mod = value_mod;
+    ga.ll = (ll && value) ? ll : nullptr;
+    hipLaunchKernelGGL(fused::gmm_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, c.st, ga);
+    CHECK_LAUNCH();
+    return ALINE_OK;
+  }
   float *raw = c.at(c.pl.Hid);
   const int stride = (3 * m.C + 3) / 4 * 4;
   a.col_per_group = 0;

@@ -53,7 +53,8 @@ struct PackArgs {
   const float *gmm_w1[16];                      //   C x 8 split-bf16 fragments of the GMM first layers
   const float *x_w2, *y_w2;                     //   8 + 8 fragments of the point embedders' second layers
   float *out;   // [L * LAYER_FLOATS + HEAD_FLOATS + (C + 2) * 8 * FRAG3]
-  int layers_only;   // pack the L layer images only (layer_tail_kernel of the generic pipeline: no head pointers needed)
+  int layers_only;   // 1: pack the L layer images only (layer_tail_kernel of the generic pipeline: no head pointers needed)
+                     // 2: pack the C GMM first-layer images only, at out[0 ..)
 };
 constexpr int SIDE_FRAGS = 8 * FRAG3;          // one [128 x 32] or [32 x 128] weight as 8 fragments
 
@@ -85,8 +86,15 @@ __device__ __forceinline__ float frag3_word(const float *W, int K, int mt, int k
 }
 
 __global__ void pack_weights_kernel(PackArgs a) {
+  if (a.layers_only == 2) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.C * SIDE_FRAGS; i += gridDim.x * blockDim.x) {
+      const int img = i / SIDE_FRAGS, e = i % SIDE_FRAGS;
+      a.out[i] = frag3_word(a.gmm_w1[img], D, e / FRAG3, 0, e % FRAG3);
+    }
+    return;
+  }
   const int core = a.L * LAYER_FLOATS + HEAD_FLOATS;
-  const int total = a.layers_only ? a.L * LAYER_FLOATS : core + (a.C + 2) * SIDE_FRAGS;
+  const int total = a.layers_only == 1 ? a.L * LAYER_FLOATS : core + (a.C + 2) * SIDE_FRAGS;
   // 1/sqrt(hd) and log2(e) folded into Wq, bq: the kernel's softmax is exp2(s - max)
   const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {

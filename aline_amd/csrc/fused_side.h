@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void embed_points_kernel(EmbedArgs a) {
 // hidden^T = relu(W1 z + b1) for its tile (8 blocks x 6 passes) and folds the 3-output second layer
 // into the accumulator layout with FMAs + one lane-group reduction per output.
 struct GmmRowsArgs {
-  const float *z; long rows;                   // [rows, 32]
+  const float *z; long rows;                   // [rows, 32]; input row of `row` = (row / zR) * zG + zoff + row % zR when zR > 0
+  int zR, zG, zoff;                            // (the target rows of every episode inside a [B * N, 32] activation)
   int C; float std_min;
   const float *w1img;                          // C x 8 packed split-bf16 fragments of the first layers
   const float *b1[16], *w2[16], *b2[16];
@@ -82,7 +83,10 @@ __global__ __launch_bounds__(256) void gmm_rows_kernel(GmmRowsArgs a) {
   const long row = ((long)blockIdx.x * 4 + wave) * 16 + tok;
   const bool ok = row < a.rows;
   f32x4 z0 = zero4(), z1 = zero4();
-  if (ok) { z0 = ld4(a.z + row * D + 4 * g); z1 = ld4(a.z + row * D + 16 + 4 * g); }
+  if (ok) {
+    const long zr = a.zR > 0 ? (row / a.zR) * a.zG + a.zoff + row % a.zR : row;
+    z0 = ld4(a.z + zr * D + 4 * g); z1 = ld4(a.z + zr * D + 16 + 4 * g);
+  }
   const Frag3 zf = split_acc(z0, z1);
   float raw[16][3];
 #pragma unroll 1
