@@ -304,7 +304,7 @@ static int gmm_heads(const Ctx &c, GemmArgs a, int rows, float *mean, float *sd,
     ga.mean = mean; ga.sd = sd; ga.wgt = wgt;
     ga.value = value; ga.value_row0 = value_row0; ga.value_mod = value_mod;
     ga.ll = (ll && value) ? ll : nullptr;
-    hipLaunchKernelGGL(fused::gmm_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, c.st, ga);
+    hipLaunchKernelGGL(fused::gmm_rows_kernel, dim3((unsigned)((rows + fused::GMM_THREADS * fused::GMM_TILES / 4 - 1) / (fused::GMM_THREADS * fused::GMM_TILES / 4))), dim3(fused::GMM_THREADS), 0, c.st, ga);
     CHECK_LAUNCH();
     return ALINE_OK;
   }
@@ -689,7 +689,7 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
     ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
     ga.value = r->target_all; ga.value_row0 = 0; ga.value_mod = (long)r->B * m->n_theta;
     ga.ll = r->target_all ? r->target_ll : nullptr;
-    hipLaunchKernelGGL(fused::gmm_rows_kernel, dim3((unsigned)((ga.rows + 63) / 64)), dim3(256), 0, c.st, ga);
+    hipLaunchKernelGGL(fused::gmm_rows_kernel, dim3((unsigned)((ga.rows + fused::GMM_THREADS * fused::GMM_TILES / 4 - 1) / (fused::GMM_THREADS * fused::GMM_TILES / 4))), dim3(fused::GMM_THREADS), 0, c.st, ga);
     CHECK_LAUNCH();
   }
   return ALINE_OK;

@@ -76,75 +76,100 @@ struct GmmRowsArgs {
   float *ll;                                   // [rows] or null
 };
 
-__global__ __launch_bounds__(256) void gmm_rows_kernel(GmmRowsArgs a) {
+constexpr int GMM_TILES = 2, GMM_THREADS = 512;   // 8 waves x 2 token tiles: a head's first-layer image (24 KB) is staged once per 256 rows
+
+__global__ __launch_bounds__(GMM_THREADS) void gmm_rows_kernel(GmmRowsArgs a) {
   __shared__ __attribute__((aligned(16))) float W1f[8 * FRAG3];   // 24 KB
   __shared__ float b1s[F], w2s[3 * F], b2s[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
-  const long row = ((long)blockIdx.x * 4 + wave) * 16 + tok;
-  const bool ok = row < a.rows;
-  f32x4 z0 = zero4(), z1 = zero4();
-  if (ok) {
-    const long zr = a.zR > 0 ? (row / a.zR) * a.zG + a.zoff + row % a.zR : row;
-    z0 = ld4(a.z + zr * D + 4 * g); z1 = ld4(a.z + zr * D + 16 + 4 * g);
+  long row[GMM_TILES];
+  bool ok[GMM_TILES];
+  Frag3 zf[GMM_TILES];
+#pragma unroll
+  for (int t = 0; t < GMM_TILES; ++t) {
+    row[t] = (((long)blockIdx.x * (GMM_THREADS / 64) + wave) * GMM_TILES + t) * 16 + tok;
+    ok[t] = row[t] < a.rows;
+    f32x4 z0 = zero4(), z1 = zero4();
+    if (ok[t]) {
+      const long zr = a.zR > 0 ? (row[t] / a.zR) * a.zG + a.zoff + row[t] % a.zR : row[t];
+      z0 = ld4(a.z + zr * D + 4 * g); z1 = ld4(a.z + zr * D + 16 + 4 * g);
+    }
+    zf[t] = split_acc(z0, z1);
   }
-  const Frag3 zf = split_acc(z0, z1);
-  float raw[16][3];
+  float raw[GMM_TILES][16][3];
 #pragma unroll 1
   for (int c = 0; c < a.C; ++c) {
     __syncthreads();
-    for (int i = tid; i < 8 * FRAG3 / 4; i += 256)
+    for (int i = tid; i < 8 * FRAG3 / 4; i += GMM_THREADS)
       reinterpret_cast<f32x4 *>(W1f)[i] = reinterpret_cast<const f32x4 *>(a.w1img + (long)c * SIDE_FRAGS)[i];
-    for (int i = tid; i < F; i += 256) b1s[i] = a.b1[c][i];
-    for (int i = tid; i < 3 * F; i += 256) w2s[i] = a.w2[c][i];
+    for (int i = tid; i < F; i += GMM_THREADS) b1s[i] = a.b1[c][i];
+    for (int i = tid; i < 3 * F; i += GMM_THREADS) w2s[i] = a.w2[c][i];
     if (tid < 3) b2s[tid] = a.b2[c][tid];
     __syncthreads();
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    float p[GMM_TILES][3];
+#pragma unroll
+    for (int t = 0; t < GMM_TILES; ++t) p[t][0] = p[t][1] = p[t][2] = 0.f;
 #pragma unroll
     for (int mp = 0; mp < 4; ++mp) {
-      f32x4 h0 = ld4(b1s + 32 * mp + 4 * g), h1 = ld4(b1s + 32 * mp + 16 + 4 * g);
-      mma6x2(h0, h1, ld_frag3(W1f + (2 * mp) * FRAG3, lane), ld_frag3(W1f + (2 * mp + 1) * FRAG3, lane), zf);
+      const Frag3 u0 = ld_frag3(W1f + (2 * mp) * FRAG3, lane), u1 = ld_frag3(W1f + (2 * mp + 1) * FRAG3, lane);
+      const f32x4 hb0 = ld4(b1s + 32 * mp + 4 * g), hb1 = ld4(b1s + 32 * mp + 16 + 4 * g);
+      f32x4 h0[GMM_TILES], h1[GMM_TILES];
+#pragma unroll
+      for (int t = 0; t < GMM_TILES; ++t) { h0[t] = hb0; h1[t] = hb1; mma6x2(h0[t], h1[t], u0, u1, zf[t]); }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float a0 = relu_nn(h0[r]), a1 = relu_nn(h1[r]);
-        const int u0 = 32 * mp + 4 * g + r, u1 = u0 + 16;
-        p0 = fmaf(a0, w2s[u0], p0); p0 = fmaf(a1, w2s[u1], p0);
-        p1 = fmaf(a0, w2s[F + u0], p1); p1 = fmaf(a1, w2s[F + u1], p1);
-        p2 = fmaf(a0, w2s[2 * F + u0], p2); p2 = fmaf(a1, w2s[2 * F + u1], p2);
+        const int u0i = 32 * mp + 4 * g + r, u1i = u0i + 16;
+        const float wa0 = w2s[u0i], wb0 = w2s[u1i], wa1 = w2s[F + u0i], wb1 = w2s[F + u1i], wa2 = w2s[2 * F + u0i],
+                    wb2 = w2s[2 * F + u1i];
+#pragma unroll
+        for (int t = 0; t < GMM_TILES; ++t) {
+          const float a0 = relu_nn(h0[t][r]), a1 = relu_nn(h1[t][r]);
+          p[t][0] = fmaf(a0, wa0, p[t][0]); p[t][0] = fmaf(a1, wb0, p[t][0]);
+          p[t][1] = fmaf(a0, wa1, p[t][1]); p[t][1] = fmaf(a1, wb1, p[t][1]);
+          p[t][2] = fmaf(a0, wa2, p[t][2]); p[t][2] = fmaf(a1, wb2, p[t][2]);
+        }
       }
     }
-    const float r0 = group_sum(p0) + b2s[0], r1 = group_sum(p1) + b2s[1], r2 = group_sum(p2) + b2s[2];
-    // static register file: write component c through a wave-uniform switch
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc)
-      if (cc == c) { raw[cc][0] = r0; raw[cc][1] = r1; raw[cc][2] = r2; }
-  }
-  if (!ok || g != 0) return;
-  // parameter maps (head.py:176-177) and compute_ll (eval.py:200-207), one lane per row
-  float mxw = -INFINITY;
+    for (int t = 0; t < GMM_TILES; ++t) {
+      const float r0 = group_sum(p[t][0]) + b2s[0], r1 = group_sum(p[t][1]) + b2s[1], r2 = group_sum(p[t][2]) + b2s[2];
+      // static register file: write component c through a wave-uniform switch
 #pragma unroll
-  for (int c = 0; c < 16; ++c) if (c < a.C) mxw = fmaxf(mxw, raw[c][2]);
-  float sw = 0.f;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) if (c < a.C) sw += __expf(raw[c][2] - mxw);
-  const float v = (a.ll && a.value) ? a.value[a.value_mod > 0 ? (a.value_row0 + row) % a.value_mod : row] : 0.f;
-  float lps[16], mx2 = -INFINITY;
-#pragma unroll
-  for (int c = 0; c < 16; ++c)
-    if (c < a.C) {
-      const float mean = raw[c][0], sd = softplus_f(raw[c][1]) + a.std_min;
-      const float w = __expf(raw[c][2] - mxw) / sw;
-      if (a.mean) a.mean[row * a.C + c] = mean;
-      if (a.sd) a.sd[row * a.C + c] = sd;
-      if (a.wgt) a.wgt[row * a.C + c] = w;
-      const float zz = (v - mean) / sd;
-      lps[c] = -0.5f * zz * zz - logf(sd) - 0.91893853320467274178f + logf(w);
-      mx2 = fmaxf(mx2, lps[c]);
+      for (int cc = 0; cc < 16; ++cc)
+        if (cc == c) { raw[t][cc][0] = r0; raw[t][cc][1] = r1; raw[t][cc][2] = r2; }
     }
-  if (a.ll && a.value) {
-    float se = 0.f;
+  }
+  if (g != 0) return;
+  // parameter maps (head.py:176-177) and compute_ll (eval.py:200-207), one lane per row
 #pragma unroll
-    for (int c = 0; c < 16; ++c) if (c < a.C) se += __expf(lps[c] - mx2);
-    a.ll[row] = mx2 + logf(se);
+  for (int t = 0; t < GMM_TILES; ++t) {
+    if (!ok[t]) continue;
+    float mxw = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < a.C) mxw = fmaxf(mxw, raw[t][c][2]);
+    float sw = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < a.C) sw += __expf(raw[t][c][2] - mxw);
+    const float v = (a.ll && a.value) ? a.value[a.value_mod > 0 ? (a.value_row0 + row[t]) % a.value_mod : row[t]] : 0.f;
+    float lps[16], mx2 = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < a.C) {
+        const float mean = raw[t][c][0], sd = softplus_f(raw[t][c][1]) + a.std_min;
+        const float w = __expf(raw[t][c][2] - mxw) / sw;
+        if (a.mean) a.mean[row[t] * a.C + c] = mean;
+        if (a.sd) a.sd[row[t] * a.C + c] = sd;
+        if (a.wgt) a.wgt[row[t] * a.C + c] = w;
+        const float zz = (v - mean) / sd;
+        lps[c] = -0.5f * zz * zz - logf(sd) - 0.91893853320467274178f + logf(w);
+        mx2 = fmaxf(mx2, lps[c]);
+      }
+    if (a.ll && a.value) {
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) if (c < a.C) se += __expf(lps[c] - mx2);
+      a.ll[row[t]] = mx2 + logf(se);
+    }
   }
 }
 
