@@ -274,7 +274,11 @@ static int launch_gemm_prec(const GemmArgs &a_in, int groups, hipStream_t st) {
   if (a.red_out && (a.red_nout < 1 || a.red_nout > 3)) return -2;
   if (a.mask && (a.ldmask % 4 || (reinterpret_cast<uintptr_t>(a.mask) & 15))) return -2;
   dim3 block(256);
-  if (a.N % 128 == 0) {
+  if (!a.red_out && a.N % 96 == 0 && a.N % 128 != 0) {
+    // in-projection of the small models (N = 3 d = 96 at d = 32): one column block, every input row is read once
+    dim3 grid((a.M + 127) / 128, a.N / 96, groups);
+    hipLaunchKernelGGL((gemm_nt_kernel<PREC, 128, 96, 4, 1>), grid, block, 0, st, a);
+  } else if (a.N % 128 == 0) {
     dim3 grid((a.M + 127) / 128, a.N / 128, groups);
     hipLaunchKernelGGL((gemm_nt_kernel<PREC, 128, 128, 2, 2>), grid, block, 0, st, a);
   } else if (a.N % 64 == 0) {
