@@ -301,10 +301,14 @@ def main():
     elif wide:
         # dominant kernel of the wide path: wide::wide_step_kernel -- one launch = the whole encoder stack + the
         # acquisition head of ONE rollout step for all B episodes (T launches per rollout); the events bracket
-        # the launch of the last step (t = T-1), whose algorithmic FLOPs are those of that step alone.
-        fl_last = (fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
-                   - fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T - 1))
-        per_launch = fl_last * args.batch
+        # the launch of the last step (t = T-1).
+        fl_all = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
+        fl_last = fl_all - fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2,
+                                                          args.T - 1)
+        # the T launches of a rollout take the same time (the kernel always runs 16 token tiles per episode) while the
+        # algorithmic FLOPs shrink with the query set: `achieved` pairs the AVERAGE launch (total / T) with the
+        # launch duration; the last step alone (fewest queries) is reported beside it
+        per_launch = fl_all / args.T * args.batch
         achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
         kname, peak, traffic = "wide::wide_step_kernel<false>", PEAK_BF16_DENSE_TFLOPS, None
         try:
@@ -313,6 +317,9 @@ def main():
         except Exception:
             traffic = None
         extra = {"launches_per_rollout": args.T,
+                 "last_step": {"algorithmic_flops": fl_last * args.batch,
+                               "achieved": fl_last * args.batch / (kernel_ms * 1e-3) / 1e12,
+                               "frac": fl_last * args.batch / (kernel_ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS},
                  "traffic_source": "rocprofv3 PMC (profiles/r01_wide_bf16_d256_pmc_traffic.json), average step, not re-measured in this run",
                  "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
                  "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md).  Algorithmic FLOPs as the reference "
