@@ -65,19 +65,25 @@ def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=4
     return math.log(L + 1) - pce, math.log(L) - nmc
 
 
-@torch.no_grad()
-def eval_boed(model, experiment, T=30, L=int(1e6), M=2000, batch_size=40, time_token=False, stepwise=False,
-              err_type="se"):
-    """Final evaluation of the EIG bounds (eval.py:142-198): ceil(M / batch) x (rollout, bounds)."""
+def gather_rows(local, dist=None, world=1):
+    """Concatenation over the ranks of per-rank [n_r, ...] tensors with different n_r, in rank order, on every rank
+    (one all_gather of the counts, one of the zero-padded blocks)."""
+    if dist is None or world <= 1:
+        return local
+    n = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    pad = torch.zeros((max(counts),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    blocks = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(blocks, pad)
+    return torch.cat([b[:c] for b, c in zip(blocks, counts)], dim=0)
+
+
+def bound_statistics(pce, nmc, err_type="se"):
+    """Mean and error bar of the bounds over the outer samples (eval.py:176-196)."""
     from .attrdict import AttrDict
-    model.eval()
-    pce_l, nmc_l = [], []
-    for _ in range((M + batch_size - 1) // batch_size):
-        theta_0, x, y = get_traces(model, experiment, T, batch_size, time_token)
-        pce, nmc = compute_EIG_from_history(experiment, theta_0, x, y, L, batch_size, stepwise)
-        pce_l.append(pce)
-        nmc_l.append(nmc)
-    pce, nmc = torch.cat(pce_l, dim=0), torch.cat(nmc_l, dim=0)
     n = pce.shape[0]
     out = {}
     for nm, v in (("pce", pce), ("nmc", nmc)):
@@ -90,3 +96,25 @@ def eval_boed(model, experiment, T=30, L=int(1e6), M=2000, batch_size=40, time_t
             raise ValueError(f"Unknown err_type: {err_type}")
         out[nm + "_mean"], out[nm + "_err"] = torch.mean(v, dim=0).cpu(), err.cpu()
     return AttrDict(out)
+
+
+@torch.no_grad()
+def eval_boed(model, experiment, T=30, L=int(1e6), M=2000, batch_size=40, time_token=False, stepwise=False,
+              err_type="se", dist=None, world=1, rank=0):
+    """Final evaluation of the EIG bounds (eval.py:142-198): ceil(M / batch) x (rollout, bounds).  The outer
+    batches are independent: with `dist` (torch.distributed, one process per GPU) rank r evaluates batches
+    r, r + world, ... and every rank returns the statistics over all of them."""
+    model.eval()
+    pce_l, nmc_l = [], []
+    for i in range((M + batch_size - 1) // batch_size):
+        if i % world != rank:
+            continue
+        theta_0, x, y = get_traces(model, experiment, T, batch_size, time_token)
+        pce, nmc = compute_EIG_from_history(experiment, theta_0, x, y, L, batch_size, stepwise)
+        pce_l.append(pce)
+        nmc_l.append(nmc)
+    dev = next(model.parameters()).device
+    shape = (0, T) if stepwise else (0,)
+    pce = torch.cat(pce_l, dim=0) if pce_l else torch.zeros(shape, device=dev)
+    nmc = torch.cat(nmc_l, dim=0) if nmc_l else torch.zeros(shape, device=dev)
+    return bound_statistics(gather_rows(pce, dist, world), gather_rows(nmc, dist, world), err_type)

@@ -77,3 +77,37 @@ def test_flat_bucket_gradient_all_reduce_averages_over_ranks():
     means = out.get(timeout=120)
     [p.join(60) for p in procs]
     assert means == [1.5 * (i + 1) for i in range(4)]     # mean of rank values (1, 2) * (i + 1)
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aline_amd.utils.eval import bound_statistics, gather_rows
+    # rank r holds outer batches r, r + world, ... of 5 batches of 4 samples each (uneven: 3 vs 2 batches), T = 3
+    mine = [i for i in range(5) if i % world == rank]
+    pce = torch.cat([torch.arange(4 * 3, dtype=torch.float32).reshape(4, 3) + 100 * i for i in mine])
+    got = gather_rows(pce, dist, world)
+    stats = bound_statistics(got, -got, "se")
+    if rank == 0:
+        out.put((got, stats["pce_mean"], stats["nmc_err"]))
+    dist.destroy_process_group()
+
+
+def test_eval_bounds_gather_over_ranks():
+    """eval_boed shards the outer batches over the ranks; every rank must end with all of them (rank order) and
+    the statistics of the single-process evaluation."""
+    from aline_amd.utils.eval import bound_statistics
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, out)) for r in range(world)]
+    [p.start() for p in procs]
+    got, mean, err = out.get(timeout=120)
+    [p.join(60) for p in procs]
+    blocks = {i: torch.arange(12, dtype=torch.float32).reshape(4, 3) + 100 * i for i in range(5)}
+    expect = torch.cat([blocks[i] for i in (0, 2, 4, 1, 3)])            # rank 0's batches, then rank 1's
+    assert torch.equal(got, expect)
+    ref = bound_statistics(expect, -expect, "se")
+    assert torch.allclose(mean, ref["pce_mean"]) and torch.allclose(err, ref["nmc_err"])
+    single = bound_statistics(torch.cat([blocks[i] for i in range(5)]), -torch.cat([blocks[i] for i in range(5)]), "se")
+    assert torch.allclose(mean, single["pce_mean"]) and torch.allclose(err, single["nmc_err"])   # order-independent
