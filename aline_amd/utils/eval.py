@@ -114,7 +114,7 @@ def eval_boed(model, experiment, T=30, L=int(1e6), M=2000, batch_size=40, time_t
         pce_l.append(pce)
         nmc_l.append(nmc)
     dev = next(model.parameters()).device
-    shape = (0, T) if stepwise else (0,)
+    shape = (0, getattr(experiment, "n_context_init", 1) + T) if stepwise else (0,)   # a rank without batches
     pce = torch.cat(pce_l, dim=0) if pce_l else torch.zeros(shape, device=dev)
     nmc = torch.cat(nmc_l, dim=0) if nmc_l else torch.zeros(shape, device=dev)
     return bound_statistics(gather_rows(pce, dist, world), gather_rows(nmc, dist, world), err_type)
