@@ -179,22 +179,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   // through LDS 32 rows at a time so that bias / ReLU / gate / accumulate and the store run on whole output rows
   // (float4 per lane, BN * 4 contiguous bytes per row) instead of 64-byte column segments.
   constexpr int LDC = BN + 4;
-  static_assert(32 * LDC * sizeof(float) <= sizeof(smem), "epilogue tile must fit the operand buffers");
+  constexpr int RP = 32 * LDC * sizeof(float) <= sizeof(smem) ? 32 : 16;     // rows per pass
+  static_assert(RP * LDC * sizeof(float) <= sizeof(smem), "epilogue tile must fit the operand buffers");
   float *Cs = reinterpret_cast<float *>(smem);
   const float *bias = a.bias[grp];
   const float tsc = a.tscalar ? a.tscalar[0] : 0.f;
-  constexpr int C4 = BN / 4, PER_T = 32 * C4 / 256;       // float4 per thread and pass (BN = 32: 1, 64: 2, 128: 4)
+  constexpr int C4 = BN / 4, PER_T = RP * C4 / 256;       // float4 per thread and pass (BN = 32: 1, 64: 2, 128: 4)
+  static_assert(RP * C4 % 256 == 0, "whole float4 rounds per pass");
 #pragma unroll
-  for (int q = 0; q < BM / 32; ++q) {
+  for (int q = 0; q < BM / RP; ++q) {
     __syncthreads();                                       // fragment reads / previous pass done
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rbase = wm * WM + 16 * i;
-      if (rbase / 32 == q) {
+      if (rbase / RP == q) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(rbase % 32 + fg * 4 + r) * LDC + wn * WN + 16 * j + fr] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r) Cs[(rbase % RP + fg * 4 + r) * LDC + wn * WN + 16 * j + fr] = acc[i][j][r];
       }
     }
     __syncthreads();
@@ -202,8 +204,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       // fused second layer: SEGS = BN / 16 consecutive lanes own one row of the pass, 16 columns each
       constexpr int SEGS = BN / 16;
       const int row = tid / SEGS, seg = tid % SEGS;
-      const int m = m0 + 32 * q + row;
-      if (row < 32 && m < a.M) {
+      const int m = m0 + RP * q + row;
+      if (row < RP && m < a.M) {
         float pj[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
     for (int e = 0; e < PER_T; ++e) {
       const int idx = tid + e * 256, row = idx / C4, c4 = idx % C4;
-      const int m = m0 + 32 * q + row, n = n0 + 4 * c4;
+      const int m = m0 + RP * q + row, n = n0 + 4 * c4;
       if (m >= a.M) continue;
       float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * c4);
       if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
