@@ -954,7 +954,7 @@ int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc
   const int nchunk = (int)((L1 - 1 + kEigChunk - 1) / kEigChunk);
   float *part = static_cast<float *>(ws);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(eig_lse_partial_kernel, dim3(nchunk, (B + 63) / 64), dim3(256), 0, st, S, (long)L1,
+  hipLaunchKernelGGL(eig_lse_partial_kernel, dim3(nchunk, (B + 255) / 256), dim3(256), 0, st, S, (long)L1,
                      B, kEigChunk, part);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(eig_lse_combine_kernel, dim3(B), dim3(256), 0, st, S, part, nchunk,

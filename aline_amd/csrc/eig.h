@@ -193,10 +193,11 @@ __global__ __launch_bounds__(256) void eig_ces_step_table_kernel(const float *__
 // pass 1: per chunk of rows l in [1 + c*CH, ...) an online (max, sumexp) per column b
 __global__ __launch_bounds__(256) void eig_lse_partial_kernel(const float *__restrict__ S, long L1, int B,
                                                               long chunk, float *__restrict__ part) {
-  // a workgroup covers cols = min(B, 64) columns x rows = 256 / cols rows per pass: for the small outer batches of
-  // the evaluation protocol (B = 20, README.md:50) 240 of 256 lanes stay busy and a pass reads contiguous memory
+  // a workgroup covers cols = min(B, 256) columns x rows = 256 / cols rows per pass: whole rows of S whenever
+  // B <= 256 (a pass reads contiguous memory: no partially used cache lines), and for the small outer batches of the
+  // evaluation protocol (B = 20, README.md:50) 240 of 256 lanes stay busy
   __shared__ float sm[256], ss[256];
-  const int cols = min(B, 64), rows = 256 / cols;
+  const int cols = min(B, 256), rows = 256 / cols;
   const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
   const int b = blockIdx.y * cols + tx;
   const long l0 = 1 + (long)blockIdx.x * chunk;
