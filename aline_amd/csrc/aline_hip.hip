@@ -1297,8 +1297,12 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
 
 extern "C" int aline_cholesky_upper(float *A, int n, int batch, int32_t *info, void *stream) {
   if (!A || n < 1 || batch < 1 || n > 8192) return ALINE_EINVAL;
-  hipLaunchKernelGGL(cholesky_upper_kernel, dim3(batch), dim3(256), (size_t)n * sizeof(float),
-                     static_cast<hipStream_t>(stream), A, n, info);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t smem = ((size_t)n * CHOL_NB + CHOL_NB + 4) * sizeof(float);
+  if (n <= 256) hipLaunchKernelGGL(cholesky_upper_kernel<1>, dim3(batch), dim3(256), smem, st, A, n, info);
+  else if (n <= 512) hipLaunchKernelGGL(cholesky_upper_kernel<2>, dim3(batch), dim3(256), smem, st, A, n, info);
+  else if (n <= 1024) hipLaunchKernelGGL(cholesky_upper_kernel<4>, dim3(batch), dim3(256), smem, st, A, n, info);
+  else hipLaunchKernelGGL(cholesky_upper_rowwise_kernel, dim3(batch), dim3(256), (size_t)n * sizeof(float), st, A, n, info);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
