@@ -137,7 +137,8 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
       o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
     }
     // online softmax over the keys in groups of four: one running-max rescale per group, exponentials in base 2
-    // (log2(e) is folded into the query scale)
+    // (log2(e) is folded into the query scale) on the bare v_exp_f32 (arguments are <= 0; the library exp2f spends four
+    // more instructions per call on the denormal range)
     float mx = -INFINITY, l = 0.f;
     int j = 0;
     for (; j + 4 <= nk; j += 4) {
@@ -150,10 +151,10 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
         sc[u] = t;
       }
       const float mn = fmaxf(fmaxf(mx, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
-      const float corr = exp2f(mx - mn);
+      const float corr = __builtin_amdgcn_exp2f(mx - mn);
       float pr[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) pr[u] = exp2f(sc[u] - mn);
+      for (int u = 0; u < 4; ++u) pr[u] = __builtin_amdgcn_exp2f(sc[u] - mn);
       l = l * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
 #pragma unroll
       for (int c = 0; c < HD; ++c) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
 #pragma unroll
       for (int c = 0; c < HD; ++c) t = fmaf(q[c], Ks[j * HD + c], t);
       const float mn = fmaxf(mx, t);
-      const float corr = exp2f(mx - mn), pw = exp2f(t - mn);
+      const float corr = __builtin_amdgcn_exp2f(mx - mn), pw = __builtin_amdgcn_exp2f(t - mn);
       l = l * corr + pw;
 #pragma unroll
       for (int c = 0; c < HD; ++c) o[c] = fmaf(pw, Vs[j * HD + c], o[c] * corr);
