@@ -137,3 +137,39 @@ def test_train_loop_across_burn_in_and_resume(tmp_path):
     recs2 = train(cfg2, model2, task)
     assert [r["epoch"] for r in recs2] == [4, 5] and [len(r["lr"]) for r in recs2] == [2, 2]
     assert recs2[0]["lr"] == pytest.approx(recs[4]["lr"])
+
+
+def test_driver_helpers_match_the_reference(tmp_path):
+    """tests/golden/driver.json holds what the reference's own utils/misc.py produced for the reference Aline model
+    (oracle/make_driver_golden.py): optimiser class, parameter names + lr per group, scheduler horizon, lr trajectory,
+    checkpoint file names / keys.  The drop-in model has the same parameter names, so everything must coincide."""
+    import json
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.driver import save_checkpoint, save_state_dict, set_layerwise_lr
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "driver.json")))
+    model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128))
+    assert [n for n, _ in model.named_parameters()] == gold["param_names"]
+    names = {id(p): n for n, p in model.named_parameters()}
+    for case in gold["cases"]:
+        cfg = _cfg(tmp_path, optimizer=case["optimizer"], lr=1e-3, max_epoch=12, burning_epoch=4)
+        opt, sch = set_layerwise_lr(cfg, model, case["epoch"])
+        assert type(opt).__name__ == case["class"] and sch.T_max == case["T_max"]
+        assert len(opt.param_groups) == len(case["groups"])
+        for g, ref in zip(opt.param_groups, case["groups"]):
+            assert g["lr"] == pytest.approx(ref["lr"]) and [names[id(p)] for p in g["params"]] == ref["names"]
+        for ref_lrs in case["lr_after_steps"]:
+            opt.step()
+            sch.step()
+            assert [g["lr"] for g in opt.param_groups] == pytest.approx(ref_lrs)
+    cfg = _cfg(tmp_path, max_epoch=12, burning_epoch=4)
+    opt, sch = set_layerwise_lr(cfg, model, 5)
+    save_checkpoint(cfg, model, opt, sch, 6, with_epoch=True)
+    save_checkpoint(cfg, model, opt, sch, 6, with_epoch=False)
+    ck = gold["checkpoint"]
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".tar")) == ck["files"]
+    state = torch.load(tmp_path / "ckpt_6.tar", weights_only=False)
+    assert sorted(state.keys()) == ck["keys"] and state["epoch"] == ck["epoch"]
+    assert [len(g["params"]) for g in state["optimizer"]["param_groups"]] == ck["optimizer_group_sizes"]
+    assert sorted(state["model"].keys()) == ck["model_keys"]
+    path = save_state_dict(model, str(tmp_path), "aae_x_burning.pth")
+    assert os.path.relpath(path, str(tmp_path)) == gold["state_dict_path"]
