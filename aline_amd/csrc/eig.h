@@ -36,6 +36,22 @@ __global__ __launch_bounds__(256) void eig_location_step_kernel(const float *__r
     const float2 *th2 = reinterpret_cast<const float2 *>(theta);
     const float2 *xi2 = reinterpret_cast<const float2 *>(xi);
     const float inv2n2 = 1.f / (2.f * noise * noise), cst = logf(noise) + LOG_SQRT_2PI;
+    // two independent elements per thread and iteration (more loads in flight); theta is streamed (non-temporal:
+    // 1.6 GB per step, read once)
+    for (; i + stride < total; i += 2 * stride) {
+      int b1 = b + db; if (b1 >= B) b1 -= B;
+      typedef __attribute__((ext_vector_type(2))) float v2f;
+      const v2f *thv = reinterpret_cast<const v2f *>(theta);
+      const v2f t0 = __builtin_nontemporal_load(thv + i), t1 = __builtin_nontemporal_load(thv + i + stride);
+      const float s0 = S[i], s1 = S[i + stride];              // S stays cacheable: the logsumexp pass reads it next
+      const float2 x0 = xi2[b], x1 = xi2[b1];
+      const float dx0 = x0.x - t0.x, dy0 = x0.y - t0.y, dx1 = x1.x - t1.x, dy1 = x1.y - t1.y;
+      const float z0 = y[b] - logf(base + 1.f / (msig + fmaf(dx0, dx0, dy0 * dy0)));
+      const float z1 = y[b1] - logf(base + 1.f / (msig + fmaf(dx1, dx1, dy1 * dy1)));
+      S[i] = s0 + (-(z0 * z0) * inv2n2 - cst);
+      S[i + stride] = s1 + (-(z1 * z1) * inv2n2 - cst);
+      b = b1 + db; if (b >= B) b -= B;
+    }
     for (; i < total; i += stride) {
       const float2 t = th2[i], x = xi2[b];
       const float dx = x.x - t.x, dy = x.y - t.y;
@@ -160,7 +176,9 @@ __global__ __launch_bounds__(256) void eig_ces_step_table_kernel(const float *__
   const int db = (int)(stride % B);
   for (long i = i0; i < total; i += stride, b = (b + db >= B ? b + db - B : b + db)) {
     const float *th = theta + i * 5;
-    const float rho = th[0], a0 = th[1], a1 = th[2], a2 = th[3], t4 = th[4];
+    const float rho = __builtin_nontemporal_load(th), a0 = __builtin_nontemporal_load(th + 1),
+                a1 = __builtin_nontemporal_load(th + 2), a2 = __builtin_nontemporal_load(th + 3),
+                t4 = __builtin_nontemporal_load(th + 4);      // theta is streamed (read once per step)
     const float *r = tab + b * CES_ROW;
     const int kind = __float_as_int(r[15]);
     float lp;
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(256) void eig_ces_step_table_kernel(const float *__
       lp = csn_log_prob(r[17], (u1 - u2) * u, r[16] * u, eps, 1.f - eps);
     }
     bad |= (lp != lp) || isinf(lp);
-    S[i] += lp;
+    S[i] += lp;                                   // S stays cacheable: the logsumexp pass reads it next
   }
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
