@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libaline_hip.so")
 MAX_LAYERS = 8
 MAX_COMPONENTS = 16
 EMB = {"data": 0, "theta": 1, "mix": 2}
-PREC = {"f32": 0, "fp32": 0, "bf16": 1, "bf16x3": 2}
+PREC = {"f32": 0, "fp32": 0, "bf16": 1, "bf16x3": 2, "f16x3": 3}
 SELECT_ARGMAX, SELECT_SAMPLE, SELECT_FORCED = 0, 1, 2
 
 _fp = C.c_void_p  # device pointers travel as plain addresses

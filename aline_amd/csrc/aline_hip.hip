@@ -10,6 +10,7 @@
 #include "fused_tail.h"
 #include "wide.h"
 #include "wide_step.h"
+#include "x3.h"
 #include "backward.h"
 
 #include <algorithm>
@@ -30,11 +31,12 @@ inline size_t align_up(size_t v, size_t a = 64) { return (v + a - 1) / a * a; }
     if (_rc != 0) return _rc; \
   } while (0)
 
+constexpr int kRawStride = 48;            // floats per row of the raw GMM head outputs (3 per component, C <= 16)
 constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidden = rows x C*F floats)
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -77,7 +79,17 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
                   2 * (size_t)wide::emb_words(m.F));
     p.wZt = take((size_t)B * n_t * d);
     p.wZimg = take((size_t)wide::tile_rows((long)T * B * n_t) * d / 2);     // bf16 tile image of all steps' target rows
-    p.wRaw = take((size_t)T * B * n_t * 32);                                 // raw GMM head outputs [row][3 c + j]
+    p.wRaw = take((size_t)T * B * n_t * kRawStride);                         // raw GMM head outputs [row][3 c + j]
+  }
+  if (T > 0 && m.d == x3::D && m.precision == ALINE_PREC_F16X3) {           // x3 path (x3.h): split-f16 tile images
+    const size_t tpe = (N + 15) / 16, img = (size_t)x3::img_pieces((long)B * tpe) * 4;
+    p.xImg = take((size_t)x3::image_words(m.L, m.F, m.C));
+    p.xIn = take(img); p.xA = take(img); p.xB = take(img);
+    p.xKV = take((size_t)B * x3::KV_EP * 4);
+    p.xKeys = take((size_t)B * x3::WNK); p.xKcnt = take((size_t)B * 2);
+    p.xLog = take((size_t)B * tpe * 16);
+    p.xZimg = take((size_t)x3::img_pieces(((long)T * B * n_t + 15) / 16) * 4);
+    p.xRaw = take((size_t)T * B * n_t * kRawStride);
   }
   p.total = off;
   return p;
@@ -90,7 +102,7 @@ enum { ST_EMBED = 1, ST_ENC = 2, ST_HEAD = 4, ST_ALL = 7 };
 int validate_model(const aline_model &m, int stages = ST_ALL) {
   if (m.d <= 0 || m.F <= 0) return ALINE_EINVAL;
   if (m.d % 32 || m.F % 32 || m.d > 512) return ALINE_EUNSUPPORTED;
-  if (m.precision < 0 || m.precision > 2) return ALINE_EINVAL;
+  if (m.precision < 0 || m.precision > ALINE_PREC_F16X3) return ALINE_EINVAL;
   if (m.n_theta < 0) return ALINE_EINVAL;
   if (m.embedding_type == ALINE_EMB_DATA ? m.n_theta != 0 : m.n_theta <= 0) return ALINE_EINVAL;
   if (stages & ST_EMBED) {
@@ -469,6 +481,27 @@ static int launch_wide_block(const Ctx &c, wide::BlockArgs a) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const unsigned grid = (unsigned)((a.M + wide::WG_TOK - 1) / wide::WG_TOK);
   hipLaunchKernelGGL(wide::wide_block_kernel<MODE>, dim3(grid), dim3(wide::BTHREADS), smem, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+
+static int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+template <int NOUT>
+static int launch_x3_head(const Ctx &c, x3::HeadArgs a) {
+  const size_t smem = (size_t)x3::NBUF * x3::CHUNK_BYTES + (size_t)x3::head_params(a.F) * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&x3::head_kernel<NOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  a.ngroups = (int)((a.ntiles + x3::WAVES - 1) / x3::WAVES);
+  hipLaunchKernelGGL(x3::head_kernel<NOUT>, dim3((unsigned)std::min(a.ngroups, device_cus())), dim3(x3::THREADS), smem, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -859,13 +892,142 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     for (int k = 0; k < m->C; ++k) {
       wide::BlockArgs b{};
       b.M = (int)total; b.F = F; b.X = reinterpret_cast<const u32x4 *>(c.at(c.pl.wZimg)); b.logits = raw;
-      b.out_stride = 32; b.out_off = 3 * k;
+      b.out_stride = kRawStride; b.out_off = 3 * k;
       b.wimg = gi + (long)k * wide::gmm_words(F);
       b.prm = reinterpret_cast<const float *>(b.wimg + (long)wide::head_chunks(F) * wide::CHUNK_W);
       TRY(launch_wide_block<wide::WB_GMM>(c, b));
     }
     wide::GmmRawArgs ga{};
-    ga.raw = raw; ga.raw_stride = 32; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
+    ga.raw = raw; ga.raw_stride = kRawStride; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
+    ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
+    ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
+    hipLaunchKernelGGL(wide::gmm_raw_finish_kernel, grid1d((size_t)total), dim3(256), 0, c.st, ga);
+    CHECK_LAUNCH();
+  }
+  return ALINE_OK;
+}
+
+
+// The x3 path (x3.h): d = 256 / 8 heads at reference precision -- every product a 3-term f16 split on the matrix pipe.
+static bool x3_eligible(const aline_model &m, const aline_rollout &r) {
+  if (getenv("ALINE_DISABLE_X3")) return false;
+  if (m.precision != ALINE_PREC_F16X3 || m.d != x3::D || m.H != x3::H || m.F % 32 || m.time_token) return false;
+  if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > x3::WNK) return false;
+  if ((size_t)x3::NBUF * x3::CHUNK_BYTES + (size_t)std::max(x3::layer_params(m.F), x3::head_params(m.F)) * 4 > 160 * 1024) return false;
+  return true;
+}
+
+static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes, void *stream) {
+  Ctx c;
+  TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
+  TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
+  if (r->P > 1024) return ALINE_EUNSUPPORTED;
+  const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, F = m->F, tpe = (N + 15) / 16, NP = 16 * tpe;
+  const long tiles = (long)r->B * tpe;
+  using x3::u32x4;
+  hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B, r->P, r->n_ctx0);
+  CHECK_LAUNCH();
+  // weights -> split-f16 fragment pairs (once per rollout)
+  x3::PackArgs pa{};
+  pa.L = m->L; pa.F = F; pa.C = m->C;
+  for (int l = 0; l < m->L; ++l) {
+    pa.in_proj_w[l] = m->in_proj_w[l]; pa.in_proj_b[l] = m->in_proj_b[l];
+    pa.out_proj_w[l] = m->out_proj_w[l]; pa.out_proj_b[l] = m->out_proj_b[l];
+    pa.lin1_w[l] = m->lin1_w[l]; pa.lin1_b[l] = m->lin1_b[l];
+    pa.lin2_w[l] = m->lin2_w[l]; pa.lin2_b[l] = m->lin2_b[l];
+    pa.n1w[l] = m->norm1_w[l]; pa.n1b[l] = m->norm1_b[l];
+    pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
+  }
+  pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
+  for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
+  unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.xImg));
+  pa.out = img;
+  hipLaunchKernelGGL(x3::pack_kernel, dim3(2048), dim3(256), 0, c.st, pa);
+  CHECK_LAUNCH();
+  // step-invariant point embeddings (fp32 rows; the generic GEMM runs the same 3-term f16 split)
+  {
+    Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
+    TRY(do_embed_points(c, xs, r->point_y, r->P));
+  }
+  u32x4 *XIN = reinterpret_cast<u32x4 *>(c.at(c.pl.xIn)), *XA = reinterpret_cast<u32x4 *>(c.at(c.pl.xA)), *XB = reinterpret_cast<u32x4 *>(c.at(c.pl.xB));
+  u32x4 *KV = reinterpret_cast<u32x4 *>(c.at(c.pl.xKV)), *Zimg = reinterpret_cast<u32x4 *>(c.at(c.pl.xZimg));
+  int *keyrow = reinterpret_cast<int *>(c.at(c.pl.xKeys)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.xKcnt));
+  float *logits = c.at(c.pl.xLog);
+  x3::AsmArgs aa{};
+  aa.g = c.g; aa.tpe = tpe; aa.Ex = c.at(c.pl.Ex); aa.Ey = c.at(c.pl.Ey); aa.ey_rows = r->P; aa.theta_tokens = m->theta_tokens; aa.X = XIN;
+  hipLaunchKernelGGL(x3::assemble_kernel, grid1d((size_t)tiles * x3::NKS * 64), dim3(256), 0, c.st, aa);
+  CHECK_LAUNCH();
+  const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
+  const long lw = x3::layer_words(F);
+  const size_t smem_layer = (size_t)x3::NBUF * x3::CHUNK_BYTES + (size_t)x3::layer_params(F) * 4;
+  const size_t smem_kv = (size_t)x3::NBUF * x3::CHUNK_BYTES + 2 * x3::D * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&x3::layer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_layer);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&x3::layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_layer);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&x3::kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
+  const int cus = device_cus();
+  for (int t = 0; t < r->T; ++t) {
+    c.g.n_ctx = r->n_ctx0 + t;
+    hipLaunchKernelGGL(x3::keys_kernel, dim3(r->B), dim3(256), 0, c.st, c.g, keyrow, kcnt);
+    CHECK_LAUNCH();
+    const int nkeys = r->n_ctx0 + t + n_t;                      // upper bound of an episode's key count at this step
+    const int nkt2 = 2 * ((std::min(nkeys, x3::WNK) + 31) / 32);
+    const u32x4 *xin = XIN;
+    for (int l = 0; l < m->L; ++l) {
+      u32x4 *xout = (l & 1) ? XB : XA;
+      x3::KvArgs ka{};
+      ka.g = c.g; ka.tpe = tpe; ka.nkt2 = nkt2; ka.X = xin; ka.img = img + l * lw; ka.F = F; ka.keyrow = keyrow; ka.kcnt = kcnt; ka.KV = KV;
+      ka.ngroups = (int)(((long)r->B * nkt2 + x3::WAVES - 1) / x3::WAVES);
+      hipLaunchKernelGGL(x3::kv_kernel, dim3((unsigned)std::min(ka.ngroups, cus)), dim3(x3::THREADS), smem_kv, c.st, ka);
+      CHECK_LAUNCH();
+      x3::LayerArgs la{};
+      la.g = c.g; la.tpe = tpe; la.ngroups = (int)((tiles + x3::WAVES - 1) / x3::WAVES);
+      la.XIN = xin; la.XOUT = xout; la.img = img + l * lw; la.F = F; la.KV = KV; la.kcnt = kcnt;
+      const bool last = l == m->L - 1;
+      la.zimg = (last && want_gmm) ? Zimg : nullptr; la.zrow0 = (long)t * r->B * n_t;
+      const bool timed = (t == r->T - 1 && last);              // bench.py times this launch of the dominant kernel
+      if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
+      if (last) hipLaunchKernelGGL(x3::layer_kernel<true>, dim3((unsigned)std::min(la.ngroups, cus)), dim3(x3::THREADS), smem_layer, c.st, la);
+      else hipLaunchKernelGGL(x3::layer_kernel<false>, dim3((unsigned)std::min(la.ngroups, cus)), dim3(x3::THREADS), smem_layer, c.st, la);
+      if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
+      CHECK_LAUNCH();
+      xin = xout;
+    }
+    {   // acquisition logits of every token row (model/head.py:27-33); the selection reads the candidate slots
+      x3::HeadArgs ha{};
+      ha.X = xin; ha.ntiles = tiles; ha.M = tiles * 16; ha.img = img + (long)m->L * lw; ha.F = F;
+      ha.out = logits; ha.out_stride = 1; ha.out_off = 0;
+      TRY(launch_x3_head<1>(c, ha));
+    }
+    SelectArgs sel{};
+    sel.g = c.g; sel.F = F; sel.logits = logits; sel.logit_stride = NP;
+    sel.mode = r->select_mode;
+    sel.uniform = r->uniform ? r->uniform + (size_t)t * r->B : nullptr;
+    sel.forced = r->forced_idx ? r->forced_idx + t : nullptr; sel.forced_stride = r->T;
+    sel.idx = r->idx ? r->idx + t : nullptr; sel.idx_stride = r->T;
+    sel.slot = r->slot ? r->slot + t : nullptr; sel.slot_stride = r->T;
+    sel.log_prob = r->log_prob ? r->log_prob + t : nullptr; sel.lp_stride = r->T;
+    const int zw = r->P - r->n_ctx0;
+    sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
+    sel.role_out = r->role;
+    hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
+    CHECK_LAUNCH();
+    if (t + 1 < r->T) {   // the chosen point enters the context: its input row becomes Ex + Ey
+      aa.g = c.g;
+      hipLaunchKernelGGL(x3::patch_row_kernel, dim3(r->B), dim3(64), 0, c.st, aa, r->n_ctx0 + t + 1);
+      CHECK_LAUNCH();
+    }
+  }
+  if (want_gmm) {   // GMM heads of all T * B * n_t target rows, then the parameter maps + mixture log-likelihood
+    const long per_step = (long)r->B * n_t, total = per_step * r->T;
+    float *raw = c.at(c.pl.xRaw);
+    for (int k = 0; k < m->C; ++k) {
+      x3::HeadArgs ha{};
+      ha.X = Zimg; ha.ntiles = (total + 15) / 16; ha.M = total; ha.img = img + (long)m->L * lw + (long)(1 + k) * x3::head_words(F); ha.F = F;
+      ha.out = raw; ha.out_stride = kRawStride; ha.out_off = 3 * k;
+      TRY(launch_x3_head<3>(c, ha));
+    }
+    wide::GmmRawArgs ga{};
+    ga.raw = raw; ga.raw_stride = kRawStride; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
     ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
     ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
     hipLaunchKernelGGL(wide::gmm_raw_finish_kernel, grid1d((size_t)total), dim3(256), 0, c.st, ga);
@@ -880,6 +1042,8 @@ int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws
     return rollout_fused(m, r, ws, ws_bytes, stream);
   if (m && r && validate_model(*m) == 0 && wide_eligible(*m, *r))
     return rollout_wide(m, r, ws, ws_bytes, stream);
+  if (m && r && validate_model(*m) == 0 && x3_eligible(*m, *r))
+    return rollout_x3(m, r, ws, ws_bytes, stream);
   TRY(aline_rollout_init(m, r, ws, ws_bytes, stream));
   for (int t = 0; t < r->T; ++t) TRY(aline_rollout_step(m, r, t, ws, ws_bytes, stream));
   return ALINE_OK;

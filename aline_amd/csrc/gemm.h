@@ -7,6 +7,10 @@
 //   F32    v_mfma_f32_16x16x4_f32   (exact fp32, 8 MFMAs per 32-deep step)
 //   BF16   v_mfma_f32_16x16x32_bf16 (1 MFMA per step)
 //   BF16X3 split operands hi+lo, 3 MFMAs per step (hi*hi + hi*lo + lo*hi), ~2^-16 relative error
+//   F16X3  the same split in f16 (v_mfma_f32_16x16x32_f16): hi and lo carry 11 bits each, the dropped lo*lo term is
+//          <= 2^-24 of the product -- fp32-grade results (reference fixtures: NLL within 2e-5, like F32) at 3 passes
+//          of the 2.5 PFLOP/s pipe instead of 8 of the 157 TFLOP/s fp32 MFMA.  Weights are scaled by 2^8 on their way
+//          into LDS (exact) so that both halves stay in f16's normal range; the epilogue scales back.
 // Row maps let a launch read/write a sub-range of each episode's token rows (e.g. only the
 // target rows) without a gather pass:  row(m) = (m / R) * G + off + (m % R).
 // blockIdx.z selects a weight group (the C independent GMM heads run as one grouped launch).
@@ -38,12 +42,33 @@ template <int PREC> struct LdsTile;  // storage of a [ROWS x 32] operand tile in
 template <> struct LdsTile<0> { static constexpr int LD = 34; using T = float; static constexpr int PLANES = 1; };
 template <> struct LdsTile<1> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 1; };
 template <> struct LdsTile<2> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 2; };
+template <> struct LdsTile<3> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 2; };
+constexpr float GEMM_F16_WSCALE = 256.f;
+
+typedef __attribute__((ext_vector_type(8))) _Float16 gemm_f16x8;
+__device__ __forceinline__ void split_f16(float a, unsigned short &hi, unsigned short &lo) {
+  const _Float16 h = (_Float16)a;
+  const _Float16 l = (_Float16)(a - (float)h);
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
 
 // store 4 consecutive k-values of one tile row
 template <int PREC>
 __device__ __forceinline__ void lds_store4(typename LdsTile<PREC>::T *base, int plane_elems, int row,
-                                           int k, float4 v) {
+                                           int k, float4 v, float scale = 1.f) {
   constexpr int LD = LdsTile<PREC>::LD;
+  if constexpr (PREC == 3) {
+    u16x4 h, l;
+    unsigned short a, b;
+    split_f16(v.x * scale, a, b); h[0] = a; l[0] = b;
+    split_f16(v.y * scale, a, b); h[1] = a; l[1] = b;
+    split_f16(v.z * scale, a, b); h[2] = a; l[2] = b;
+    split_f16(v.w * scale, a, b); h[3] = a; l[3] = b;
+    *reinterpret_cast<u16x4 *>(base + row * LD + k) = h;
+    *reinterpret_cast<u16x4 *>(base + plane_elems + row * LD + k) = l;
+    return;
+  }
   if constexpr (PREC == 0) {
     float *p = base + row * LD + k;
     p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
@@ -124,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       int idx = tid + i * 256;
-      lds_store4<PREC>(Bs, B_ELEMS, idx >> 3, (idx & 7) * 4, bv[i]);
+      lds_store4<PREC>(Bs, B_ELEMS, idx >> 3, (idx & 7) * 4, bv[i], PREC == 3 ? GEMM_F16_WSCALE : 1.f);
     }
     __syncthreads();
     if (k0 + GEMM_BK < a.K) load_step(k0 + GEMM_BK);
@@ -143,6 +168,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
+    } else if constexpr (PREC == 3) {
+      gemm_f16x8 ah[TM], bh[TN], al[TM], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const gemm_f16x8 *>(As + (wm * WM + i * 16 + fr) * LD + fg * 8);
+        al[i] = *reinterpret_cast<const gemm_f16x8 *>(As + A_ELEMS + (wm * WM + i * 16 + fr) * LD + fg * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const gemm_f16x8 *>(Bs + (wn * WN + j * 16 + fr) * LD + fg * 8);
+        bl[j] = *reinterpret_cast<const gemm_f16x8 *>(Bs + B_ELEMS + (wn * WN + j * 16 + fr) * LD + fg * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
     } else {
       bf16x8 ah[TM], bh[TN];
 #pragma unroll
@@ -196,7 +241,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(rbase % RP + fg * 4 + r) * LDC + wn * WN + 16 * j + fr] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r)
+            Cs[(rbase % RP + fg * 4 + r) * LDC + wn * WN + 16 * j + fr] = PREC == 3 ? acc[i][j][r] * (1.f / GEMM_F16_WSCALE) : acc[i][j][r];
       }
     }
     __syncthreads();
@@ -298,6 +344,7 @@ static int launch_gemm(int prec, const GemmArgs &a, int groups, hipStream_t st) 
     case 0: return launch_gemm_prec<0>(a, groups, st);
     case 1: return launch_gemm_prec<1>(a, groups, st);
     case 2: return launch_gemm_prec<2>(a, groups, st);
+    case 3: return launch_gemm_prec<3>(a, groups, st);
   }
   return -1;
 }

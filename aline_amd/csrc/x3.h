@@ -1,0 +1,664 @@
+// x3 path: d = 256 (8 heads of 32) at REFERENCE precision on the f16 matrix pipe.
+//
+// Every matrix product of the step (model/embedder.py second layers excepted: they run once per rollout on the
+// exact-fp32 GEMM) is computed as an fp32-grade 3-term split on v_mfma_f32_16x16x32_f16:
+//     a = a_hi + a_lo,  b = b_hi + b_lo   (a_hi = f16(a), a_lo = f16(a - a_hi): 22 significant bits)
+//     a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi        (dropped: a_lo b_lo <= 2^-24 |a b|, the size of fp32 rounding)
+// accumulated in fp32.  Measured on the reference fixtures this is indistinguishable from the exact-fp32 pipeline
+// (posterior log-likelihood within 2e-5, tests/test_x3_gpu.py), at 3 MFMA passes on the 2.5 PFLOP/s pipe instead of
+// the 157 TFLOP/s fp32 MFMA.  Weights are pre-scaled by 2^8 at pack time (exact; keeps both halves of a weight in
+// f16's normal range), products are scaled back in the epilogues.
+//
+// Operand scheme (as wide.h): a token tile is X^T [features x 16 tokens]; every linear is Y^T = W X^T, so an
+// accumulator tile is the B operand of the next product with k order pi(ks,g,j) = 32 ks + 16 (j>>2) + 4 g + (j&3);
+// weights are A fragments pre-permuted at pack time, as PAIRS (hi fragment 1 KB | lo fragment 1 KB).
+//
+// Kernels (one launch each per layer and step; activations travel as split-f16 TILE IMAGES, episodes padded to whole
+// 16-row tiles, so tiles never straddle episodes and every wave-level load / store is whole KBs):
+//   keys_kernel    per step: the key list of every episode (context rows, then the visible target rows)
+//   kv_kernel      K / V of the key rows only, written as the A fragments the attention needs
+//   layer_kernel   Q projection, masked set-attention, out-projection, LN1, FFN, LN2 of a token tile, all in
+//                  registers: 8 waves x one 16-token tile, weights streamed through LDS by LDS-DMA (32 KB chunks
+//                  of 16 pairs, 3 buffers); persistent workgroups walk the tile list, the weight stream is cyclic
+//   head_kernel    acquisition logits / one GMM head (hidden layer in registers, [F -> 1|3] in fp32 FMA)
+#pragma once
+#include "wide.h"
+
+namespace x3 {
+
+using wide::u32x4;
+using wide::u32x2;
+using wide::group_sum4;
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int D = 256, H = 8, HD = 32, NMT = D / 16, NKS = D / 32, WNK = 64;
+constexpr int THREADS = 512, WAVES = THREADS / 64;
+constexpr int CHUNK_PAIRS = 16, CHUNK_BYTES = CHUNK_PAIRS * 2048, CHUNK_WORDS = CHUNK_BYTES / 4;
+constexpr int NBUF = 3, PD = 2;                       // LDS ring, chunks in flight ahead of the one in use
+constexpr int PIECES_PER_WAVE = CHUNK_BYTES / 1024 / WAVES;
+constexpr float WSCALE = 256.f, WINV = 1.f / 256.f;
+constexpr long KV_EP = 8192;                          // u32x4 per episode: K pairs [h][kt 4] | V^T pairs [i 16][s 2]
+constexpr long KV_VOFF = 4096;
+
+#define XMFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0)
+// acc += (ah + al) (bh + bl) without the lo*lo term; small terms first
+__device__ __forceinline__ void mfma3(f32x4 &acc, const f16x8 &ah, const f16x8 &al, const f16x8 &bh, const f16x8 &bl) {
+  XMFMA(acc, al, bh);
+  XMFMA(acc, ah, bl);
+  XMFMA(acc, ah, bh);
+}
+
+// (a, b) -> packed hi halves, packed lo halves (round to nearest even both times)
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+  const f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  const f32x2 r = {a - hf[0], b - hf[1]};
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// two accumulator tiles (features 16 m + 4 g + r, 16 (m+1) + 4 g + r) -> the hi / lo B fragments of their k-step
+__device__ __forceinline__ void split_frag(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split2(a[0], a[1], h0, l0);
+  split2(a[2], a[3], h1, l1);
+  split2(b[0], b[1], h2, l2);
+  split2(b[2], b[3], h3, l3);
+  hi = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});
+  lo = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});
+}
+// the fp32 values a fragment pair stands for: elements 4 hf .. 4 hf + 3
+__device__ __forceinline__ f32x4 frag_value(const f16x8 &hi, const f16x8 &lo, int hf) {
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (float)hi[4 * hf + r] + (float)lo[4 * hf + r];
+  return v;
+}
+__device__ __forceinline__ float group_max4(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// ---- images ---------------------------------------------------------------------------------------------------
+// activation image, in 16-byte pieces: [tile][ks][hi | lo][lane = 16 g + row % 16]; a piece holds features
+// 32 ks + 4 g + (0..3) and 32 ks + 16 + 4 g + (0..3) of its token row (= the B fragment element order)
+__host__ __device__ inline long img_pieces(long tiles) { return tiles * (NKS * 2 * 64); }
+__device__ __forceinline__ long xpiece(long tile, int ks, int hl, int lane) { return ((tile * NKS + ks) * 2 + hl) * 64 + lane; }
+
+// weight image of a layer (32-bit words): chunks [Q 8][K 8][V 8][OUT 8][FFN: per 32 hidden units W1 | W2], then fp32
+// parameters bq (pre-scaled) bk bv | bo | b1 | b2 | ln1w ln1b ln2w ln2b.  A chunk is 16 fragment pairs.
+__host__ __device__ inline int layer_chunks(int F) { return 32 + F / 16; }
+__host__ __device__ inline int layer_params(int F) { return 9 * D + F; }
+__host__ __device__ inline long layer_words(int F) { return (long)layer_chunks(F) * CHUNK_WORDS + layer_params(F); }
+// head image (acquisition head, GMM heads): F/32 chunks of W1, then b1 [F] | w2 [3][F] | b2 [4]
+__host__ __device__ inline int head_chunks(int F) { return F / 32; }
+__host__ __device__ inline int head_params(int F) { return 4 * F + 4; }
+__host__ __device__ inline long head_words(int F) { return (long)head_chunks(F) * CHUNK_WORDS + head_params(F); }
+__host__ __device__ inline long image_words(int L, int F, int C) { return (long)L * layer_words(F) + (long)(1 + C) * head_words(F); }
+
+struct PackArgs {
+  int L, F, C;
+  const float *in_proj_w[8], *in_proj_b[8], *out_proj_w[8], *out_proj_b[8], *lin1_w[8], *lin1_b[8], *lin2_w[8],
+      *lin2_b[8], *n1w[8], *n1b[8], *n2w[8], *n2b[8];
+  const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
+  const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
+  unsigned *out;
+};
+
+// word e (0..511) of the pair (rows row0.., k-step ks) of the row-major weight W [*, K]: hi fragment, lo fragment
+__device__ __forceinline__ unsigned pair_word(const float *W, int K, int row0, int ks, int e, float scale) {
+  const int hl = e >> 8, lane = (e & 255) >> 2, w = e & 3, g = lane >> 4, j0 = 2 * w;
+  const int k0 = 32 * ks + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
+  const float *p = W + (long)(row0 + (lane & 15)) * K + k0;
+  unsigned hi, lo;
+  split2(p[0] * scale, p[1] * scale, hi, lo);
+  return hl ? lo : hi;
+}
+
+__global__ void pack_kernel(PackArgs a) {
+  const long lw = layer_words(a.F), hw = head_words(a.F), total = image_words(a.L, a.F, a.C);
+  const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;   // softmax runs in exp2
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    unsigned v = 0;
+    if (i < a.L * lw) {
+      const int l = i / lw;
+      const long o = i % lw, nfw = (long)layer_chunks(a.F) * CHUNK_WORDS;
+      if (o < nfw) {
+        const int ch = o / CHUNK_WORDS, cw = o % CHUNK_WORDS, p = cw >> 9, e = cw & 511;
+        if (ch < 24) v = pair_word(a.in_proj_w[l] + (long)(ch >> 3) * D * D, D, 16 * p, ch & 7, e, (ch < 8 ? qscale : 1.f) * WSCALE);
+        else if (ch < 32) v = pair_word(a.out_proj_w[l], D, 16 * p, ch & 7, e, WSCALE);
+        else {
+          const int c = (ch - 32) >> 1;
+          if (((ch - 32) & 1) == 0) v = pair_word(a.lin1_w[l], D, 32 * c + 16 * (p & 1), p >> 1, e, WSCALE);
+          else v = pair_word(a.lin2_w[l], a.F, 16 * p, c, e, WSCALE);
+        }
+      } else {
+        const int p = o - nfw;
+        float f;
+        if (p < 3 * D) f = a.in_proj_b[l][p] * (p < D ? qscale : 1.f);
+        else if (p < 4 * D) f = a.out_proj_b[l][p - 3 * D];
+        else if (p < 4 * D + a.F) f = a.lin1_b[l][p - 4 * D];
+        else {
+          const int q = p - 4 * D - a.F;
+          f = q < D ? a.lin2_b[l][q] : q < 2 * D ? a.n1w[l][q - D] : q < 3 * D ? a.n1b[l][q - 2 * D]
+            : q < 4 * D ? a.n2w[l][q - 3 * D] : a.n2b[l][q - 4 * D];
+        }
+        v = __float_as_uint(f);
+      }
+    } else {
+      const long oh = i - a.L * lw;
+      const int k = oh / hw;                          // 0: acquisition head, 1 + c: GMM head c
+      const long o = oh % hw, nfw = (long)head_chunks(a.F) * CHUNK_WORDS;
+      const float *w1 = k == 0 ? a.acq_w1 : a.gmm_w1[k - 1], *b1 = k == 0 ? a.acq_b1 : a.gmm_b1[k - 1];
+      const float *w2 = k == 0 ? a.acq_w2 : a.gmm_w2[k - 1], *b2 = k == 0 ? a.acq_b2 : a.gmm_b2[k - 1];
+      const int nout = k == 0 ? 1 : 3;
+      if (o < nfw) {
+        const int ch = o / CHUNK_WORDS, cw = o % CHUNK_WORDS, p = cw >> 9, e = cw & 511;
+        v = pair_word(w1, D, 32 * ch + 16 * (p & 1), p >> 1, e, WSCALE);
+      } else {
+        const int p = o - nfw;
+        const float f = p < a.F ? b1[p] : p < (1 + nout) * a.F ? w2[p - a.F] : (p >= 4 * a.F && p < 4 * a.F + nout) ? b2[p - 4 * a.F] : 0.f;
+        v = __float_as_uint(f);
+      }
+    }
+    a.out[i] = v;
+  }
+}
+
+// ---- X0 image from the cached fp32 point embeddings (model/embedder.py:128-214): Ex (+ Ey on context rows), theta
+// tokens; rows beyond N of an episode's last tile are zero.  One thread = one (piece hi, piece lo).
+struct AsmArgs {
+  Geo g; int tpe;
+  const float *Ex, *Ey; int ey_rows; const float *theta_tokens;
+  u32x4 *X;
+};
+__device__ __forceinline__ void store_split8(u32x4 *X, long tile, int ks, int lane, const f32x4 &lo4, const f32x4 &hi4) {
+  f16x8 h, l;
+  split_frag(lo4, hi4, h, l);
+  X[xpiece(tile, ks, 0, lane)] = __builtin_bit_cast(u32x4, h);
+  X[xpiece(tile, ks, 1, lane)] = __builtin_bit_cast(u32x4, l);
+}
+__device__ __forceinline__ void embed_row8(const AsmArgs &a, int b, int row, int c, f32x4 &lo, f32x4 &hi) {
+  const Geo &g = a.g;
+  if (row < g.P + g.n_td) {
+    const float *e = a.Ex + ((long)b * (g.P + g.n_td) + row) * D + c;
+    lo = *reinterpret_cast<const f32x4 *>(e); hi = *reinterpret_cast<const f32x4 *>(e + 16);
+    if (row < g.P && is_ctx(g, b, row)) {
+      const float *y = a.Ey + ((long)b * a.ey_rows + row) * D + c;
+      lo += *reinterpret_cast<const f32x4 *>(y); hi += *reinterpret_cast<const f32x4 *>(y + 16);
+    }
+  } else {
+    const float *t = a.theta_tokens + (row - g.P - g.n_td) * D + c;
+    lo = *reinterpret_cast<const f32x4 *>(t); hi = *reinterpret_cast<const f32x4 *>(t + 16);
+  }
+}
+__global__ void assemble_kernel(AsmArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tiles = (long)a.g.B * a.tpe;
+  if (i >= tiles * NKS * 64) return;
+  const int lane = i & 63, ks = (i >> 6) % NKS, gq = lane >> 4;
+  const long tile = (i >> 6) / NKS;
+  const int b = tile / a.tpe, row = (int)(tile % a.tpe) * 16 + (lane & 15);
+  f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+  if (row < a.g.N) embed_row8(a, b, row, 32 * ks + 4 * gq, lo, hi);
+  store_split8(a.X, tile, ks, lane, lo, hi);
+}
+// between steps the input image changes in ONE row per episode: the point chosen at the previous step (role ==
+// `order`) became a context point, its row becomes Ex + Ey.  One wave per episode.
+__global__ __launch_bounds__(64) void patch_row_kernel(AsmArgs a, int order) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int slot = -1;
+  for (int p = lane; p < a.g.P; p += 64)
+    if (a.g.role[(long)b * a.g.P + p] == order) slot = p;
+  slot = __reduce_max_sync(~0ull, slot);
+  if (slot < 0 || lane >= D / 8) return;
+  const int ks = lane >> 2, gq = lane & 3;
+  f32x4 lo, hi;
+  embed_row8(a, b, slot, 32 * ks + 4 * gq, lo, hi);
+  store_split8(a.X, (long)b * a.tpe + (slot >> 4), ks, gq * 16 + (slot & 15), lo, hi);
+}
+
+// ---- key list of every episode (model/encoder.py:83-126): context rows in slot order, then the visible targets --
+__global__ __launch_bounds__(256) void keys_kernel(Geo g, int *__restrict__ keyrow, int *__restrict__ kcnt) {
+  __shared__ int wave_cnt[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < g.P; c0 += 256) {
+    const int row = c0 + tid;
+    const bool key = row < g.P && is_ctx(g, b, row);
+    const unsigned long long bal = __ballot(key);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+    if (key && k < WNK) keyrow[b * WNK + k] = row;
+    __syncthreads();
+    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int n = min(s_base, WNK);
+    kcnt[2 * b] = n;
+    const int n_t = g.n_td + g.n_th;
+    for (int j = 0; j < n_t; ++j)
+      if ((!g.tmask || g.tmask[j]) && n < WNK) keyrow[b * WNK + n++] = g.P + j;
+    kcnt[2 * b + 1] = n;
+  }
+}
+
+// ---- the weight stream ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void *gsrc, void *ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {   // all but the N youngest vector-memory operations of this wave are done
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// Cyclic stream of 32 KB chunks through a ring of NBUF LDS buffers, PD chunks ahead of the one in use.  Every wave
+// moves its 4 KB share of a chunk with 4 LDS-DMA instructions.  next(): this wave's pieces of the chunk have landed
+// (counted vmcnt: later operations only make the wait more conservative), then the workgroup barrier -- after which
+// every wave's pieces are visible and nobody reads the previous chunk any more, so its buffer takes the chunk PD
+// positions further down the stream.
+template <class SrcFn>
+struct Stream {
+  SrcFn src;              // position in the cyclic sequence -> first byte of the chunk
+  char *ring;
+  int seq_len, s_issue, b_issue, b_use;
+  unsigned lane_off, wave_off;
+  __device__ __forceinline__ void issue() {
+    const char *p = src(s_issue) + wave_off + lane_off;
+    char *d = ring + b_issue * CHUNK_BYTES + wave_off;
+#pragma unroll
+    for (int i = 0; i < PIECES_PER_WAVE; ++i) glds16(p + i * 1024, d + i * 1024);
+    s_issue = s_issue + 1 == seq_len ? 0 : s_issue + 1;
+    b_issue = b_issue + 1 == NBUF ? 0 : b_issue + 1;
+  }
+  __device__ __forceinline__ void start() {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue();
+  }
+  __device__ __forceinline__ const f16x8 *next() {
+    wait_vmcnt<PIECES_PER_WAVE *(PD - 1)>();
+    __builtin_amdgcn_s_barrier();
+    issue();
+    const f16x8 *fr = reinterpret_cast<const f16x8 *>(ring + b_use * CHUNK_BYTES + lane_off);
+    b_use = b_use + 1 == NBUF ? 0 : b_use + 1;
+    return fr;
+  }
+  __device__ __forceinline__ void finish() { wait_vmcnt<0>(); }   // no LDS-DMA may outlive the workgroup
+};
+template <class SrcFn>
+__device__ __forceinline__ Stream<SrcFn> make_stream(SrcFn src, char *ring, int seq_len, int tid) {
+  Stream<SrcFn> s{src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u,
+                  (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * (unsigned)(PIECES_PER_WAVE * 1024)};
+  return s;
+}
+// pair p of the chunk in use
+#define PAIR_HI(fr, p) (fr)[(2 * (p)) * 64]
+#define PAIR_LO(fr, p) (fr)[(2 * (p) + 1) * 64]
+
+// Y^T (16 feature tiles) += W[:, k-step] X^T[k-step]: one chunk = the 16 feature-tile pairs of one k-step
+__device__ __forceinline__ void chunk_linear(f32x4 (&y)[NMT], const f16x8 *fr, const f16x8 &bh, const f16x8 &bl) {
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) mfma3(y[m], PAIR_HI(fr, m), PAIR_LO(fr, m), bh, bl);
+}
+
+__device__ __forceinline__ void load_tile(const u32x4 *X, long tile, int lane_idx, f16x8 (&xh)[NKS], f16x8 (&xl)[NKS]) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    xh[ks] = __builtin_bit_cast(f16x8, X[xpiece(tile, ks, 0, lane_idx)]);
+    xl[ks] = __builtin_bit_cast(f16x8, X[xpiece(tile, ks, 1, lane_idx)]);
+  }
+}
+
+// v = LayerNorm(v) over the 256 features of each token (16 tiles x 4 registers x 4 lane groups), fp32, two passes
+__device__ __forceinline__ void layer_norm(f32x4 (&v)[NMT], const float *lw, const float *lb, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
+  const float mean = group_sum4(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[mt][r] -= mean; q = fmaf(v[mt][r], v[mt][r], q); }
+  const float rstd = 1.f / sqrtf(group_sum4(q) * (1.f / D) + 1e-5f);
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+    const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + 16 * mt + 4 * g), bv = *reinterpret_cast<const f32x4 *>(lb + 16 * mt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[mt][r] = fmaf(v[mt][r] * rstd, wv[r], bv[r]);
+  }
+}
+
+// ---- K / V of the key rows ----------------------------------------------------------------------------------------
+struct KvArgs {
+  Geo g; int tpe, nkt2, ngroups;
+  const u32x4 *X;                 // layer input image
+  const unsigned *img;            // this layer's weight image
+  int F;
+  const int *keyrow, *kcnt;
+  u32x4 *KV;
+};
+
+__global__ __launch_bounds__(THREADS) void kv_kernel(KvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *prm = reinterpret_cast<float *>(lds + NBUF * CHUNK_BYTES);      // bk | bv
+  const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float *gprm = reinterpret_cast<const float *>(a.img + (long)layer_chunks(a.F) * CHUNK_WORDS);
+  for (int i = tid; i < 2 * D; i += THREADS) prm[i] = gprm[D + i];
+  const char *wbase = reinterpret_cast<const char *>(a.img) + (long)8 * CHUNK_BYTES;     // K chunks, then V chunks
+  auto st = make_stream([wbase](int s) { return wbase + (long)s * CHUNK_BYTES; }, lds, 16, tid);
+  st.start();
+  __syncthreads();
+  const long ntiles = (long)a.g.B * a.nkt2;
+  for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+    const long tile = (long)grp * WAVES + wave;
+    const bool valid = tile < ntiles;
+    const long tl = valid ? tile : ntiles - 1;
+    const int b = tl / a.nkt2, kt = tl % a.nkt2, key = 16 * kt + tok;
+    const int row = key < a.kcnt[2 * b + 1] ? a.keyrow[b * WNK + key] : -1;
+    f16x8 xh[NKS], xl[NKS];
+    if (row >= 0) {
+      load_tile(a.X, (long)b * a.tpe + (row >> 4), 16 * g + (row & 15), xh, xl);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) { xh[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; xl[ks] = xh[ks]; }
+    }
+    u32x4 *kv = a.KV + (long)b * KV_EP;
+    f32x4 y[NMT];
+    // K^T = Wk KX^T: rows = channels, columns = keys -> A fragments of S^T = K Q^T, pair (head, kt)
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NKS; ++cc) {
+      const f16x8 *fr = st.next();
+      chunk_linear(y, fr, xh[cc], xl[cc]);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 4 * g), b1 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 16 + 4 * g);
+      f16x8 fh, fl;
+      split_frag(y[2 * h] * WINV + b0, y[2 * h + 1] * WINV + b1, fh, fl);
+      if (valid) {
+        kv[((h * 4 + kt) * 2) * 64 + lane] = __builtin_bit_cast(u32x4, fh);
+        kv[((h * 4 + kt) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, fl);
+      }
+    }
+    // V = KX Wv^T with the MFMA operands swapped (rows = keys, columns = channels): accumulator tile i holds
+    // V[key 16 kt + 4 g + r][channel 16 i + tok] -- half (kt & 1) of this lane's piece of the V^T pair (i, kt / 2)
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NKS; ++cc) {
+      const f16x8 *fr = st.next();
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) mfma3(y[m], xh[cc], xl[cc], PAIR_HI(fr, m), PAIR_LO(fr, m));
+    }
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) {
+      const float bv = prm[D + 16 * i + tok];
+      unsigned h0, l0, h1, l1;
+      split2(y[i][0] * WINV + bv, y[i][1] * WINV + bv, h0, l0);
+      split2(y[i][2] * WINV + bv, y[i][3] * WINV + bv, h1, l1);
+      if (valid) {
+        u32x2 *ph = reinterpret_cast<u32x2 *>(kv + KV_VOFF + ((i * 2 + (kt >> 1)) * 2) * 64 + lane) + (kt & 1);
+        u32x2 *pl = reinterpret_cast<u32x2 *>(kv + KV_VOFF + ((i * 2 + (kt >> 1)) * 2 + 1) * 64 + lane) + (kt & 1);
+        *ph = (u32x2){h0, h1};
+        *pl = (u32x2){l0, l1};
+      }
+    }
+  }
+  st.finish();
+}
+
+// ---- one encoder layer of a token tile ----------------------------------------------------------------------------
+struct LayerArgs {
+  Geo g; int tpe, ngroups;
+  const u32x4 *XIN; u32x4 *XOUT;
+  const unsigned *img; int F;
+  const u32x4 *KV; const int *kcnt;
+  u32x4 *zimg; long zrow0;        // last layer: the rows of the target tokens also go to this (dense-row) image
+};
+
+// masked set-attention of one token tile against NKT key tiles, head by head (model/encoder.py:8-46): S^T = K Q^T in
+// the exp2 domain (scale folded into Wq), softmax over the keys of a token (4 NKT values per lane x 4 lane groups),
+// O^T = V^T P.  qh / ql [h] go in as the Q^T fragment pair of head h and come out as the pair of the normalised head
+// output (= k-step h of the out-projection).
+template <int NKT>
+__device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], const u32x4 *kv, int nv) {
+  constexpr int NS = NKT > 2 ? 2 : 1;
+  f32x4 mb[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mb[kt][r] = (16 * kt + r) < nv ? 0.f : -INFINITY;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const f16x8 kh = __builtin_bit_cast(f16x8, kv[((h * 4 + kt) * 2) * 64]), kl = __builtin_bit_cast(f16x8, kv[((h * 4 + kt) * 2 + 1) * 64]);
+      s[kt] = mb[kt];
+      mfma3(s[kt], kh, kl, qh[h], ql[h]);
+    }
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+    for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+    mx = group_max4(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+        sum += s[kt][r];
+      }
+    const float inv = 1.f / group_sum4(sum);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o0 = z4, o1 = z4;
+#pragma unroll
+    for (int si = 0; si < NS; ++si) {
+      f16x8 ph, pl;
+      split_frag(s[2 * si], (2 * si + 1 < NKT) ? s[(2 * si + 1 < NKT) ? 2 * si + 1 : 0] : z4, ph, pl);
+      const u32x4 *v0 = kv + KV_VOFF + (((2 * h) * 2 + si) * 2) * 64, *v1 = kv + KV_VOFF + (((2 * h + 1) * 2 + si) * 2) * 64;
+      mfma3(o0, __builtin_bit_cast(f16x8, v0[0]), __builtin_bit_cast(f16x8, v0[64]), ph, pl);
+      mfma3(o1, __builtin_bit_cast(f16x8, v1[0]), __builtin_bit_cast(f16x8, v1[64]), ph, pl);
+    }
+    split_frag(o0 * inv, o1 * inv, qh[h], ql[h]);
+  }
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *prm = reinterpret_cast<float *>(lds + NBUF * CHUNK_BYTES);   // bq bk bv | bo | b1 | b2 | ln1w ln1b ln2w ln2b
+  const Geo &G = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int F = a.F, np = layer_params(F), n_t = G.n_td + G.n_th;
+  {
+    const float *gprm = reinterpret_cast<const float *>(a.img + (long)layer_chunks(F) * CHUNK_WORDS);
+    for (int i = tid; i < np; i += THREADS) prm[i] = gprm[i];
+  }
+  const float *bo = prm + 3 * D, *b1 = prm + 4 * D, *b2 = b1 + F, *ln1w = b2 + D, *ln1b = ln1w + D, *ln2w = ln1b + D, *ln2b = ln2w + D;
+  // stream order of one tile group: Q (chunks 0..7), OUT (24..31), FFN (32..)
+  const char *wbase = reinterpret_cast<const char *>(a.img);
+  const int seq = 16 + F / 16;
+  auto st = make_stream([wbase](int s) { return wbase + (long)(s < 8 ? s : s + 16) * CHUNK_BYTES; }, lds, seq, tid);
+  st.start();
+  __syncthreads();
+  const long ntiles = (long)G.B * a.tpe;
+  for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+    const long tile = (long)grp * WAVES + wave;
+    const bool valid = tile < ntiles;
+    const long tl = valid ? tile : ntiles - 1;
+    const int b = tl / a.tpe, j = tl % a.tpe;
+    const int r = 16 * j + tok, rc = min(r, G.N - 1);
+    const bool rowok = valid && r < G.N;
+    const int lidx = 16 * g + (rc & 15);
+    f16x8 xh[NKS], xl[NKS];
+    load_tile(a.XIN, tl, lidx, xh, xl);
+    const int n_ck = a.kcnt[2 * b], n_ak = a.kcnt[2 * b + 1];
+    const bool isq = rc < G.P && !is_ctx(G, b, rc);
+
+    f32x4 y[NMT];
+    // ---- Q^T = Wq X^T (pre-scaled by log2(e) / sqrt(hd)) ----------------------------------------------------------
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NKS; ++cc) {
+      const f16x8 *fr = st.next();
+      chunk_linear(y, fr, xh[cc], xl[cc]);
+    }
+    f16x8 qh[H], ql[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 16 + 4 * g);
+      split_frag(y[2 * h] * WINV + c0, y[2 * h + 1] * WINV + c1, qh[h], ql[h]);
+    }
+    // ---- attention: context and target rows see the context keys, query rows also the visible targets -------------
+    {
+      const u32x4 *kv = a.KV + (long)b * KV_EP + lane;
+      const int nv = (isq ? n_ak : n_ck) - 4 * g;          // key 16 kt + 4 g + r is visible iff 16 kt + r < nv
+      const int nkt = __builtin_amdgcn_readfirstlane((n_ak + 15) >> 4);     // (uniform per wave: one episode per tile)
+      if (nkt <= 1) attention_tile<1>(qh, ql, kv, nv);
+      else if (nkt == 2) attention_tile<2>(qh, ql, kv, nv);
+      else attention_tile<4>(qh, ql, kv, nv);
+    }
+    // ---- X1 = LN1(X + bo + Wo A) -------------------------------------------------------------------------------------
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NKS; ++cc) {
+      const f16x8 *fr = st.next();
+      chunk_linear(y, fr, qh[cc], ql[cc]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+      y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(bo + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
+    layer_norm(y, ln1w, ln1b, g);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) split_frag(y[2 * ks], y[2 * ks + 1], xh[ks], xl[ks]);
+    // ---- X = LN2(X1 + b2 + W2 relu(W1 X1 + b1)): 32 hidden units per chunk pair ---------------------------------------
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < F / 32; ++c) {
+      f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+      {
+        const f16x8 *fr = st.next();
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          mfma3(h0, PAIR_HI(fr, 2 * ks), PAIR_LO(fr, 2 * ks), xh[ks], xl[ks]);
+          mfma3(h1, PAIR_HI(fr, 2 * ks + 1), PAIR_LO(fr, 2 * ks + 1), xh[ks], xl[ks]);
+        }
+      }
+      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 16 + 4 * g);
+      h0 = h0 * WINV + c0; h1 = h1 * WINV + c1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { h0[r] = relu_nn(h0[r]); h1[r] = relu_nn(h1[r]); }
+      f16x8 hbh, hbl;
+      split_frag(h0, h1, hbh, hbl);
+      const f16x8 *fr = st.next();
+      chunk_linear(y, fr, hbh, hbl);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+      y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(b2 + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
+    layer_norm(y, ln2w, ln2b, g);
+    const bool ztgt = LAST && a.zimg && rowok && r >= G.P;
+    const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      f16x8 oh, ol;
+      split_frag(y[2 * ks], y[2 * ks + 1], oh, ol);
+      if (rowok) {
+        a.XOUT[xpiece(tl, ks, 0, lidx)] = __builtin_bit_cast(u32x4, oh);
+        a.XOUT[xpiece(tl, ks, 1, lidx)] = __builtin_bit_cast(u32x4, ol);
+      }
+      if (ztgt) {
+        a.zimg[xpiece(zr >> 4, ks, 0, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, oh);
+        a.zimg[xpiece(zr >> 4, ks, 1, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, ol);
+      }
+    }
+  }
+  st.finish();
+}
+
+// ---- acquisition head (NOUT = 1, model/head.py:27-33) / one GMM head (NOUT = 3, model/head.py:152-186) --------------
+// out[row * out_stride + out_off + j] = w2[j] . relu(W1 z + b1) + b2[j] over the 16-row tiles of an image
+struct HeadArgs {
+  const u32x4 *X; long ntiles, M;
+  const unsigned *img; int F, ngroups;
+  float *out; int out_stride, out_off;
+};
+template <int NOUT>
+__global__ __launch_bounds__(THREADS) void head_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *prm = reinterpret_cast<float *>(lds + NBUF * CHUNK_BYTES);      // b1 [F] | w2 [3][F] | b2 [4]
+  const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int F = a.F;
+  {
+    const float *gprm = reinterpret_cast<const float *>(a.img + (long)head_chunks(F) * CHUNK_WORDS);
+    for (int i = tid; i < head_params(F); i += THREADS) prm[i] = gprm[i];
+  }
+  const char *wbase = reinterpret_cast<const char *>(a.img);
+  auto st = make_stream([wbase](int s) { return wbase + (long)s * CHUNK_BYTES; }, lds, F / 32, tid);
+  st.start();
+  __syncthreads();
+  for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+    const long tile = (long)grp * WAVES + wave;
+    const bool valid = tile < a.ntiles;
+    const long tl = valid ? tile : a.ntiles - 1;
+    const long row = 16 * tl + tok;
+    f16x8 xh[NKS], xl[NKS];
+    load_tile(a.X, tl, lane, xh, xl);
+    float plog[NOUT];
+#pragma unroll
+    for (int jo = 0; jo < NOUT; ++jo) plog[jo] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < F / 32; ++c) {
+      f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+      const f16x8 *fr = st.next();
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        mfma3(h0, PAIR_HI(fr, 2 * ks), PAIR_LO(fr, 2 * ks), xh[ks], xl[ks]);
+        mfma3(h1, PAIR_HI(fr, 2 * ks + 1), PAIR_LO(fr, 2 * ks + 1), xh[ks], xl[ks]);
+      }
+      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(prm + 32 * c + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(prm + 32 * c + 16 + 4 * g);
+      h0 = h0 * WINV + c0; h1 = h1 * WINV + c1;
+#pragma unroll
+      for (int jo = 0; jo < NOUT; ++jo) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(prm + (1 + jo) * F + 32 * c + 4 * g);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(prm + (1 + jo) * F + 32 * c + 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          plog[jo] = fmaf(relu_nn(h0[r]), w0[r], plog[jo]);
+          plog[jo] = fmaf(relu_nn(h1[r]), w1[r], plog[jo]);
+        }
+      }
+    }
+#pragma unroll
+    for (int jo = 0; jo < NOUT; ++jo) {
+      const float v = group_sum4(plog[jo]) + prm[4 * F + jo];
+      if (g == 0 && valid && row < a.M) a.out[row * a.out_stride + a.out_off + jo] = v;
+    }
+  }
+  st.finish();
+}
+
+}  // namespace x3

@@ -46,7 +46,7 @@ class Aline(nn.Module):
             self.set_precision(precision)
 
     def set_precision(self, precision: str):
-        """'f32' (reference precision), 'bf16' or 'bf16x3' for the matrix products."""
+        """'f32' / 'f16x3' (reference precision: exact fp32 MFMA / 3-term f16 split), 'bf16' or 'bf16x3'."""
         if precision not in _lib.PREC:
             raise ValueError(precision)
         for mod in (self.embedder, self.encoder, self.head):

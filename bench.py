@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--d-ff", type=int, default=128)
     ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3", "f16x3"])
     ap.add_argument("--graph", type=int, default=1, help="replay the rollout from one HIP graph")
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -336,7 +336,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32 (fp32 MFMA; FFN/acquisition products as exact 3-way split-bf16, fp32 accumulate)",
-                  "bf16": "bf16", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)"}[args.precision],
+                  "bf16": "bf16", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)", "f16x3": "f32-grade (3-term split-f16 MFMA, fp32 accumulate)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": "location_finding K=1, batch=1000, T=30, n_query_init=200: T-step rollout "
                                "forward (embed + encoder + heads + design sampling + context update + "

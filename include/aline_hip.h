@@ -36,9 +36,12 @@ enum { ALINE_EMB_DATA = 0, ALINE_EMB_THETA = 1, ALINE_EMB_MIX = 2 };
 
 /* arithmetic of the matrix products (accumulation, LayerNorm, softmax, log-likelihoods are
  * always fp32):  F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the reference-precision mode;
- * BF16 = one bf16 MFMA pass; BF16X3 = split-bf16 (hi*hi + hi*lo + lo*hi), ~fp32 accuracy at
- * 3 bf16 MFMA passes. */
-enum { ALINE_PREC_F32 = 0, ALINE_PREC_BF16 = 1, ALINE_PREC_BF16X3 = 2 };
+ * BF16 = one bf16 MFMA pass; BF16X3 = split-bf16 (hi*hi + hi*lo + lo*hi), ~2^-16 relative error at
+ * 3 bf16 MFMA passes; F16X3 = the same 3-term split in f16 (11 + 11 significant bits, dropped term
+ * <= 2^-24): reference-grade results (posterior log-likelihood within 1e-4 of the fp32 reference on
+ * every fixture, like F32) at 3 passes of the f16/bf16 matrix pipe -- the parity mode of the wide
+ * (d = 256) path and of the generic GEMMs.  Inputs to F16X3 products must be below 65504 in magnitude. */
+enum { ALINE_PREC_F32 = 0, ALINE_PREC_BF16 = 1, ALINE_PREC_BF16X3 = 2, ALINE_PREC_F16X3 = 3 };
 
 /* design selection of model/head.py:350-358 */
 enum { ALINE_SELECT_ARGMAX = 0,   /* eval: max -> log            (head.py:355-358) */

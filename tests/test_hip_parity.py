@@ -86,7 +86,8 @@ def test_step_api_teacher_forced(golden, name, mode):
 
 # Measured on MI355X over all fixtures: f32 <= 3e-5, bf16x3 1.1e-4..4.0e-4, bf16 0.06..0.40.  Only
 # f32 meets the north-star 1e-4 NLL bound; the bf16 modes are throughput modes with stated bounds.
-@pytest.mark.parametrize("precision,nll_tol", [("f32", 1e-4), ("bf16x3", 1e-3), ("bf16", 0.6)])
+# f16x3 (3-term f16 split, x3.h / gemm.h PREC 3) is the second reference-precision mode: same 1e-4 bound as f32.
+@pytest.mark.parametrize("precision,nll_tol", [("f32", 1e-4), ("f16x3", 1e-4), ("bf16x3", 1e-3), ("bf16", 0.6)])
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
 def test_rollout_api_teacher_forced(golden, name, precision, nll_tol):
     """Static-slot rollout (one C call for T steps) vs the reference: NLLs, log-probs, designs."""
@@ -104,9 +105,9 @@ def test_rollout_api_teacher_forced(golden, name, precision, nll_tol):
     nll_q, nll = ro.nlls(dims["embedding_type"], fx.meta["mask_type"])
     assert maxdiff(nll, fx.t(f"{mode}.nll")) < nll_tol
     assert maxdiff(nll_q, fx.t(f"{mode}.nll_q")) < nll_tol
-    assert maxdiff(ro.log_prob, fx.t(f"{mode}.log_probs")) < {"f32": 2e-4, "bf16x3": 2e-3, "bf16": 1.5}[precision]
+    assert maxdiff(ro.log_prob, fx.t(f"{mode}.log_probs")) < {"f32": 2e-4, "f16x3": 2e-4, "bf16x3": 2e-3, "bf16": 1.5}[precision]
     assert (ro.idx.cpu() == fx.forced_idx(mode)).all()
-    if precision == "f32":
+    if precision in ("f32", "f16x3"):
         for t in range(T):
             ref = fx.t(f"{mode}.zt_{t}")
             assert maxdiff(ro.zt[t, :, :ref.shape[1]], ref) < tols(dims)["p"]

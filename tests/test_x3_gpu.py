@@ -1,0 +1,98 @@
+"""x3 path (aline_amd/csrc/x3.h): d_model = 256, 8 heads, every matrix product a 3-term f16 split on the matrix
+pipe (precision "f16x3").  It claims REFERENCE precision, so the bounds here are the fp32 bounds: posterior
+log-likelihood within 1e-4 of the exact-fp32 pipeline of the same C ABI on the same weights and forced designs
+(the committed reference fixture is checked in test_hip_parity::test_rollout_api_teacher_forced[f16x3])."""
+import os
+
+import pytest
+import torch
+
+from helpers import native_model
+
+pytestmark = pytest.mark.gpu
+
+DIMS = {"dim_x": 2, "dim_y": 1, "d": 256, "F": 1024, "n_head": 8, "L": 2, "C": 10, "n_theta": 2,
+        "embedding_type": "theta", "time_token": False}
+LL_TOL, LP_TOL = 1e-4, 1e-4
+
+
+def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, dims=DIMS):
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    for k in ("ALINE_DISABLE_X3",):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        model, _ = native_model(dims, 11, prec)
+        torch.manual_seed(seed)
+        task = HiddenLocation(device=torch.device("cuda"), n_query_init=n_query)
+        batch = task.sample_batch(B)
+        if target_mask is not None:
+            batch.target_mask = torch.tensor(target_mask, dtype=torch.bool, device="cuda")
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        forced = torch.stack([torch.stack([torch.randint(0, n_query - t, (1,), generator=g)[0] for t in range(T)])
+                              for _ in range(B)]).to("cuda")
+        ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None).run()
+        torch.cuda.synchronize()
+        return ro.target_ll.float().cpu().clone(), ro.log_prob.float().cpu().clone(), ro.idx.cpu().clone()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("B,n_query,T", [(3, 200, 6), (5, 37, 4), (2, 250, 3), (4, 16, 5), (9, 200, 20), (2, 90, 40)])
+def test_x3_matches_fp32_pipeline(B, n_query, T):
+    """N = 203 (13 tiles, the headline shape), 40 (partial tile), 253, 19, more tiles than one workgroup round
+    (9 episodes x 13 tiles), and 43 keys (three key tiles)."""
+    ll_x, lp_x, _ = _run("f16x3", {}, B, n_query, T)
+    ll_f, lp_f, _ = _run("f32", {}, B, n_query, T)
+    assert torch.isfinite(ll_x).all() and torch.isfinite(lp_x).all()
+    assert (ll_x - ll_f).abs().max() < LL_TOL, float((ll_x - ll_f).abs().max())
+    assert (lp_x - lp_f).abs().max() < LP_TOL, float((lp_x - lp_f).abs().max())
+
+
+def test_x3_generic_gemm_policy_matches_fp32():
+    """ALINE_DISABLE_X3 = the generic pipeline with the f16x3 GEMM policy (gemm.h PREC 3): same bound."""
+    ll_g, lp_g, _ = _run("f16x3", {"ALINE_DISABLE_X3": "1"}, 3, 200, 6)
+    ll_f, lp_f, _ = _run("f32", {}, 3, 200, 6)
+    assert (ll_g - ll_f).abs().max() < LL_TOL and (lp_g - lp_f).abs().max() < LP_TOL
+
+
+@pytest.mark.parametrize("mask", [[True, False], [False, True], [False, False]])
+def test_x3_with_target_mask(mask):
+    """Queries attend only the selected targets (encoder.py:110-121)."""
+    ll_x, lp_x, _ = _run("f16x3", {}, 3, 70, 5, target_mask=mask)
+    ll_f, lp_f, _ = _run("f32", {}, 3, 70, 5, target_mask=mask)
+    assert (ll_x - ll_f).abs().max() < LL_TOL and (lp_x - lp_f).abs().max() < LP_TOL
+    _, lp_other, _ = _run("f16x3", {}, 3, 70, 5, target_mask=[not m for m in mask] if any(mask) else [True, True])
+    assert (lp_x - lp_other).abs().max() > 1e-4
+
+
+def test_x3_sixteen_components_and_wide_ffn():
+    """C = 16 mixture components (raw head rows of 48 floats) and F = 2048.  With 16 sharp random components
+    the fp32 pipeline itself is only good to ~3e-4 here (it differs from an fp64 evaluation by that much), so two
+    fp32-grade pipelines are compared at 5e-4."""
+    dims = dict(DIMS, C=16, F=2048, L=1)
+    ll_x, lp_x, _ = _run("f16x3", {}, 2, 40, 3, dims=dims)
+    ll_f, lp_f, _ = _run("f32", {}, 2, 40, 3, dims=dims)
+    assert (ll_x - ll_f).abs().max() < 5e-4 and (lp_x - lp_f).abs().max() < LP_TOL
+
+
+def test_x3_sampling_and_bookkeeping():
+    _, lp, idx = _run("f16x3", {}, 6, 60, 8, select="sample")
+    assert lp.shape == (6, 8) and (lp <= 0).all() and torch.isfinite(lp).all()
+    for t in range(8):
+        assert int(idx[:, t].min()) >= 0 and int(idx[:, t].max()) < 60 - t
+
+
+def test_x3_too_many_keys_falls_back_to_generic():
+    """More than 64 visible keys is outside the x3 kernels' key image: the generic f16x3 pipeline runs instead."""
+    ll_x, lp_x, _ = _run("f16x3", {}, 2, 90, 70)
+    ll_f, lp_f, _ = _run("f32", {}, 2, 90, 70)
+    assert (ll_x - ll_f).abs().max() < LL_TOL and (lp_x - lp_f).abs().max() < LP_TOL
+
+
+def test_x3_is_reproducible():
+    a = _run("f16x3", {}, 9, 200, 6)
+    b = _run("f16x3", {}, 9, 200, 6)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
