@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libaline_hip.so")
+LIB_PATH = os.environ.get("ALINE_HIP_LIB") or os.path.join(_HERE, "csrc", "libaline_hip.so")   # (override: kernel timing experiments)
 
 MAX_LAYERS = 8
 MAX_COMPONENTS = 16

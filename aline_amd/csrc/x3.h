@@ -37,7 +37,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int D = 256, H = 8, HD = 32, NMT = D / 16, NKS = D / 32, WNK = 64;
 constexpr int THREADS = 512, WAVES = THREADS / 64;
 constexpr int CHUNK_PAIRS = 16, CHUNK_BYTES = CHUNK_PAIRS * 2048, CHUNK_WORDS = CHUNK_BYTES / 4;
-constexpr int NBUF = 3, PD = 2;                       // LDS ring, chunks in flight ahead of the one in use
+constexpr int NBUF = 4, PD = 3;                       // LDS ring, chunks issued ahead of the one in use
 constexpr int PIECES_PER_WAVE = CHUNK_BYTES / 1024 / WAVES;
 constexpr float WSCALE = 256.f, WINV = 1.f / 256.f;
 constexpr long KV_EP = 8192;                          // u32x4 per episode: K pairs [h][kt 4] | V^T pairs [i 16][s 2]
@@ -265,53 +265,152 @@ __device__ __forceinline__ void wait_vmcnt() {   // all but the N youngest vecto
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-// Cyclic stream of 32 KB chunks through a ring of NBUF LDS buffers, PD chunks ahead of the one in use.  Every wave
-// moves its 4 KB share of a chunk with 4 LDS-DMA instructions.  next(): this wave's pieces of the chunk have landed
-// (counted vmcnt: later operations only make the wait more conservative), then the workgroup barrier -- after which
-// every wave's pieces are visible and nobody reads the previous chunk any more, so its buffer takes the chunk PD
-// positions further down the stream.
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)(p);
+}
+
+// Cyclic stream of 32 KB chunks through a ring of NBUF = 4 LDS buffers, issued PD = 3 chunks ahead of the one in use.
+// Every wave moves its 4 KB share of a chunk with 4 LDS-DMA instructions.  sync(), once per chunk u: this wave's
+// pieces of the chunks <= u + 1 have landed (counted vmcnt -- only chunk u + 2 may still be in flight; operations
+// issued later only make the wait more conservative), then the workgroup barrier: every wave's pieces of chunks u and
+// u + 1 are visible and nobody reads chunk u - 1 any more, so its buffer may take chunk u + 3 (issue(), once per wave
+// and chunk, any time before the next sync).  Making chunk u + 1 readable already lets the last MFMA batch of chunk u
+// prefetch the first fragments of chunk u + 1, so no wave starts a chunk by waiting for LDS.
+// What the stream costs (timing experiments, tools/x3_variants.sh, layer kernel at the headline shape): 165 us of a 770 us
+// launch disappear with the LDS-DMA instructions removed, none with their vmcnt wait removed, 30 us with the barrier
+// removed; issuing from four waves only (one per SIMD) or from every wave in a different MFMA batch than its SIMD
+// partner changes nothing (+-4 %) -- part of the cost is clock: the chip holds 2.1 GHz with the stream, 2.35 without.
 template <class SrcFn>
 struct Stream {
   SrcFn src;              // position in the cyclic sequence -> first byte of the chunk
   char *ring;
   int seq_len, s_issue, b_issue, b_use;
   unsigned lane_off, wave_off;
+  int dma_slot;           // the MFMA batch (0..3) of a chunk behind which this wave issues its pieces (0: all waves)
   __device__ __forceinline__ void issue() {
+#ifndef X3_NO_DMA      // (timing experiments only: tools/x3_variants.sh)
     const char *p = src(s_issue) + wave_off + lane_off;
     char *d = ring + b_issue * CHUNK_BYTES + wave_off;
 #pragma unroll
     for (int i = 0; i < PIECES_PER_WAVE; ++i) glds16(p + i * 1024, d + i * 1024);
+#endif
     s_issue = s_issue + 1 == seq_len ? 0 : s_issue + 1;
-    b_issue = b_issue + 1 == NBUF ? 0 : b_issue + 1;
+    b_issue = (b_issue + 1) & (NBUF - 1);
   }
   __device__ __forceinline__ void start() {
 #pragma unroll
     for (int i = 0; i < PD; ++i) issue();
   }
-  __device__ __forceinline__ const f16x8 *next() {
-    wait_vmcnt<PIECES_PER_WAVE *(PD - 1)>();
+  __device__ __forceinline__ void sync() {
+#ifndef X3_NO_WAIT     // (timing experiments only)
+    wait_vmcnt<PIECES_PER_WAVE *(PD - 2)>();
+#endif
+#ifndef X3_NO_BARRIER  // (timing experiments only)
     __builtin_amdgcn_s_barrier();
-    issue();
-    const f16x8 *fr = reinterpret_cast<const f16x8 *>(ring + b_use * CHUNK_BYTES + lane_off);
-    b_use = b_use + 1 == NBUF ? 0 : b_use + 1;
-    return fr;
+#endif
   }
+  // LDS byte address of this lane's 16 bytes of fragment 0 of the chunk in use / of the next one
+  __device__ __forceinline__ const f16x8 *cur() const { return reinterpret_cast<const f16x8 *>(ring + b_use * CHUNK_BYTES + lane_off); }
+  __device__ __forceinline__ const f16x8 *nxt() const { return reinterpret_cast<const f16x8 *>(ring + ((b_use + 1) & (NBUF - 1)) * CHUNK_BYTES + lane_off); }
+  __device__ __forceinline__ void advance() { b_use = (b_use + 1) & (NBUF - 1); }
   __device__ __forceinline__ void finish() { wait_vmcnt<0>(); }   // no LDS-DMA may outlive the workgroup
 };
 template <class SrcFn>
 __device__ __forceinline__ Stream<SrcFn> make_stream(SrcFn src, char *ring, int seq_len, int tid) {
-  Stream<SrcFn> s{src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u,
-                  (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * (unsigned)(PIECES_PER_WAVE * 1024)};
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Stream<SrcFn> s{src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u, (unsigned)wave * (unsigned)(PIECES_PER_WAVE * 1024),
+#ifdef X3_DMA_SPREAD     // (timing experiment: partner waves issue two batches apart; 5 % slower than all behind batch 0)
+                  (wave + 2 * (wave >> 2)) & 3};
+#else
+                  0};
+#endif
   return s;
 }
-// pair p of the chunk in use
-#define PAIR_HI(fr, p) (fr)[(2 * (p)) * 64]
-#define PAIR_LO(fr, p) (fr)[(2 * (p) + 1) * 64]
 
-// Y^T (16 feature tiles) += W[:, k-step] X^T[k-step]: one chunk = the 16 feature-tile pairs of one k-step
-__device__ __forceinline__ void chunk_linear(f32x4 (&y)[NMT], const f16x8 *fr, const f16x8 &bh, const f16x8 &bl) {
+// The 16 fragment pairs of a chunk go through a register ring in 4 batches of 4 pairs (2 x 32 VGPRs): the 8
+// ds_read_b128 of batch k + 1 (after the last batch: of the first batch of the NEXT chunk, which sync() has already made
+// readable) are issued in front of the 12 MFMAs of batch k and land while they run.  The sched_group_barriers pin that
+// order (left alone the scheduler sinks every read to its use and the wave waits a full LDS round trip per fragment).
+struct FragRing { f16x8 hi[2][4], lo[2][4]; };
+__device__ __forceinline__ void fetch_batch(FragRing &r, int slot, const f16x8 *fr, int batch) {
 #pragma unroll
-  for (int m = 0; m < NMT; ++m) mfma3(y[m], PAIR_HI(fr, m), PAIR_LO(fr, m), bh, bl);
+  for (int j = 0; j < 4; ++j) {
+    r.hi[slot][j] = fr[(2 * (4 * batch + j)) * 64];
+    r.lo[slot][j] = fr[(2 * (4 * batch + j) + 1) * 64];
+  }
+}
+// The compiler's wait for a batch goes where its registers are first used.  touch_batch() is that use, placed BEFORE the
+// reads of the following batch are issued: with an LDS-DMA pending hipcc waits lgkmcnt(0) instead of a counted wait, and
+// a wait placed after the next batch's reads would drain those too (a full LDS round trip per batch).
+__device__ __forceinline__ void touch_batch(FragRing &r, int slot) {
+  asm volatile("" : "+v"(r.hi[slot][0]), "+v"(r.lo[slot][0]), "+v"(r.hi[slot][1]), "+v"(r.lo[slot][1]),
+                    "+v"(r.hi[slot][2]), "+v"(r.lo[slot][2]), "+v"(r.hi[slot][3]), "+v"(r.lo[slot][3]));
+}
+__device__ __forceinline__ void prime(FragRing &r, const f16x8 *base) { fetch_batch(r, 0, base, 0); }
+// One chunk: body(p, A_hi, A_lo) consumes pair p with exactly 3 MFMAs.  Precondition: ring slot 0 holds (or is being
+// read with) batch 0 of `cur`, and the sync() of this chunk has been passed.  Ends with the sync() of the next chunk.
+template <bool PREFETCH_NEXT, class St, class Body>
+__device__ __forceinline__ void chunk_pipe(St &st, FragRing &r, const f16x8 *cur, const f16x8 *nxt, Body body) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    __builtin_amdgcn_sched_barrier(0);
+    touch_batch(r, k & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k < 3) {
+      fetch_batch(r, (k + 1) & 1, cur, k + 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    } else if (PREFETCH_NEXT) {
+      fetch_batch(r, 0, nxt, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(4 * k + j, r.hi[k & 1][j], r.lo[k & 1][j]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k == st.dma_slot) st.issue();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  st.sync();
+}
+// Convention: a kernel calls st.sync() once after st.start(); from then on every chunk carries the sync that publishes
+// the chunk after the next one, so a phase starts with its first chunk already readable.
+// A run of N chunks (one phase of a kernel): pair p of chunk i is consumed by body(i, p, A_hi, A_lo).
+template <int N, class St, class Body>
+__device__ __forceinline__ void chunk_run(St &st, FragRing &r, Body body) {
+  prime(r, st.cur());
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const f16x8 *cur = st.cur(), *nx = st.nxt();
+    st.advance();
+    if (i + 1 < N) chunk_pipe<true>(st, r, cur, nx, [&](int p, const f16x8 &ah, const f16x8 &al) { body(i, p, ah, al); });
+    else chunk_pipe<false>(st, r, cur, nx, [&](int p, const f16x8 &ah, const f16x8 &al) { body(i, p, ah, al); });
+  }
+}
+// FFN-shaped run over F/32 groups of 32 hidden units: chunk A = the group's W1 pairs (k-step p >> 1, hidden tile
+// p & 1) -> hidden units in registers; chunk B = the group's W2 pairs -> consume(c, p, A_hi, A_lo) with the hidden
+// fragment pair made by `hidden(c, h0, h1)`.  Fragment prefetch runs across all chunk boundaries of the run.
+template <class St, class Hidden, class Consume>
+__device__ __forceinline__ void ffn_run(St &st, FragRing &r, int ngroups, const f16x8 (&xh)[NKS], const f16x8 (&xl)[NKS],
+                                        Hidden hidden, Consume consume) {
+  prime(r, st.cur());
+#pragma unroll 1
+  for (int c = 0; c < ngroups; ++c) {
+    f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+    {
+      const f16x8 *cur = st.cur(), *nx = st.nxt();
+      st.advance();
+      chunk_pipe<true>(st, r, cur, nx, [&](int p, const f16x8 &ah, const f16x8 &al) {
+        if (p & 1) mfma3(h1, ah, al, xh[p >> 1], xl[p >> 1]);
+        else mfma3(h0, ah, al, xh[p >> 1], xl[p >> 1]);
+      });
+    }
+    hidden(c, h0, h1);
+    {
+      const f16x8 *cur = st.cur(), *nx = st.nxt();
+      st.advance();
+      chunk_pipe<true>(st, r, cur, nx, [&](int p, const f16x8 &ah, const f16x8 &al) { consume(c, p, ah, al); });
+    }
+  }
 }
 
 __device__ __forceinline__ void load_tile(const u32x4 *X, long tile, int lane_idx, f16x8 (&xh)[NKS], f16x8 (&xl)[NKS]) {
@@ -363,6 +462,8 @@ __global__ __launch_bounds__(THREADS) void kv_kernel(KvArgs a) {
   auto st = make_stream([wbase](int s) { return wbase + (long)s * CHUNK_BYTES; }, lds, 16, tid);
   st.start();
   __syncthreads();
+  st.sync();
+  FragRing ring;
   const long ntiles = (long)a.g.B * a.nkt2;
   for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
     const long tile = (long)grp * WAVES + wave;
@@ -382,11 +483,7 @@ __global__ __launch_bounds__(THREADS) void kv_kernel(KvArgs a) {
     // K^T = Wk KX^T: rows = channels, columns = keys -> A fragments of S^T = K Q^T, pair (head, kt)
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cc = 0; cc < NKS; ++cc) {
-      const f16x8 *fr = st.next();
-      chunk_linear(y, fr, xh[cc], xl[cc]);
-    }
+    chunk_run<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, xh[cc], xl[cc]); });
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const f32x4 b0 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 4 * g), b1 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 16 + 4 * g);
@@ -401,12 +498,7 @@ __global__ __launch_bounds__(THREADS) void kv_kernel(KvArgs a) {
     // V[key 16 kt + 4 g + r][channel 16 i + tok] -- half (kt & 1) of this lane's piece of the V^T pair (i, kt / 2)
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cc = 0; cc < NKS; ++cc) {
-      const f16x8 *fr = st.next();
-#pragma unroll
-      for (int m = 0; m < NMT; ++m) mfma3(y[m], xh[cc], xl[cc], PAIR_HI(fr, m), PAIR_LO(fr, m));
-    }
+    chunk_run<NKS>(st, ring, [&](int cc, int m, const f16x8 &bh, const f16x8 &bl) { mfma3(y[m], xh[cc], xl[cc], bh, bl); });
 #pragma unroll
     for (int i = 0; i < NMT; ++i) {
       const float bv = prm[D + 16 * i + tok];
@@ -500,6 +592,8 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
   auto st = make_stream([wbase](int s) { return wbase + (long)(s < 8 ? s : s + 16) * CHUNK_BYTES; }, lds, seq, tid);
   st.start();
   __syncthreads();
+  st.sync();
+  FragRing ring;
   const long ntiles = (long)G.B * a.tpe;
   for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
     const long tile = (long)grp * WAVES + wave;
@@ -518,11 +612,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     // ---- Q^T = Wq X^T (pre-scaled by log2(e) / sqrt(hd)) ----------------------------------------------------------
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cc = 0; cc < NKS; ++cc) {
-      const f16x8 *fr = st.next();
-      chunk_linear(y, fr, xh[cc], xl[cc]);
-    }
+    chunk_run<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, xh[cc], xl[cc]); });
     f16x8 qh[H], ql[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -541,11 +631,8 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     // ---- X1 = LN1(X + bo + Wo A) -------------------------------------------------------------------------------------
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cc = 0; cc < NKS; ++cc) {
-      const f16x8 *fr = st.next();
-      chunk_linear(y, fr, qh[cc], ql[cc]);
-    }
+    chunk_run<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, qh[cc], ql[cc]); });
+    load_tile(a.XIN, tl, lidx, xh, xl);      // the residual (not kept through the out-projection: registers)
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(bo + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
@@ -555,25 +642,17 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     // ---- X = LN2(X1 + b2 + W2 relu(W1 X1 + b1)): 32 hidden units per chunk pair ---------------------------------------
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int c = 0; c < F / 32; ++c) {
-      f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
-      {
-        const f16x8 *fr = st.next();
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          mfma3(h0, PAIR_HI(fr, 2 * ks), PAIR_LO(fr, 2 * ks), xh[ks], xl[ks]);
-          mfma3(h1, PAIR_HI(fr, 2 * ks + 1), PAIR_LO(fr, 2 * ks + 1), xh[ks], xl[ks]);
-        }
-      }
-      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 16 + 4 * g);
-      h0 = h0 * WINV + c0; h1 = h1 * WINV + c1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { h0[r] = relu_nn(h0[r]); h1[r] = relu_nn(h1[r]); }
+    {
       f16x8 hbh, hbl;
-      split_frag(h0, h1, hbh, hbl);
-      const f16x8 *fr = st.next();
-      chunk_linear(y, fr, hbh, hbl);
+      ffn_run(st, ring, F / 32, xh, xl,
+              [&](int c, f32x4 &h0, f32x4 &h1) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 16 + 4 * g);
+                h0 = h0 * WINV + c0; h1 = h1 * WINV + c1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { h0[r] = relu_nn(h0[r]); h1[r] = relu_nn(h1[r]); }
+                split_frag(h0, h1, hbh, hbl);
+              },
+              [&](int, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, hbh, hbl); });
     }
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
@@ -620,6 +699,8 @@ __global__ __launch_bounds__(THREADS) void head_kernel(HeadArgs a) {
   auto st = make_stream([wbase](int s) { return wbase + (long)s * CHUNK_BYTES; }, lds, F / 32, tid);
   st.start();
   __syncthreads();
+  st.sync();
+  FragRing ring;
   for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
     const long tile = (long)grp * WAVES + wave;
     const bool valid = tile < a.ntiles;
@@ -630,14 +711,18 @@ __global__ __launch_bounds__(THREADS) void head_kernel(HeadArgs a) {
     float plog[NOUT];
 #pragma unroll
     for (int jo = 0; jo < NOUT; ++jo) plog[jo] = 0.f;
+    prime(ring, st.cur());
 #pragma unroll 1
     for (int c = 0; c < F / 32; ++c) {
       f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
-      const f16x8 *fr = st.next();
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        mfma3(h0, PAIR_HI(fr, 2 * ks), PAIR_LO(fr, 2 * ks), xh[ks], xl[ks]);
-        mfma3(h1, PAIR_HI(fr, 2 * ks + 1), PAIR_LO(fr, 2 * ks + 1), xh[ks], xl[ks]);
+      {
+        const f16x8 *cur = st.cur(), *nx = st.nxt();
+        st.advance();
+        auto w1 = [&](int p, const f16x8 &ah, const f16x8 &al) {
+          if (p & 1) mfma3(h1, ah, al, xh[p >> 1], xl[p >> 1]);
+          else mfma3(h0, ah, al, xh[p >> 1], xl[p >> 1]);
+        };
+        chunk_pipe<true>(st, ring, cur, nx, w1);
       }
       const f32x4 c0 = *reinterpret_cast<const f32x4 *>(prm + 32 * c + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(prm + 32 * c + 16 + 4 * g);
       h0 = h0 * WINV + c0; h1 = h1 * WINV + c1;

@@ -4,7 +4,9 @@
 #   tools/pmc_all.sh d256  -> wide::wide_step_kernel      (--d-model 256 --d-ff 1024 --heads 8 --precision bf16)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-if [ "$1" = "d256" ]; then ARGS="--d-model 256 --d-ff 1024 --heads 8 --precision bf16"; else ARGS=""; fi
+#   tools/pmc_all.sh x3    -> x3::layer_kernel            (--d-model 256 --d-ff 1024 --heads 8 --precision f16x3)
+if [ "$1" = "d256" ]; then ARGS="--d-model 256 --d-ff 1024 --heads 8 --precision bf16";
+elif [ "$1" = "x3" ]; then ARGS="--d-model 256 --d-ff 1024 --heads 8 --precision f16x3"; else ARGS=""; fi
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" \
@@ -12,5 +14,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$1/p$i -- python3 $R/bench.py $ARGS --steps 1 --warmup 1 --graph 0 --no-cpu-baseline --train-steps 0 > $R/gpurun_out/pmc_$1_$i.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$1$TAG/p$i -- python3 $R/bench.py $ARGS --steps 1 --warmup 1 --graph 0 --no-cpu-baseline --train-steps 0 > $R/gpurun_out/pmc_$1${TAG}_$i.log 2>&1 || exit 1
 done
