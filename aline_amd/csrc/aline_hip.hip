@@ -225,7 +225,7 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
   const int hd = d / m.H;
   // small-width model in reference precision: the token-local tail of a layer (out-projection, LN1, FFN, LN2) is
   // one kernel on the packed layer images of the fused path (fused_tail.h)
-  const bool tail = m.precision == ALINE_PREC_F32 && d == fused::D && F == fused::F && !getenv("ALINE_NO_LAYER_TAIL");
+  const bool tail = (m.precision == ALINE_PREC_F32 || m.precision == ALINE_PREC_F16X3) && d == fused::D && F == fused::F && !getenv("ALINE_NO_LAYER_TAIL");
   float *wimg = c.at(c.pl.Wpack);
   if (tail) {
     fused::PackArgs pa{};
@@ -300,7 +300,7 @@ struct HeadIO {
 static int gmm_heads(const Ctx &c, GemmArgs a, int rows, float *mean, float *sd, float *wgt, const float *value,
                      float *ll, long value_row0, long value_mod) {
   const aline_model &m = *c.m;
-  if (m.precision == ALINE_PREC_F32 && m.d == fused::D && m.F == fused::F && !getenv("ALINE_NO_LAYER_TAIL")) {
+  if ((m.precision == ALINE_PREC_F32 || m.precision == ALINE_PREC_F16X3) && m.d == fused::D && m.F == fused::F && !getenv("ALINE_NO_LAYER_TAIL")) {
     // small-width model: all C heads, the parameter maps and compute_ll in one kernel on the transposed register
     // scheme of the fused path (fused_side.h), first layers as packed split-bf16 fragments
     float *side = c.at(c.pl.Wpack) + (size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS;
@@ -619,8 +619,11 @@ int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void
   HeadIO io{};
   if (m->time_token) {
     float *sc = c.at(c.pl.scalar);
-    const int TT = r->time_token_T > 0 ? r->time_token_T : r->T;
-    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, c.st, sc, (float)t / (float)TT);
+    // t / T as the training loop feeds it (train_aline.py:82); time_token_T < 0 selects the schedule of the reference's
+    // evaluation loop, (T - t) / T (utils/eval.py:24)
+    const int TT = r->time_token_T > 0 ? r->time_token_T : r->time_token_T < 0 ? -r->time_token_T : r->T;
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, c.st, sc,
+                       r->time_token_T < 0 ? (float)(TT - t) / (float)TT : (float)t / (float)TT);
     CHECK_LAUNCH();
     io.time_t = sc;
   }

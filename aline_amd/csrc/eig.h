@@ -142,14 +142,24 @@ __global__ __launch_bounds__(256) void eig_ces_step_kernel(const float *__restri
 //   lp = -z^2 / 2 - log(sd) - c + softplus(-x) + softplus(x),  z = (logit(y) - (U1 - U2) u) / sd,  sd = dn * u,
 //   log(sd) = log(dn) + theta_4 exactly (u = exp(theta_4)).
 // 11 transcendentals per (l, b) instead of 8 powf + ~12 more; censored outcomes (y at eps / 1 - eps) take the
-// general csn_log_prob.  Table row = 20 floats; used when B * 80 bytes fits 48 KB.
-constexpr int CES_ROW = 20;
+// general csn_log_prob.  Table row = 24 floats; used when B * 96 bytes fits 48 KB.
+constexpr int CES_ROW = 24;
+// 2^a - 1 and log2(1 + r) without cancellation for small arguments (series below 2^-3 / 0.1, the native units above)
+__device__ __forceinline__ float exp2m1_f(float a) {
+  const float z = a * 0.69314718055994530942f;
+  const float p = z * (1.f + z * (0.5f + z * (0.16666666666666666f + z * (0.041666666666666664f + z * (0.0083333333333333332f + z * 0.0013888888888888889f)))));
+  return fabsf(a) < 0.125f ? p : __builtin_amdgcn_exp2f(a) - 1.f;
+}
+__device__ __forceinline__ float log2_1p_f(float r) {
+  const float p = r * (1.f + r * (-0.5f + r * (0.33333333333333331f + r * (-0.25f + r * (0.2f + r * (-0.16666666666666666f + r * (0.14285714285714285f + r * -0.125f)))))));
+  return fabsf(r) < 0.1f ? p * 1.44269504088896340736f : __builtin_amdgcn_logf(1.f + r);
+}
 __global__ __launch_bounds__(256) void eig_ces_step_table_kernel(const float *__restrict__ theta,
                                                                  const float *__restrict__ xi,
                                                                  const float *__restrict__ y,
                                                                  float *__restrict__ S, long L1, int B,
                                                                  float noise, float eps, int *nan_flag) {
-  extern __shared__ float tab[];        // [B][CES_ROW]: x[6] | log2 x[6] | 1/dn | cst | logit(y) | kind | dn | y
+  extern __shared__ float tab[];        // [B][CES_ROW]: x[6] | log2 x[6] | 1/dn | cst | logit(y) | kind | dn | y | log2(xa / xb)[3]
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     float *r = tab + b * CES_ROW;
     float x[6];
@@ -166,6 +176,8 @@ __global__ __launch_bounds__(256) void eig_ces_step_table_kernel(const float *__
     r[15] = __int_as_float(kind);
     r[16] = dn;
     r[17] = v;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[18 + c] = (float)log2((double)x[c] / (double)x[3 + c]);
   }
   __syncthreads();
   const long total = L1 * B;
@@ -182,24 +194,29 @@ __global__ __launch_bounds__(256) void eig_ces_step_table_kernel(const float *__
     const float *r = tab + b * CES_ROW;
     const int kind = __float_as_int(r[15]);
     float lp;
-    if (kind == 0) {
-      const float ir = 1.f / rho;
-      const float s1 = a0 * __builtin_amdgcn_exp2f(rho * r[6]) + a1 * __builtin_amdgcn_exp2f(rho * r[7]) +
-                       a2 * __builtin_amdgcn_exp2f(rho * r[8]);
-      const float s2 = a0 * __builtin_amdgcn_exp2f(rho * r[9]) + a1 * __builtin_amdgcn_exp2f(rho * r[10]) +
-                       a2 * __builtin_amdgcn_exp2f(rho * r[11]);
-      const float u1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(s1) * ir);
-      const float u2 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(s2) * ir);
-      // z = (logit(y) - (u1 - u2) u) / (dn u)
-      const float z = (r[14] * __expf(-t4) - (u1 - u2)) * r[12];
-      lp = -0.5f * z * z - t4 + r[13];
-    } else if (kind == 3) {
+    if (kind == 3) {
       lp = -INFINITY;
     } else {
-      const float u = expf(t4), ir = 1.f / rho;
-      const float u1 = powf(a0 * powf(r[0], rho) + a1 * powf(r[1], rho) + a2 * powf(r[2], rho), ir);
-      const float u2 = powf(a0 * powf(r[3], rho) + a1 * powf(r[4], rho) + a2 * powf(r[5], rho), ir);
-      lp = csn_log_prob(r[17], (u1 - u2) * u, r[16] * u, eps, 1.f - eps);
+      // U_a - U_b without the cancellation of two large utilities (designs with similar baskets are exactly where the
+      // likelihood discriminates): with t_i = x_b,i^rho, e_i = (x_a,i / x_b,i)^rho - 1 and s_b = sum alpha_i t_i,
+      //   s_a / s_b = 1 + (sum alpha_i t_i e_i) / s_b,   U_a - U_b = U_b ((s_a / s_b)^(1/rho) - 1)
+      // every "- 1" / "1 +" taken by series for small arguments.  fp64 says: 1e-4 in the log-likelihood where the plain
+      // fp32 evaluation -- the reference's own -- is 1e-2 .. 5e-2 off (tests/test_r2_gpu.py::test_ces_realistic_regime).
+      const float ir = 1.f / rho;
+      const float t0 = a0 * __builtin_amdgcn_exp2f(rho * r[9]), t1 = a1 * __builtin_amdgcn_exp2f(rho * r[10]),
+                  t2 = a2 * __builtin_amdgcn_exp2f(rho * r[11]);
+      const float s2 = t0 + t1 + t2;
+      const float ds = t0 * exp2m1_f(rho * r[18]) + t1 * exp2m1_f(rho * r[19]) + t2 * exp2m1_f(rho * r[20]);
+      const float u2 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(s2) * ir);
+      const float du = u2 * exp2m1_f(log2_1p_f(ds / s2) * ir);          // u1 - u2
+      if (kind == 0) {
+        // z = (logit(y) - (u1 - u2) u) / (dn u)
+        const float z = (r[14] * __expf(-t4) - du) * r[12];
+        lp = -0.5f * z * z - t4 + r[13];
+      } else {                                     // outcome at a censoring limit: log cdf with its asymptotic tail
+        const float u = expf(t4);
+        lp = csn_log_prob(r[17], du * u, r[16] * u, eps, 1.f - eps);
+      }
     }
     bad |= (lp != lp) || isinf(lp);
     S[i] += lp;                                   // S stays cacheable: the logsumexp pass reads it next

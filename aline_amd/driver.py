@@ -124,10 +124,24 @@ def epoch_target_mask(task_cfg):
     return mask_type, mask
 
 
+def offset_rank_rng(rank, world):
+    """Episode data parallelism: every rank must draw its OWN episodes but the SAME per-epoch T and target
+    mask.  T / mask come from python's `random` (train_aline.py:59,62), the episodes from torch (and numpy): those two are
+    re-seeded per rank, `random` is left alone.  Called at start-up and after load_checkpoint (which restores identical
+    generator states on every rank)."""
+    if world <= 1:
+        return
+    base = int(torch.initial_seed()) % (2 ** 31)
+    torch.manual_seed(base + 1000003 * (rank + 1))              # CPU and CUDA generators
+    np.random.seed((base + 7919 * (rank + 1)) % (2 ** 32))
+
+
 def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_epoch=None, verbose=None,
-          logger=None, dist=None, world=1, on_epoch=None):
+          logger=None, dist=None, world=1, on_epoch=None, rank=0):
     """Epoch loop of train_aline.py:21-181 on the native training step.  Returns the per-epoch records
-    (dicts with epoch, T, mask_type, loss, design_loss, predict_loss, lr, seconds)."""
+    (dicts with epoch, T, mask_type, loss, design_loss, predict_loss, lr, seconds).  With `dist` / `world` > 1 (one
+    process per GPU) every rank trains on its own episodes, gradients are all-reduced once per step; checkpoints and
+    state_dicts are written by rank 0 only, followed by a barrier."""
     if _get(cfg, "time_token", False):
         raise NotImplementedError("aline_amd: the native backward does not cover the time-token variant")
     batch_size = batch_size or _get(cfg, "batch_size")
@@ -143,6 +157,11 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
     start_epoch = 0
     if _get(cfg, "load_checkpoint", False):
         start_epoch, optimizer, scheduler = load_checkpoint(cfg, model, optimizer, scheduler, _get(cfg, "load_path"))
+    offset_rank_rng(rank, world)
+
+    def barrier():
+        if dist is not None and world > 1:
+            dist.barrier()
     full_n_query = _get(task_cfg, "n_query_init", getattr(experiment, "n_query_init", None))
     if start_epoch < burn:
         experiment.n_query_init = _get(cfg, "T")          # fewer candidates while only the predictor trains
@@ -161,7 +180,9 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
             optimizer, scheduler = set_layerwise_lr(cfg, model, epoch)
             experiment.n_query_init = full_n_query
             stem = str(_get(cfg, "file_name", "aline.pth")).split(".")[0]
-            say(f"burn-in finished; model saved at {save_state_dict(model, _get(cfg, 'output_dir', '.'), stem + '_burning.pth')}")
+            if rank == 0:
+                say(f"burn-in finished; model saved at {save_state_dict(model, _get(cfg, 'output_dir', '.'), stem + '_burning.pth')}")
+            barrier()
         optimizer.step()
         scheduler.step()
         rec = dict(epoch=epoch, T=T, mask_type=mask_type, loss=float(terms["loss"]),
@@ -175,5 +196,7 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
             on_epoch(rec)
         every = _get(cfg, "checkpoint", 0)
         if every and (epoch + 1) % every == 0:
-            save_checkpoint(cfg, model, optimizer, scheduler, epoch + 1, with_epoch=True)
+            if rank == 0:
+                save_checkpoint(cfg, model, optimizer, scheduler, epoch + 1, with_epoch=True)
+            barrier()
     return records

@@ -18,7 +18,7 @@ class Rollout:
     """
 
     def __init__(self, model, batch, T, select="argmax", forced_idx=None, uniform=None,
-                 time_token_T=0, keep_zt=False, keep_posterior=True):
+                 time_token_T=0, keep_zt=False, keep_posterior=True, time_token_reverse=False):
         self.model = model
         self.m = model.model_struct()
         g = _native._get
@@ -70,7 +70,8 @@ class Rollout:
             self.forced = forced_idx.to(dev, torch.int64).contiguous()
             assert self.forced.shape == (B, T)
             r.forced_idx = self.forced.data_ptr()
-        r.time_token_T = time_token_T
+        # step t feeds t / T (training loop) or, reversed, (T - t) / T (the reference's eval loop, utils/eval.py:24)
+        r.time_token_T = -(time_token_T or T) if time_token_reverse else time_token_T
         r.idx, r.slot, r.log_prob = self.idx.data_ptr(), self.slot.data_ptr(), self.log_prob.data_ptr()
         r.target_ll = self.target_ll.data_ptr()
         r.zt = _lib.ptr(self.zt)

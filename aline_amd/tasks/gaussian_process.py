@@ -69,8 +69,12 @@ class GPTask(Task):
         ktype = torch.multinomial(w / w.sum(), B, replacement=True)
         K = self.kernel_matrix(x, ls, scale, ktype) + self.jitter * torch.eye(n, device=x.device)
         K = K.contiguous()
-        _lib.check(_lib.lib.aline_cholesky_upper(K.data_ptr(), n, B, None, _lib.stream_ptr(x.device)),
+        info = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _lib.check(_lib.lib.aline_cholesky_upper(K.data_ptr(), n, B, info.data_ptr(), _lib.stream_ptr(x.device)),
                    "cholesky_upper")                                           # K <- U, K = U^T U
+        if int(info.item()) != 0:      # a non-positive pivot (fp32 RBF + jitter can lose definiteness): the reference's
+            # torch.linalg.cholesky raises there (gaussian_process.py:407); a silently wrong factor is never returned
+            raise RuntimeError("aline_amd: GP kernel matrix is not positive definite in fp32 (cholesky info != 0)")
         f = K.transpose(1, 2) @ torch.randn(B, n, 1, device=x.device)          # f = L z
         return f + self.noise_scale * torch.randn(B, n, 1, device=x.device)
 

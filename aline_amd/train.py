@@ -56,6 +56,7 @@ def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, b
     dev = nll.device
     g_logp = torch.zeros(B, T, device=dev)
     design_loss = torch.zeros((), device=dev)
+    R = None
     if T > 1:
         disc = torch.tensor([gamma ** t for t in range(1, T)], device=dev)
         R = disc * torch.clamp(nll_q[:, :-1] - nll_q[:, 1:], min=0.0)    # [B, T-1], detached by construction
@@ -73,7 +74,7 @@ def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, b
         g_ll.fill_(-1.0 / (T * B * n_t))
     loss = predict_loss if burn_in else alpha * design_loss + predict_loss
     return dict(loss=loss, design_loss=design_loss, predict_loss=predict_loss, g_logp=g_logp.contiguous(),
-                g_ll=g_ll.contiguous())
+                g_ll=g_ll.contiguous(), R=R)
 
 
 def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30):

@@ -35,7 +35,8 @@ def get_traces(model, experiment, T=30, batch_size=40, time_token=False):
     model.eval()
     theta_shape = experiment.sample_theta((batch_size)).shape
     batch = experiment.sample_batch(batch_size)
-    ro = Rollout(model, batch, T, select="argmax", time_token_T=T if time_token else 0)
+    # the reference's eval loop feeds batch.t = (T - t) / T (eval.py:24), not the t / T of training
+    ro = Rollout(model, batch, T, select="argmax", time_token_T=T if time_token else 0, time_token_reverse=bool(time_token))
     ro.run()
     cx, cy = ro.export_context()
     theta_0 = batch.target_theta.reshape(*theta_shape)
@@ -43,11 +44,13 @@ def get_traces(model, experiment, T=30, batch_size=40, time_token=False):
 
 
 @torch.no_grad()
-def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=40, stepwise=False):
-    """sPCE / sNMC bounds from a design history (eval.py:42-80)."""
+def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=40, stepwise=False, thetas=None):
+    """sPCE / sNMC bounds from a design history (eval.py:42-80).  `thetas` [L, B, ...] replaces the contrastive draw of
+    eval.py:61 (tests pin the function to the reference's bounds on the reference's own draw)."""
     T = x.shape[1]
     criterion = EIGStepLoss(L, batch_size, experiment, reduction="none", device=x.device)
-    thetas = experiment.sample_theta((L, batch_size))
+    if thetas is None:
+        thetas = experiment.sample_theta((L, batch_size))
     thetas = torch.concat([theta_0.unsqueeze(0), thetas], dim=0).contiguous()
     pce_l, nmc_l = [], []
     for t in range(T):
@@ -63,6 +66,23 @@ def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=4
     else:
         pce, nmc = pce_l[-1], nmc_l[-1]
     return math.log(L + 1) - pce, math.log(L) - nmc
+
+
+def calculate_gmm_variance(mixture_means, mixture_stds, mixture_weights):
+    """Variance of the per-point GMM prediction (utils/misc.py:244-279), the uncertainty-sampling score computed from
+    `posterior_out_query`: sum_c w_c (sd_c^2 + (mu_c - sum_c w_c mu_c)^2).  [B, n, C] (weights may be [B, C]) -> [B, n]."""
+    w = mixture_weights.unsqueeze(1).expand_as(mixture_means) if mixture_weights.dim() == 2 else mixture_weights
+    mean = (w * mixture_means).sum(-1, keepdim=True)
+    return (w * (mixture_stds ** 2 + (mixture_means - mean) ** 2)).sum(-1)
+
+
+def save_bounds(bounds, output_dir, file_name, n_query_final, T_final):
+    """The bounds file of the reference's driver (train_aline.py:271-275): <output_dir>/eval/<stem>_N<n>_T<T>.tar."""
+    import os
+    path = os.path.join(output_dir, "eval", f"{file_name.split('.')[0]}_N{n_query_final}_T{T_final}.tar")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(bounds, path)
+    return path
 
 
 def gather_rows(local, dist=None, world=1):

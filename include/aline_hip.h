@@ -115,7 +115,8 @@ typedef struct aline_rollout {
   int32_t select_mode;
   const float *uniform;                         /* [T,B] */
   const int64_t *forced_idx;                    /* [B,T] index into the compacted query list */
-  int32_t time_token_T;                         /* t/T is fed when model.time_token */
+  int32_t time_token_T;                         /* model.time_token: step t feeds t/T (train_aline.py:82); NEGATIVE: (|T| - t)/|T|, the
+                                                   schedule of the reference's eval loop (utils/eval.py:24); 0: T = this->T */
   /* outputs */
   int64_t *idx;                                 /* [B,T] compacted index (reference convention) */
   int32_t *slot;                                /* [B,T] chosen slot p */

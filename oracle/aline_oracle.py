@@ -276,10 +276,12 @@ def reinforce_losses(log_probs: Tensor, nlls_q: List[Tensor], nlls: List[Tensor]
 
 
 def rollout(sd, batch, cfg, T: int, forced_idx: Optional[Tensor] = None,
-            mask_type: str = "all", with_query_gmm: bool = False):
+            mask_type: str = "all", with_query_gmm: bool = False, time_schedule: str = "train"):
     """T-step acquisition loop (train_aline.py:80-110 / utils/eval.py:24-30).
 
     forced_idx [B, T] teacher-forces the designs; None = eval-mode argmax.
+    time_schedule (time-token models): "train" feeds t / T (train_aline.py:82), "eval" feeds (T - t) / T as the
+    reference's evaluation loop does (utils/eval.py:24).
     Returns per-step lists and the final batch.
     """
     res = {"idx": [], "log_prob": [], "zt": [], "target_ll": [], "nll_q": [], "nll": [],
@@ -287,7 +289,7 @@ def rollout(sd, batch, cfg, T: int, forced_idx: Optional[Tensor] = None,
     for t in range(T):
         if cfg.get("time_token"):
             batch = dict(batch)
-            batch["t"] = torch.tensor([t / T])
+            batch["t"] = torch.tensor([(T - t) / T if time_schedule == "eval" else t / T])
         out = forward(sd, batch, cfg, None if forced_idx is None else forced_idx[:, t],
                       with_query_gmm=with_query_gmm)
         batch = update_batch(batch, out["idx"])

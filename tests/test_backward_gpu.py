@@ -20,6 +20,9 @@ def test_gradients_match_reference_autograd(golden, name):
     torch.cuda.synchronize()
     assert abs(float(terms["predict_loss"]) - float(fx.np("train.predict_loss"))) < 1e-4
     assert abs(float(terms["design_loss"]) - float(fx.np("train.design_loss"))) < 5e-3
+    # the batch-normalised rewards themselves (train_aline.py:113-122): z-scores of clamped NLL gains over B = 4 / 8
+    # episodes, so an NLL difference of 1e-5 next to the clamp moves an entry by ~1e-3
+    assert float((terms["R"].cpu() - fx.t("train.R")).abs().max()) < 5e-3
     worst = ("", 0.0)
     for k, p in model.named_parameters():
         ref = fx.t("train.grad." + k)
