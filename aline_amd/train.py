@@ -95,8 +95,13 @@ def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30):
     return t_chunk
 
 
+ALLREDUCE_CALLS = 0      # collectives issued by this process (bench.py reports the count per optimiser step)
+
+
 def all_reduce_grads(model, dist, world):
     """One flat-bucket all-reduce (sum, then / world) of every gradient (RCCL over xGMI on the node)."""
+    global ALLREDUCE_CALLS
+    ALLREDUCE_CALLS += 1
     params = [p for p in model.parameters() if p.grad is not None]
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat)

@@ -164,6 +164,94 @@ def cpu_baseline(args, model):
                       f"same work as the GPU path (posterior_out_query lazy), {dt:.1f} s"}
 
 
+def x3_layer_flops(d, F, n_c, n_q, n_t, n_s):
+    """Algorithmic FLOPs of ONE x3::layer_kernel launch per episode (one encoder layer of one step, SURVEY 8-d terms): Q
+    projection of all N rows, masked attention core, out-projection, FFN.  (K / V of the key rows: x3::kv_kernel.)"""
+    N = n_c + n_q + n_t
+    return 2 * N * d * d + 4 * d * ((n_c + n_t) * n_c + n_q * (n_c + n_s)) + 2 * N * d * d + 4 * N * d * F
+
+
+def measure_d256(args, device, batch, precision):
+    """Sub-measurement (not `value`): the same workload on the matrix-core-bound model d = 256 / F = 1024 / H = 8.
+    precision f16x3 = the reference-precision x3 path (every product a 3-term f16 split, posterior NLL within 1e-4 of the
+    reference: tests/test_hip_parity.py, tests/test_r2_gpu.py); bf16 = the single-pass wide path (throughput mode, NLL
+    error ~1e-2)."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    d, F, H, L = 256, 1024, 8, args.layers
+    torch.manual_seed(args.seed)
+    model = Aline(Embedder(2, 1, d, F, 2, "theta"), Encoder(d, F, H, 0.0, L), OutputHead(2, 1, d, F, num_components=10))
+    model = model.to(device).set_precision(precision).train()
+    ro = Rollout(model, batch, args.T, select="sample", keep_zt=False, keep_posterior=True)
+    ro.run(); torch.cuda.synchronize(device)
+    ro.capture()
+    ro.refresh_uniform(); ro.replay(); torch.cuda.synchronize(device)
+    steps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ro.refresh_uniform(); ro.replay()
+    e1.record(); torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / steps
+    ev = HipEvents()
+    ro.r.ev_kernel_start, ro.r.ev_kernel_stop = ev.a, ev.b
+    kms = []
+    for _ in range(3):
+        ro.refresh_uniform(); ro.run(); torch.cuda.synchronize(device)
+        k = ev.elapsed_ms()
+        if k is not None:
+            kms.append(k)
+    ro.r.ev_kernel_start, ro.r.ev_kernel_stop = None, None
+    kernel_ms = sum(kms) / len(kms) if kms else None
+    fl_ep = algorithmic_flops_per_episode(2, 1, d, F, H, L, 10, 1, args.n_query, 0, 2, 2, args.T, with_query_gmm=False)
+    whole = fl_ep * args.batch / (ms * 1e-3) / 1e12
+    out = {"model": f"d={d} F={F} H={H} L={L}", "precision": precision, "ms_per_rollout": ms,
+           "value": args.batch * args.T * args.n_query / (ms * 1e-3), "unit": "designs/s",
+           "whole_rollout": {"achieved": whole, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_BF16_DENSE_TFLOPS,
+                             "algorithmic_flops_per_rollout": fl_ep * args.batch}}
+    if kernel_ms:
+        t = args.T - 1                                             # the events bracket the last layer of the last step
+        passes = 3 if precision == "f16x3" else 1
+        if precision == "f16x3":
+            per_launch = x3_layer_flops(d, F, 1 + t, args.n_query - t, 2, 2) * args.batch
+            kname = "x3::layer_kernel<true>"
+        else:
+            fl_all = fused_kernel_flops_per_episode(d, F, L, 1, args.n_query, 2, 2, args.T)
+            per_launch = fl_all / args.T * args.batch
+            kname = "wide::wide_step_kernel<false>"
+        ach = per_launch / (kernel_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": kname, "kernel_ms_per_launch": kernel_ms,
+                           "algorithmic_flops_per_launch": per_launch, "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_BF16_DENSE_TFLOPS, "mfma_passes_per_product": passes,
+                           "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / passes,
+                           "frac_vs_instruction_mix_peak": ach * passes / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                           "peak_note": "dense f16/bf16 MFMA peak (MI355X_MICROARCH.md).  A reference-precision product costs "
+                                        "3 MFMA passes (hi*hi + hi*lo + lo*hi), so the pipe can deliver at most peak / 3 of "
+                                        "algorithmic FLOP/s in this mode: instruction_mix_peak; frac_vs_instruction_mix_peak is "
+                                        "the matrix-pipe utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees: profiles/)"}
+    return out
+
+
+def query_gmm_ms_per_rollout(args, model, device):
+    """Time of posterior_out_query (model/head.py:366: the C GMM heads on the n_query candidate rows) for all T steps of a
+    rollout, through the per-step entry point on encodings of the shapes the rollout sees (n_query - t candidates at step
+    t).  The product computes it lazily (no caller in train_aline.py / utils/eval.py reads it) and the fused rollout kernel
+    keeps encodings on chip, so this is what evaluating it at every step would add."""
+    from aline_amd.utils import AttrDict
+    d = args.d_model
+    z_all = torch.randn(args.batch, 1 + args.n_query + 2 + args.T, d, device=device)
+    def one_pass():
+        for t in range(args.T):
+            n_c, n_q = 1 + t, args.n_query - t
+            fb = AttrDict(context_x=torch.empty(args.batch, n_c, 2, device=device), query_x=torch.empty(args.batch, n_q, 2, device=device),
+                          target_all=torch.empty(args.batch, 2, 1, device=device), target_mask=None)
+            model.head._query_posterior(fb, z_all[:, :n_c + n_q + 2].contiguous())
+    one_pass(); torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); one_pass(); e1.record(); torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1)
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -187,19 +275,43 @@ def main():
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--train-steps", type=int, default=2,
                     help="also time K full training steps (rollout + backward + all-reduce + AdamW); 0 = skip")
+    ap.add_argument("--sustain-s", type=float, default=2.5,
+                    help="after the timed steps, replay the rollout back to back for this many seconds (sustained_ms_per_step)")
+    ap.add_argument("--no-d256", action="store_true", help="skip the d_model = 256 sub-measurement (N = 1 only)")
+    ap.add_argument("--no-query-gmm", action="store_true", help="skip the value_with_query_gmm figure")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything touches the GPU (a process that
+        # has initialised HIP must not be replaced), one per GPU over RCCL, and hand their exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"--gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}")
+        if os.environ.get("ALINE_BENCH_DRY_SPAWN"):          # (tests: show the launch line, start nothing)
+            print(json.dumps({"spawn": cmd}))
+            raise SystemExit(0)
+        raise SystemExit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}: the launcher started a different number of ranks")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
+        joined = torch.ones(1, device=device)
+        dist.all_reduce(joined)
+        if int(joined.item()) != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"{int(joined.item())} ranks joined, --gpus {args.gpus} asked")
 
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
@@ -245,6 +357,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # sustained leg: the same replay back to back for >= --sustain-s seconds (so that SMI sampling sees the GPU busy)
+    sustained_ms = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-4)) + 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            ro.refresh_uniform()
+            run()
+        barrier()
+        sdt = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([sdt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sdt = float(tt.item())
+        sustained_ms = sdt / n_sus * 1e3
+        log(f"sustained leg: {n_sus} rollouts in {sdt:.2f} s = {sustained_ms:.3f} ms each")
+
     designs_per_rollout = args.batch * args.T * args.n_query
     exact = args.batch * sum(args.n_query - t for t in range(args.T))
     value = world * designs_per_rollout * args.steps / dt
@@ -255,7 +385,7 @@ def main():
     ro.r.ev_kernel_start, ro.r.ev_kernel_stop = ev.a, ev.b
     kms = []
     has_kernel_events = ((args.d_model == 32 and args.d_ff == 128 and args.heads == 4 and args.precision == "f32")
-                         or (args.d_model == 256 and args.heads == 8 and args.precision == "bf16"))
+                         or (args.d_model == 256 and args.heads == 8 and args.precision in ("bf16", "f16x3")))
     for _ in range(max(3, args.steps) if has_kernel_events else 0):
         ro.refresh_uniform()
         ro.run()
@@ -272,6 +402,7 @@ def main():
     fused = (args.d_model == 32 and args.d_ff == 128 and args.heads == 4 and args.precision == "f32"
              and kernel_ms > 0.0)
     wide = args.d_model == 256 and args.heads == 8 and args.precision == "bf16" and kernel_ms > 0.0
+    x3 = args.d_model == 256 and args.heads == 8 and args.precision == "f16x3" and kernel_ms > 0.0
     extra = {}
     if fused:
         fl_k = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
@@ -325,6 +456,20 @@ def main():
                  "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md).  Algorithmic FLOPs as the reference "
                               "computes them (K/V for the visible keys only, SURVEY 8-d); the kernel spends MFMA "
                               "slots on 16 token tiles per episode for 203 tokens (13 tiles used)"}
+    elif x3:
+        # dominant kernel of the x3 path: x3::layer_kernel -- one launch = one encoder layer of one step for all B episodes
+        # (L * T launches per rollout); the events bracket the last layer of the last step
+        t = args.T - 1
+        per_launch = x3_layer_flops(args.d_model, args.d_ff, 1 + t, args.n_query - t, 2, 2) * args.batch
+        achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
+        kname, peak, traffic = "x3::layer_kernel<true>", PEAK_BF16_DENSE_TFLOPS, None
+        extra = {"launches_per_rollout": args.T * args.layers, "mfma_passes_per_product": 3,
+                 "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / 3,
+                 "frac_vs_instruction_mix_peak": achieved_tflops * 3 / PEAK_BF16_DENSE_TFLOPS,
+                 "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
+                 "peak_note": "dense f16 MFMA peak (MI355X_MICROARCH.md).  Every product is a 3-term f16 split (reference "
+                              "precision), i.e. 3 MFMA passes per algorithmic multiply-add: the pipe can deliver at most "
+                              "peak / 3 in this mode (instruction_mix_peak); frac_vs_instruction_mix_peak = matrix-pipe utilisation"}
     else:   # generic pipeline: many kernels per step; report the whole graph as a lower bound
         achieved_tflops = fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12
         kname, per_launch, kernel_ms = "whole rollout graph (generic pipeline, all kernels)", fl_ep * args.batch, dev_ms / args.steps
@@ -334,7 +479,7 @@ def main():
         "metric": "candidate designs scored/sec (batch x T x n_query), location_finding T=30",
         "value": value, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": "weak", "vs_baseline": None, "ranks": world, "sustained_ms_per_step": sustained_ms,
         "dtype": {"f32": "f32 (fp32 MFMA; FFN/acquisition products as exact 3-way split-bf16, fp32 accumulate)",
                   "bf16": "bf16", "bf16x3": "bf16x3(split-bf16 MFMA, fp32 accumulate)", "f16x3": "f32-grade (3-term split-f16 MFMA, fp32 accumulate)"}[args.precision],
         "data": "synthetic",
@@ -359,10 +504,12 @@ def main():
         # secondary measurement (not `value`): one optimiser step of train_aline.py:55-152 -- sampled
         # rollout, REINFORCE terms, native backward of all T steps, ONE flat-bucket RCCL all-reduce of the
         # gradients (N > 1), inf-norm clipping, AdamW.
+        from aline_amd import train as train_mod
         from aline_amd.train import train_step
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
         train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)        # warm-up
         barrier()
+        ar0 = train_mod.ALLREDUCE_CALLS
         t1 = time.perf_counter()
         for _ in range(args.train_steps):
             train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)
@@ -376,8 +523,27 @@ def main():
                              "ms_per_step": tdt / args.train_steps * 1e3, "steps": args.train_steps,
                              "includes": "fused forward rollout + generic fp32 backward of all T steps + "
                                          "flat-bucket gradient all-reduce (N>1) + inf-norm clip + AdamW",
-                             "collective": "1 all-reduce / optimiser step" if world > 1 else "none (N=1)"}
+                             "collective": "1 all-reduce / optimiser step" if world > 1 else "none (N=1)",
+                             "rccl_allreduce_calls": train_mod.ALLREDUCE_CALLS - ar0,
+                             "rccl_allreduce_per_step": (train_mod.ALLREDUCE_CALLS - ar0) / args.train_steps}
         log(f"train step: {tdt / args.train_steps * 1e3:.1f} ms")
+    if not args.no_query_gmm and args.precision in ("f32", "f16x3"):
+        qms = query_gmm_ms_per_rollout(args, model, device)
+        if dist is not None:
+            tq = torch.tensor([qms], device=device, dtype=torch.float64)
+            dist.all_reduce(tq, op=dist.ReduceOp.MAX)
+            qms = float(tq.item())
+        out["value_with_query_gmm"] = world * designs_per_rollout / ((dt / args.steps) + qms * 1e-3)
+        out["query_gmm"] = {"ms_per_rollout": qms,
+                            "note": "posterior_out_query (model/head.py:366) is lazy in the product and is NOT part of `value`; this "
+                                    "is `value` with the C GMM heads evaluated on the candidate rows at all T steps through the "
+                                    "per-step entry point, on encodings of the rollout's shapes (SURVEY 8-d: with and without)"}
+        log(f"query GMM of all T steps: {qms:.2f} ms")
+    if world == 1 and not args.no_d256 and args.d_model != 256:
+        out["d256"] = {}
+        for prec in ("f16x3", "bf16"):
+            out["d256"][prec] = measure_d256(args, device, batch, prec)
+            log(f"d256 [{prec}]: {out['d256'][prec]['ms_per_rollout']:.2f} ms per rollout")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, model)
         log("cpu baseline done")

@@ -111,3 +111,25 @@ def test_eval_bounds_gather_over_ranks():
     assert torch.allclose(mean, ref["pce_mean"]) and torch.allclose(err, ref["nmc_err"])
     single = bound_statistics(torch.cat([blocks[i] for i in range(5)]), -torch.cat([blocks[i] for i in range(5)]), "se")
     assert torch.allclose(mean, single["pce_mean"]) and torch.allclose(err, single["nmc_err"])   # order-independent
+
+
+def test_bench_gpus_n_without_launcher_starts_n_ranks():
+    """`bench.py --gpus N` called directly (no torchrun environment) must start N ranks itself -- one per GPU through
+    torch.distributed.run on 127.0.0.1 -- before touching the GPU, never report a 1-rank number as the N-GPU point; under a
+    launcher that started a different number of ranks it must refuse."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ALINE_BENCH_DRY_SPAWN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["spawn"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
+                         text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
