@@ -1138,6 +1138,12 @@ extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_ro
   return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).Stamps * sizeof(float);
 }
 
+// Diagnostic only: byte offset of the wide path's acquisition-logit buffer [B * N] (tools/probes/relu_int_repro.py).
+extern "C" size_t aline_debug_wlog_offset(const aline_model *m, const aline_rollout *r) {
+  if (!m || !r) return 0;
+  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).wLog * sizeof(float);
+}
+
 // ================================= backward (training) ============================================
 namespace {
 

@@ -350,7 +350,11 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
+#ifdef ALINE_RELU_SITE_FFN
+        for (int r = 0; r < 4; ++r) { h[0][ct][r] = relu_int(h[0][ct][r]); h[1][ct][r] = relu_int(h[1][ct][r]); }
+#else
         for (int r = 0; r < 4; ++r) { h[0][ct][r] = relu_nn(h[0][ct][r]); h[1][ct][r] = relu_nn(h[1][ct][r]); }
+#endif
         hb[ct] = acc_to_frag(h[0][ct], h[1][ct]);
       }
 #pragma unroll
@@ -382,8 +386,27 @@ __global__ __launch_bounds__(BTHREADS) void wide_block_kernel(BlockArgs a) {
           for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#if defined(ALINE_RELU_SITE_ACQ_AFTER)   // (diagnostic: wait states between the integer max and its consumer)
+              { float r0 = relu_int(h[0][ct][r]), r1 = relu_int(h[1][ct][r]);
+                asm volatile("s_nop 3" : "+v"(r0), "+v"(r1));
+                plog[ct][j] = fmaf(r0, w0[r], plog[ct][j]);
+                plog[ct][j] = fmaf(r1, w1[r], plog[ct][j]); }
+#elif defined(ALINE_RELU_SITE_ACQ_NOPK)  // (diagnostic: integer max, but no packed FMA: each product is its own statement)
+              { float r0 = relu_int(h[0][ct][r]), r1 = relu_int(h[1][ct][r]);
+                float p0 = plog[ct][j];
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(p0) : "v"(r0), "v"(w0[r]));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(p0) : "v"(r1), "v"(w1[r]));
+                plog[ct][j] = p0; }
+#elif defined(ALINE_RELU_SITE_ACQ_GUARD)     // (diagnostic: integer ReLU with NaNs mapped to 0 first, as fmaxf does)
+              plog[ct][j] = fmaf(relu_int(h[0][ct][r] != h[0][ct][r] ? 0.f : h[0][ct][r]), w0[r], plog[ct][j]);
+              plog[ct][j] = fmaf(relu_int(h[1][ct][r] != h[1][ct][r] ? 0.f : h[1][ct][r]), w1[r], plog[ct][j]);
+#elif defined(ALINE_RELU_SITE_ACQ)
+              plog[ct][j] = fmaf(relu_int(h[0][ct][r]), w0[r], plog[ct][j]);
+              plog[ct][j] = fmaf(relu_int(h[1][ct][r]), w1[r], plog[ct][j]);
+#else
               plog[ct][j] = fmaf(relu_nn(h[0][ct][r]), w0[r], plog[ct][j]);
               plog[ct][j] = fmaf(relu_nn(h[1][ct][r]), w1[r], plog[ct][j]);
+#endif
             }
         }
       }
@@ -512,7 +535,11 @@ __global__ __launch_bounds__(BTHREADS) void wide_embed_kernel(EmbedArgs a) {
           const int u = hbase + 16 * (j >> 2) + 4 * g + (j & 3);
           float acc = b1s[u];
           for (int k = 0; k < a.K; ++k) acc = fmaf(xv[ct][k], w1s[u * a.K + k], acc);
+#ifdef ALINE_RELU_SITE_EMB
+          h[j] = relu_int(acc);
+#else
           h[j] = relu_nn(acc);
+#endif
         }
         const u32x4 v = {pack_bf16(h[0], h[1]), pack_bf16(h[2], h[3]), pack_bf16(h[4], h[5]), pack_bf16(h[6], h[7])};
         hb[ct] = __builtin_bit_cast(bf16x8, v);

@@ -9,7 +9,7 @@ mkdir -p aline_amd/csrc/variants
 if [ "$mode" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
-    (cd aline_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -shared -o variants/lib_$name.so aline_hip.hip) &
+    (cd aline_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function $flags -shared -o variants/lib_$name.so aline_hip.hip) &
   done
   wait
 else
