@@ -101,6 +101,7 @@ def _load():
         "aline_eig_finalize_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
         "aline_debug_stamps_offset": (C.c_size_t, [MP, RP]),
         "aline_debug_wlog_offset": (C.c_size_t, [MP, RP]),
+        "aline_debug_xraw_offset": (C.c_size_t, [MP, RP]),
         "aline_cholesky_upper": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp]),
         "aline_rollout_backward_workspace_bytes": (C.c_size_t, [MP, RP, C.c_int]),
         "aline_rollout_backward": (C.c_int, [MP, RP, _fp, _fp, GP, C.c_int, _fp, C.c_size_t, _fp]),

@@ -987,6 +987,9 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
       la.XIN = xin; la.XOUT = xout; la.img = img + l * lw; la.F = F; la.KV = KV; la.kcnt = kcnt;
       const bool last = l == m->L - 1;
       la.zimg = (last && want_gmm) ? Zimg : nullptr; la.zrow0 = (long)t * r->B * n_t;
+#ifdef X3_STAMPS
+      la.stamps = want_gmm ? nullptr : reinterpret_cast<unsigned long long *>(c.at(c.pl.xRaw));
+#endif
       const bool timed = (t == r->T - 1 && last);              // bench.py times this launch of the dominant kernel
       if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
       if (last) hipLaunchKernelGGL(x3::layer_kernel<true>, dim3((unsigned)std::min(la.ngroups, cus)), dim3(x3::THREADS), smem_layer, c.st, la);
@@ -1138,6 +1141,13 @@ extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_ro
   return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).Stamps * sizeof(float);
 }
 
+// Diagnostic only: byte offset of the x3 path's raw-GMM buffer (unused while no posterior output is requested: the
+// in-kernel stamps of the X3_STAMPS build land there, tools/x3_stamps.py).
+extern "C" size_t aline_debug_xraw_offset(const aline_model *m, const aline_rollout *r) {
+  if (!m || !r) return 0;
+  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).xRaw * sizeof(float);
+}
+
 // Diagnostic only: byte offset of the wide path's acquisition-logit buffer [B * N] (tools/probes/relu_int_repro.py).
 extern "C" size_t aline_debug_wlog_offset(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return 0;
@@ -1145,6 +1155,16 @@ extern "C" size_t aline_debug_wlog_offset(const aline_model *m, const aline_roll
 }
 
 // ================================= backward (training) ============================================
+// Arithmetic of the NT GEMMs of the backward pass (forward recompute and dX products): exact-fp32 MFMA.  ALINE_BWD_PREC=3
+// (3-term f16 split) was measured and is NOT used: upstream gradients are ~1e-8 .. 1e-5 (1 / (T B n_t) scaling), below
+// f16's normal range, so the split loses them (tests/test_backward_gpu.py fails), and the step is bound by HBM traffic of
+// the saved activations, not by the matrix pipe (67.7 -> 66.9 ms).
+static int bwd_prec() {
+  static int p = -1;
+  if (p < 0) { const char *e = getenv("ALINE_BWD_PREC"); p = e ? atoi(e) : ALINE_PREC_F32; if (p < 0 || p > 3) p = 0; }
+  return p;
+}
+
 namespace {
 
 struct BwdPlan {
@@ -1206,7 +1226,7 @@ int gemm_dx(const BCtx &c, const float *dY, int ldy, const float *W, int N, int 
   GemmArgs a = gemm_args(dY, ldy, Wt, nullptr, N, dX, ldx, M, K, N, false);
   a.accum = accum ? 1 : 0;
   a.mask = relu_of; a.ldmask = ldx;      // gradient through the ReLU whose output is `relu_of` [M, K]
-  TRY(launch_gemm(ALINE_PREC_F32, a, 1, c.st));
+  TRY(launch_gemm(bwd_prec(), a, 1, c.st));
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -1310,11 +1330,11 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
   hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_x * F), dim3(256), 0, c.st, xs, P + n_td, B,
                      m->dim_x, F, m->x_w1, m->x_b1, EHx);
   CHECK_LAUNCH();
-  TRY(launch_gemm(0, gemm_args(EHx, F, m->x_w2, m->x_b2, F, Ex, d, rows_x, d, F, false), 1, c.st));
+  TRY(launch_gemm(bwd_prec(), gemm_args(EHx, F, m->x_w2, m->x_b2, F, Ex, d, rows_x, d, F, false), 1, c.st));
   hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_y * F), dim3(256), 0, c.st, ys, P, B, m->dim_y,
                      F, m->y_w1, m->y_b1, EHy);
   CHECK_LAUNCH();
-  TRY(launch_gemm(0, gemm_args(EHy, F, m->y_w2, m->y_b2, F, Ey, d, rows_y, d, F, false), 1, c.st));
+  TRY(launch_gemm(bwd_prec(), gemm_args(EHy, F, m->y_w2, m->y_b2, F, Ey, d, rows_y, d, F, false), 1, c.st));
   CHECK_LAUNCH();
   (void)hipMemsetAsync(c.at(c.pl.dEx), 0, (size_t)rows_x * d * sizeof(float), c.st);
   (void)hipMemsetAsync(c.at(c.pl.dEy), 0, (size_t)rows_y * d * sizeof(float), c.st);
@@ -1341,7 +1361,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
                        m->theta_tokens, Xs(0));
     CHECK_LAUNCH();
     for (int l = 0; l < L; ++l) {
-      TRY(launch_gemm(0, gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
+      TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
       Ctx fc; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
       switch (hd) {
         case 4: TRY(launch_attention<4>(fc, QKVl(l), Al(l), max_keys)); break;
@@ -1351,10 +1371,10 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
         case 64: TRY(launch_attention<64>(fc, QKVl(l), Al(l), max_keys)); break;
         default: return ALINE_EUNSUPPORTED;
       }
-      TRY(launch_gemm(0, gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));
+      TRY(launch_gemm(bwd_prec(), gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));
       TRY(launch_add_layernorm(c.st, Xs(l), dTmp, m->norm1_w[l], m->norm1_b[l], X1l(l), M, d, U1l(l)));
-      TRY(launch_gemm(0, gemm_args(X1l(l), d, m->lin1_w[l], m->lin1_b[l], d, Hidl(l), F, (int)M, F, d, true), 1, c.st));
-      TRY(launch_gemm(0, gemm_args(Hidl(l), F, m->lin2_w[l], m->lin2_b[l], F, dTmp, d, (int)M, d, F, false), 1, c.st));
+      TRY(launch_gemm(bwd_prec(), gemm_args(X1l(l), d, m->lin1_w[l], m->lin1_b[l], d, Hidl(l), F, (int)M, F, d, true), 1, c.st));
+      TRY(launch_gemm(bwd_prec(), gemm_args(Hidl(l), F, m->lin2_w[l], m->lin2_b[l], F, dTmp, d, (int)M, d, F, false), 1, c.st));
       TRY(launch_add_layernorm(c.st, X1l(l), dTmp, m->norm2_w[l], m->norm2_b[l], Xs(l + 1), M, d, U2l(l)));
     }
     const float *Z = Xs(L);
@@ -1362,11 +1382,11 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
     {
       GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, d, HidA, F, I * P, F, d, true);
       a.R_in = P; a.G_in = N; a.off_in = 0;
-      TRY(launch_gemm(0, a, 1, c.st));
+      TRY(launch_gemm(bwd_prec(), a, 1, c.st));
       GemmArgs ag = gemm_args(Z, d, nullptr, nullptr, d, HidG, C * F, I * n_t, F, d, true);
       ag.R_in = n_t; ag.G_in = N; ag.off_in = P; ag.col_per_group = F;
       for (int k = 0; k < C; ++k) { ag.W[k] = m->gmm_w1[k]; ag.bias[k] = m->gmm_b1[k]; }
-      TRY(launch_gemm(0, ag, C, c.st));
+      TRY(launch_gemm(bwd_prec(), ag, C, c.st));
       CHECK_LAUNCH();
     }
 
@@ -1385,7 +1405,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       TRY(transpose_to(c, m->acq_w1, F, d, Wt));
       GemmArgs ga = gemm_args(HidA, F, Wt, nullptr, F, dX, d, I * P, d, F, false);
       ga.R_out = P; ga.G_out = N; ga.off_out = 0;
-      TRY(launch_gemm(0, ga, 1, c.st));
+      TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
       CHECK_LAUNCH();
     }
     {
@@ -1412,7 +1432,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       for (int k = 0; k < C; ++k) {
         GemmArgs ga = gemm_args(HidG + (size_t)k * F, C * F, Wt + (size_t)k * F * d, nullptr, F, dX, d, I * n_t, d, F, false);
         ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
-        TRY(launch_gemm(0, ga, 1, c.st));
+        TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
       }
       CHECK_LAUNCH();
     }

@@ -280,8 +280,31 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
 // launch disappear with the LDS-DMA instructions removed, none with their vmcnt wait removed, 30 us with the barrier
 // removed; issuing from four waves only (one per SIMD) or from every wave in a different MFMA batch than its SIMD
 // partner changes nothing (+-4 %) -- part of the cost is clock: the chip holds 2.1 GHz with the stream, 2.35 without.
+// In-kernel phase stamps (X3_STAMPS diagnostic build only, tools/x3_stamps.py): s_memtime deltas accumulated per wave.
+//   0 LDS wait (touch)   1 MFMA batch (+ next reads)   2 DMA issue   3 vmcnt wait   4 barrier   5 hidden / epilogue VALU
+//   6 attention   7 layer norms + image I/O   8 whole kernel
+#ifdef X3_STAMPS
+#define X3_NSTAMP 9
+struct Stamps {
+  unsigned long long t_prev, acc[X3_NSTAMP];
+  __device__ __forceinline__ void start() { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory"); }
+  __device__ __forceinline__ void lap(int k) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    acc[k] += t - t_prev;
+    t_prev = t;
+  }
+};
+#define X3_LAP(st, k) (st).stamps.lap(k)
+#else
+#define X3_LAP(st, k)
+#endif
+
 template <class SrcFn>
 struct Stream {
+#ifdef X3_STAMPS
+  Stamps stamps;
+#endif
   SrcFn src;              // position in the cyclic sequence -> first byte of the chunk
   char *ring;
   int seq_len, s_issue, b_issue, b_use;
@@ -305,9 +328,11 @@ struct Stream {
 #ifndef X3_NO_WAIT     // (timing experiments only)
     wait_vmcnt<PIECES_PER_WAVE *(PD - 2)>();
 #endif
+    X3_LAP(*this, 3);
 #ifndef X3_NO_BARRIER  // (timing experiments only)
     __builtin_amdgcn_s_barrier();
 #endif
+    X3_LAP(*this, 4);
   }
   // LDS byte address of this lane's 16 bytes of fragment 0 of the chunk in use / of the next one
   __device__ __forceinline__ const f16x8 *cur() const { return reinterpret_cast<const f16x8 *>(ring + b_use * CHUNK_BYTES + lane_off); }
@@ -318,7 +343,11 @@ struct Stream {
 template <class SrcFn>
 __device__ __forceinline__ Stream<SrcFn> make_stream(SrcFn src, char *ring, int seq_len, int tid) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  Stream<SrcFn> s{src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u, (unsigned)wave * (unsigned)(PIECES_PER_WAVE * 1024),
+  Stream<SrcFn> s{
+#ifdef X3_STAMPS
+                  Stamps{},
+#endif
+                  src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u, (unsigned)wave * (unsigned)(PIECES_PER_WAVE * 1024),
 #ifdef X3_DMA_SPREAD     // (timing experiment: partner waves issue two batches apart; 5 % slower than all behind batch 0)
                   (wave + 2 * (wave >> 2)) & 3};
 #else
@@ -355,6 +384,10 @@ __device__ __forceinline__ void chunk_pipe(St &st, FragRing &r, const f16x8 *cur
   for (int k = 0; k < 4; ++k) {
     __builtin_amdgcn_sched_barrier(0);
     touch_batch(r, k & 1);
+#ifdef X3_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    X3_LAP(st, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (k < 3) {
       fetch_batch(r, (k + 1) & 1, cur, k + 1);
@@ -367,7 +400,8 @@ __device__ __forceinline__ void chunk_pipe(St &st, FragRing &r, const f16x8 *cur
     for (int j = 0; j < 4; ++j) body(4 * k + j, r.hi[k & 1][j], r.lo[k & 1][j]);
     __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (k == st.dma_slot) st.issue();
+    X3_LAP(st, 1);
+    if (k == st.dma_slot) { st.issue(); X3_LAP(st, 2); }
   }
   __builtin_amdgcn_sched_barrier(0);
   st.sync();
@@ -523,6 +557,9 @@ struct LayerArgs {
   const unsigned *img; int F;
   const u32x4 *KV; const int *kcnt;
   u32x4 *zimg; long zrow0;        // last layer: the rows of the target tokens also go to this (dense-row) image
+#ifdef X3_STAMPS
+  unsigned long long *stamps;     // [8 waves][X3_NSTAMP] of workgroup 0
+#endif
 };
 
 // masked set-attention of one token tile against NKT key tiles, head by head (model/encoder.py:8-46): S^T = K Q^T in
@@ -592,6 +629,11 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
   auto st = make_stream([wbase](int s) { return wbase + (long)(s < 8 ? s : s + 16) * CHUNK_BYTES; }, lds, seq, tid);
   st.start();
   __syncthreads();
+#ifdef X3_STAMPS
+  unsigned long long t_begin;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin)::"memory");
+  st.stamps.start();
+#endif
   st.sync();
   FragRing ring;
   const long ntiles = (long)G.B * a.tpe;
@@ -607,6 +649,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     load_tile(a.XIN, tl, lidx, xh, xl);
     const int n_ck = a.kcnt[2 * b], n_ak = a.kcnt[2 * b + 1];
     const bool isq = rc < G.P && !is_ctx(G, b, rc);
+    X3_LAP(st, 7);
 
     f32x4 y[NMT];
     // ---- Q^T = Wq X^T (pre-scaled by log2(e) / sqrt(hd)) ----------------------------------------------------------
@@ -624,9 +667,11 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
       const u32x4 *kv = a.KV + (long)b * KV_EP + lane;
       const int nv = (isq ? n_ak : n_ck) - 4 * g;          // key 16 kt + 4 g + r is visible iff 16 kt + r < nv
       const int nkt = __builtin_amdgcn_readfirstlane((n_ak + 15) >> 4);     // (uniform per wave: one episode per tile)
+      X3_LAP(st, 5);
       if (nkt <= 1) attention_tile<1>(qh, ql, kv, nv);
       else if (nkt == 2) attention_tile<2>(qh, ql, kv, nv);
       else attention_tile<4>(qh, ql, kv, nv);
+      X3_LAP(st, 6);
     }
     // ---- X1 = LN1(X + bo + Wo A) -------------------------------------------------------------------------------------
 #pragma unroll
@@ -639,6 +684,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     layer_norm(y, ln1w, ln1b, g);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) split_frag(y[2 * ks], y[2 * ks + 1], xh[ks], xl[ks]);
+    X3_LAP(st, 7);
     // ---- X = LN2(X1 + b2 + W2 relu(W1 X1 + b1)): 32 hidden units per chunk pair ---------------------------------------
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -651,6 +697,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h0[r] = relu_nn(h0[r]); h1[r] = relu_nn(h1[r]); }
                 split_frag(h0, h1, hbh, hbl);
+                X3_LAP(st, 5);
               },
               [&](int, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, hbh, hbl); });
     }
@@ -673,8 +720,17 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
         a.zimg[xpiece(zr >> 4, ks, 1, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, ol);
       }
     }
+    X3_LAP(st, 7);
   }
   st.finish();
+#ifdef X3_STAMPS
+  if (a.stamps && blockIdx.x == 0 && lane == 0) {
+    unsigned long long t_end;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
+    st.stamps.acc[8] = t_end - t_begin;
+    for (int k = 0; k < X3_NSTAMP; ++k) a.stamps[wave * X3_NSTAMP + k] = st.stamps.acc[k];
+  }
+#endif
 }
 
 // ---- acquisition head (NOUT = 1, model/head.py:27-33) / one GMM head (NOUT = 3, model/head.py:152-186) --------------
