@@ -107,6 +107,9 @@ def _load():
         "aline_rollout_backward": (C.c_int, [MP, RP, _fp, _fp, GP, C.c_int, _fp, C.c_size_t, _fp]),
         "aline_rollout_backward_ex": (C.c_int, [MP, RP, _fp, _fp, _fp, _fp, _fp, GP, C.c_int, _fp, C.c_size_t, _fp]),
         "aline_eig_finalize": (C.c_int, [_fp, C.c_int64, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
+        "aline_head_backward": (C.c_int, [MP, RP, _fp, _fp, _fp, _fp, _fp, GP, _fp, _fp, C.c_size_t, _fp]),
+        "aline_encoder_backward": (C.c_int, [MP, RP, _fp, _fp, GP, _fp, _fp, C.c_size_t, _fp]),
+        "aline_embed_backward": (C.c_int, [MP, RP, _fp, GP, _fp, C.c_size_t, _fp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

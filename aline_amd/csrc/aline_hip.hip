@@ -1303,15 +1303,26 @@ extern "C" int aline_rollout_backward(const aline_model *m, const aline_rollout 
   return aline_rollout_backward_ex(m, r, g_logp, g_ll, nullptr, nullptr, nullptr, gr, t_chunk, ws, ws_bytes, stream);
 }
 
-extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollout *r, const float *g_logp,
-                                         const float *g_ll, const float *g_pm, const float *g_ps,
-                                         const float *g_pw, const aline_grads *gr, int t_chunk, void *ws,
-                                         size_t ws_bytes, void *stream) {
-  if (!m || !r || !g_logp || !gr || !ws || t_chunk < 1) return ALINE_EINVAL;
-  if (!g_ll && !g_pm && !g_ps && !g_pw) return ALINE_EINVAL;
-  TRY(validate_model(*m));
+// Which part of the chain a backward call covers, and the tensors at its cut points (token rows in the reference order
+// ctx | query | target data | theta tokens, [B * N, d]; stage calls are single steps, T = 1):
+//   x_in   input of the encoder (ST_ENC without ST_EMBED)        z_in   encoder output (ST_HEAD without ST_ENC)
+//   d_in   upstream gradient wrt the stage's output (ST_ENC without ST_HEAD: dz; ST_EMBED alone: dx)
+//   d_out  gradient wrt the stage's input (ST_HEAD alone: dz; ST_ENC without ST_EMBED: dx)
+struct StageIO { int stages; const float *x_in, *z_in, *d_in; float *d_out; };
+
+static int backward_impl(const aline_model *m, const aline_rollout *r, const float *g_logp, const float *g_ll,
+                         const float *g_pm, const float *g_ps, const float *g_pw, const aline_grads *gr, int t_chunk,
+                         void *ws, size_t ws_bytes, void *stream, StageIO io) {
+  const bool do_emb = io.stages & ST_EMBED, do_enc = io.stages & ST_ENC, do_head = io.stages & ST_HEAD;
+  if (!m || !r || !gr || !ws || t_chunk < 1) return ALINE_EINVAL;
+  if (do_head && (!g_logp || (!g_ll && !g_pm && !g_ps && !g_pw))) return ALINE_EINVAL;
+  TRY(validate_model(*m, io.stages));
   if (m->precision != ALINE_PREC_F32 || m->time_token) return ALINE_EUNSUPPORTED;
-  if (!r->role || !r->slot || !r->point_x || !r->point_y || !r->target_all) return ALINE_EINVAL;
+  if (!r->role || (do_head && (!r->slot || !r->target_all)) || (do_emb && (!r->point_x || !r->point_y))) return ALINE_EINVAL;
+  if (io.stages != ST_ALL && r->T != 1) return ALINE_EINVAL;
+  if ((do_enc && !do_emb && !io.x_in) || (do_head && !do_enc && !io.z_in) || (!do_head && !io.d_in) ||
+      (!do_emb && !io.d_out))
+    return ALINE_EINVAL;
   const int tc = std::min(t_chunk, (int)r->T);
   BCtx c;
   c.m = m;
@@ -1320,13 +1331,14 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
   c.ws = static_cast<float *>(ws);
   c.st = static_cast<hipStream_t>(stream);
   const int B = r->B, P = r->P, n_td = r->n_target_data, n_th = m->n_theta, n_t = n_td + n_th;
-  const int N = P + n_t, d = m->d, F = m->F, L = m->L, C = m->C, hd = d / m->H;
+  const int N = P + n_t, d = m->d, F = m->F, L = m->L, C = m->C, hd = m->H > 0 ? d / m->H : 0;
   const int rows_x = B * (P + n_td), rows_y = B * P;
 
   // ---- step-invariant point embeddings, keeping the hidden activations -----------------------------
   float *Ex = c.at(c.pl.Ex), *Ey = c.at(c.pl.Ey), *EHx = c.at(c.pl.EHx), *EHy = c.at(c.pl.EHy);
   Src3 xs{{r->point_x, r->target_x, nullptr}, {P, n_td, 0}};
   Src3 ys{{r->point_y, nullptr, nullptr}, {P, 0, 0}};
+  if (do_emb) {
   hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_x * F), dim3(256), 0, c.st, xs, P + n_td, B,
                      m->dim_x, F, m->x_w1, m->x_b1, EHx);
   CHECK_LAUNCH();
@@ -1338,6 +1350,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
   CHECK_LAUNCH();
   (void)hipMemsetAsync(c.at(c.pl.dEx), 0, (size_t)rows_x * d * sizeof(float), c.st);
   (void)hipMemsetAsync(c.at(c.pl.dEy), 0, (size_t)rows_y * d * sizeof(float), c.st);
+  }
 
   for (int tA = 0; tA < r->T; tA += tc) {
     const int nt_steps = std::min(tc, r->T - tA);
@@ -1357,10 +1370,14 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
     float *dTmp = c.at(c.pl.dTmp), *dQKV = c.at(c.pl.dQKV), *dHid = c.at(c.pl.dHid);
 
     // ---- forward recompute, saving what the backward needs --------------------------------------------
-    hipLaunchKernelGGL(assemble_kernel, grid1d((size_t)M * d), dim3(256), 0, c.st, g, d, Ex, Ey, P,
-                       m->theta_tokens, Xs(0));
-    CHECK_LAUNCH();
-    for (int l = 0; l < L; ++l) {
+    if (do_emb && do_enc) {
+      hipLaunchKernelGGL(assemble_kernel, grid1d((size_t)M * d), dim3(256), 0, c.st, g, d, Ex, Ey, P,
+                         m->theta_tokens, Xs(0));
+      CHECK_LAUNCH();
+    } else if (do_enc) {
+      (void)hipMemcpyAsync(Xs(0), io.x_in, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+    }
+    for (int l = 0; l < L && do_enc; ++l) {
       TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
       Ctx fc; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
       switch (hd) {
@@ -1377,9 +1394,9 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       TRY(launch_gemm(bwd_prec(), gemm_args(Hidl(l), F, m->lin2_w[l], m->lin2_b[l], F, dTmp, d, (int)M, d, F, false), 1, c.st));
       TRY(launch_add_layernorm(c.st, X1l(l), dTmp, m->norm2_w[l], m->norm2_b[l], Xs(l + 1), M, d, U2l(l)));
     }
-    const float *Z = Xs(L);
+    const float *Z = do_enc ? Xs(L) : io.z_in;
     float *HidA = c.at(c.pl.HidA), *HidG = c.at(c.pl.HidG);
-    {
+    if (do_head) {
       GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, d, HidA, F, I * P, F, d, true);
       a.R_in = P; a.G_in = N; a.off_in = 0;
       TRY(launch_gemm(bwd_prec(), a, 1, c.st));
@@ -1392,8 +1409,9 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
 
     // ---- heads backward -> dZ --------------------------------------------------------------------------
     float *dX = c.at(c.pl.dXa), *dXn = c.at(c.pl.dXb);
-    (void)hipMemsetAsync(dX, 0, (size_t)M * d * sizeof(float), c.st);
-    {
+    if (do_head) (void)hipMemsetAsync(dX, 0, (size_t)M * d * sizeof(float), c.st);
+    else (void)hipMemcpyAsync(dX, io.d_in, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+    if (do_head) {
       AcqBwdArgs a{};
       a.g = g; a.F = F; a.hid = HidA; a.w2 = m->acq_w2; a.b2 = m->acq_b2; a.g_logp = g_logp; a.slot = r->slot;
       a.T = r->T; a.dw2 = gr->acq_w2; a.db2 = gr->acq_b2;
@@ -1408,7 +1426,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
       CHECK_LAUNCH();
     }
-    {
+    if (do_head) {
       GmmBwdArgs a{};
       a.hid = HidG; a.rows = (long)I * n_t; a.C = C; a.F = F; a.std_min = m->std_min;
       for (int k = 0; k < C; ++k) { a.w2[k] = m->gmm_w2[k]; a.b2[k] = m->gmm_b2[k]; a.dw2[k] = gr->gmm_w2[k]; a.db2[k] = gr->gmm_b2[k]; }
@@ -1437,8 +1455,12 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       CHECK_LAUNCH();
     }
 
+    if (!do_enc && do_head) {       // head stage alone: dLoss / dz is the result
+      (void)hipMemcpyAsync(io.d_out, dX, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+      continue;
+    }
     // ---- encoder layers backward ---------------------------------------------------------------------------
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = L - 1; l >= 0 && do_enc; --l) {
       // LN2
       TRY(ln_bwd(c, dX, U2l(l), m->norm2_w[l], dTmp, gr->norm2_w[l], gr->norm2_b[l], M));   // dTmp = dU2
       // FFN
@@ -1465,6 +1487,10 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
       TRY(gemm_dx(c, dQKV, 3 * d, m->in_proj_w[l], 3 * d, d, dXn, d, (int)M, true));             // dXn = dX_l
       std::swap(dX, dXn);
     }
+    if (!do_emb) {                  // encoder (+ head) without the embedder: dLoss / dx is the result
+      (void)hipMemcpyAsync(io.d_out, dX, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+      continue;
+    }
     // ---- embeddings: sum over the chunk's steps ------------------------------------------------------------
     hipLaunchKernelGGL(assemble_bwd_kernel, grid1d((size_t)B * N * d), dim3(256), 0, c.st, g, d, nt_steps, dX,
                        c.at(c.pl.dEx), c.at(c.pl.dEy), P, gr->theta_tokens ? gr->theta_tokens : c.at(c.pl.dTmp));
@@ -1472,7 +1498,7 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
   }
 
   // ---- point embedders backward (model/embedder.py:47-57) -------------------------------------------------
-  {
+  if (do_emb) {
     float *dEx = c.at(c.pl.dEx), *dEy = c.at(c.pl.dEy), *dH = c.at(c.pl.dHid);
     TRY(gemm_dw(c, dEx, d, EHx, F, gr->x_w2, gr->x_b2, rows_x, d, F));
     TRY(gemm_dx(c, dEx, d, m->x_w2, d, F, dH, F, rows_x, false, EHx));
@@ -1486,6 +1512,28 @@ extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollo
     CHECK_LAUNCH();
   }
   return ALINE_OK;
+}
+
+extern "C" int aline_rollout_backward_ex(const aline_model *m, const aline_rollout *r, const float *g_logp,
+                                         const float *g_ll, const float *g_pm, const float *g_ps,
+                                         const float *g_pw, const aline_grads *gr, int t_chunk, void *ws,
+                                         size_t ws_bytes, void *stream) {
+  return backward_impl(m, r, g_logp, g_ll, g_pm, g_ps, g_pw, gr, t_chunk, ws, ws_bytes, stream, StageIO{ST_ALL, nullptr, nullptr, nullptr, nullptr});
+}
+
+// ---- stage backward entry points (one step, T = 1; include/aline_hip.h) ------------------------------------------
+extern "C" int aline_head_backward(const aline_model *m, const aline_rollout *r, const float *z, const float *g_logp,
+                                   const float *g_pm, const float *g_ps, const float *g_pw, const aline_grads *gr,
+                                   float *dz, void *ws, size_t ws_bytes, void *stream) {
+  return backward_impl(m, r, g_logp, nullptr, g_pm, g_ps, g_pw, gr, 1, ws, ws_bytes, stream, StageIO{ST_HEAD, nullptr, z, nullptr, dz});
+}
+extern "C" int aline_encoder_backward(const aline_model *m, const aline_rollout *r, const float *x_in, const float *dz,
+                                      const aline_grads *gr, float *dx, void *ws, size_t ws_bytes, void *stream) {
+  return backward_impl(m, r, nullptr, nullptr, nullptr, nullptr, nullptr, gr, 1, ws, ws_bytes, stream, StageIO{ST_ENC, x_in, nullptr, dz, dx});
+}
+extern "C" int aline_embed_backward(const aline_model *m, const aline_rollout *r, const float *dx, const aline_grads *gr,
+                                    void *ws, size_t ws_bytes, void *stream) {
+  return backward_impl(m, r, nullptr, nullptr, nullptr, nullptr, nullptr, gr, 1, ws, ws_bytes, stream, StageIO{ST_EMBED, nullptr, nullptr, dx, nullptr});
 }
 
 extern "C" int aline_cholesky_upper(float *A, int n, int batch, int32_t *info, void *stream) {

@@ -31,7 +31,13 @@ class Embedder(nn.Module):
             self.theta_tokens = nn.Parameter(torch.randn(n_target_theta, dim_embedding))
 
     def forward(self, batch) -> torch.Tensor:
-        _native.require_no_grad(self)
+        """Under autograd (trainable parameters) the call is one node with a native backward (aline_embed_backward), so the
+        reference's own Aline composition (model/base.py:47-50) trains with this module swapped in by `_target_` alone."""
+        if _native.wants_grad(self):
+            return _native.EmbedFn.apply(self, batch, *_native.embedder_params(self)[0])
+        return self._forward_impl(batch)
+
+    def _forward_impl(self, batch) -> torch.Tensor:
         m = _lib.AlineModel()
         _native.fill_embedder(m, self)
         m.precision = _native.precision_of(self)

@@ -51,7 +51,13 @@ class Encoder(nn.Module):
         self.encoder = _Stack(_LayerParams(dim_embedding, dim_feedforward), num_layers)
 
     def forward(self, batch, embeddings):
-        _native.require_no_grad(self)
+        """Under autograd the call is one node with a native backward (aline_encoder_backward): gradients wrt the encoder's
+        weights and wrt `embeddings`."""
+        if _native.wants_grad(self, embeddings):
+            return _native.EncoderFn.apply(self, batch, embeddings, *_native.encoder_params(self)[0])
+        return self._forward_impl(batch, embeddings)
+
+    def _forward_impl(self, batch, embeddings):
         m = _lib.AlineModel()
         _native.fill_encoder(m, self)
         m.precision = _native.precision_of(self)

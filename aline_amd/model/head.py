@@ -145,7 +145,18 @@ class OutputHead(nn.Module):
         return tuple(q)
 
     def forward(self, batch, z, forced_idx=None, uniform=None):
-        _native.require_no_grad(self)
+        """Under autograd the call is one node with a native backward (aline_head_backward): `design_out.log_prob` and
+        `posterior_out.mixture_*` are differentiable wrt the head's weights and wrt `z`."""
+        if _native.wants_grad(self, z):
+            from ..utils.attrdict import AttrDict as _AD
+            lp, pm, ps, pw, zt, idx = _native.HeadFn.apply(self, batch, z, forced_idx, uniform, *_native.head_params(self)[0])
+            node = lp.grad_fn
+            return _AD(posterior_out_query=getattr(node, "lazy_query", None) or _AD(),
+                       posterior_out=_AD(mixture_means=pm, mixture_stds=ps, mixture_weights=pw),
+                       design_out=_AD(idx=idx, log_prob=lp, zt=zt))
+        return self._forward_impl(batch, z, forced_idx, uniform)
+
+    def _forward_impl(self, batch, z, forced_idx=None, uniform=None):
         m = _lib.AlineModel()
         _native.fill_head(m, self)
         m.precision = _native.precision_of(self)

@@ -229,6 +229,25 @@ int aline_rollout_backward_ex(const aline_model *m, const aline_rollout *r, cons
                               const float *g_post_weight, const aline_grads *grads, int t_chunk, void *ws,
                               size_t ws_bytes, void *stream);
 
+/* Stage backward entry points: the backward of ONE stand-alone stage of ONE step, so that a `_target_`-only swap of
+ * model.embedder.Embedder / model.encoder.Encoder / model.head.OutputHead trains under the reference's own composition
+ * `Aline.forward = head(batch, encoder(batch, embedder(batch)))` (model/base.py:47-50, train_aline.py:246-249) and its
+ * `loss.backward()` (train_aline.py:128).  The step is described as a T = 1 rollout (role[b, p] = 1..n_ctx for the context
+ * points, 0 for the queries; slot[b] = chosen point; only the members of the stage's own model fields are read).  Token rows
+ * [B * N, d] in the reference order ctx | query | target data | theta tokens.  Gradients are ACCUMULATED into `grads` (members
+ * of other stages may be NULL).  Workspace: aline_rollout_backward_workspace_bytes(m, r, 1).  fp32 only.
+ *   aline_head_backward     OutputHead.forward (model/head.py:319-393): z, g_logp [B], g_post_* [B, n_t, C] (NULL = zero)
+ *                           -> head gradients, dz [B * N, d]
+ *   aline_encoder_backward  Encoder.forward (model/encoder.py:128-141): x_in (the embeddings), dz -> encoder gradients, dx
+ *   aline_embed_backward    Embedder.forward (model/embedder.py:67-214): dx -> embedder gradients                       */
+int aline_head_backward(const aline_model *m, const aline_rollout *r, const float *z, const float *g_logp,
+                        const float *g_post_mean, const float *g_post_std, const float *g_post_weight,
+                        const aline_grads *grads, float *dz, void *ws, size_t ws_bytes, void *stream);
+int aline_encoder_backward(const aline_model *m, const aline_rollout *r, const float *x_in, const float *dz,
+                           const aline_grads *grads, float *dx, void *ws, size_t ws_bytes, void *stream);
+int aline_embed_backward(const aline_model *m, const aline_rollout *r, const float *dx, const aline_grads *grads,
+                         void *ws, size_t ws_bytes, void *stream);
+
 /* --- diagnostics ----------------------------------------------------------------------------- */
 /* Byte offset, inside a rollout workspace, of the per-phase cycle stamps the fused rollout kernel
  * writes when the process runs with ALINE_FUSED_STAMPS=1 (diagnostic instantiation only). */

@@ -93,3 +93,78 @@ def test_reference_style_training_loop_with_autograd(golden):
         if err > worst[1]:
             worst = (k, err)
     assert worst[1] < 1e-3, worst
+
+
+class _RefComposition(torch.nn.Module):
+    """The reference's own composition, model/base.py:32-50, verbatim in structure: three hydra-instantiated modules and
+    `head(batch, encoder(batch, embedder(batch)))` -- what `train_aline.py:246-249` builds when only the `_target_` strings
+    of config/{embedder,encoder,head}/*.yaml are switched to the aline_amd classes."""
+
+    def __init__(self, embedder, encoder, head):
+        super().__init__()
+        self.embedder, self.encoder, self.head = embedder, encoder, head
+
+    def forward(self, batch):
+        return self.head(batch, self.encoder(batch, self.embedder(batch)))
+
+
+@pytest.mark.parametrize("name", ["cfg2_location_d32", "cfg1_almix_d1_data"])
+def test_target_only_swap_trains_under_reference_composition(golden, name):
+    """Stage backward entry points (aline_embed_backward / aline_encoder_backward / aline_head_backward): the stand-alone
+    Embedder, Encoder and OutputHead composed by the reference's own Aline class, the reference's training-loop body
+    (train_aline.py:80-132) and `loss.backward()` -- gradients against the reference's autograd gradients."""
+    from aline_amd import Embedder, Encoder, OutputHead
+    from aline_amd.tasks import Task
+    from aline_amd.utils import select_targets_by_mask
+    import aline_oracle as orc
+    fx = golden(name)
+    dims, T = fx.meta["dims"], fx.meta["T"]
+    model = _RefComposition(
+        Embedder(dims["dim_x"], dims["dim_y"], dims["d"], dims["F"], dims["n_theta"], dims["embedding_type"]),
+        Encoder(dims["d"], dims["F"], dims["n_head"], 0.0, dims["L"]),
+        OutputHead(dims["dim_x"], dims["dim_y"], dims["d"], dims["F"], num_components=dims["C"]))
+    model.load_state_dict(orc.make_state_dict(fx.meta["wseed"], **dims), strict=True)
+    model = model.cuda().train()
+    task = Task(dim_x=dims["dim_x"], dim_y=1)
+    batch = to_dev(fx.batch())
+    forced = fx.forced_idx("train").cuda()
+
+    def compute_ll(value, means, stds, weights):          # reference utils/eval.py:200-207
+        comp = torch.distributions.Normal(means, stds, validate_args=False)
+        return torch.logsumexp(comp.log_prob(value) + torch.log(weights), dim=-1)
+
+    n_th = dims["n_theta"]
+    log_probs, nlls, nlls_q = [], [], []
+    for t in range(T):
+        z = model.encoder(batch, model.embedder(batch))
+        pred = model.head(batch, z, forced_idx=forced[:, t])      # (teacher forcing: the fixture's designs)
+        d, p = pred.design_out, pred.posterior_out
+        batch = task.update_batch(batch, d.idx)
+        log_probs.append(d.log_prob)
+        ll = compute_ll(batch.target_all, p.mixture_means, p.mixture_stds, p.mixture_weights)
+        masked = select_targets_by_mask(ll, batch.target_mask)
+        nlls_q.append(-masked.mean(dim=-1))
+        if dims["embedding_type"] == "mix":
+            nlls.append(-(ll[:, :-n_th].mean(-1) + ll[:, -n_th:].mean(-1)))
+        else:
+            nlls.append(-ll.mean(dim=-1))
+    log_probs = torch.stack(log_probs, 1)
+    R = torch.stack([torch.clamp(nlls_q[t - 1] - nlls_q[t], min=0.0).detach() for t in range(1, T)], 1)
+    R = (R - R.mean(dim=0, keepdim=True)) / (R.std(dim=0, keepdim=True) + 1e-9)
+    design_loss = -torch.mean(log_probs[:, :-1] * R)
+    predict_loss = torch.mean(torch.stack(nlls))
+    (design_loss + predict_loss).backward()
+    torch.cuda.synchronize()
+    assert abs(float(predict_loss) - float(fx.np("train.predict_loss"))) < 1e-4
+    worst = ("", 0.0)
+    for k, prm in model.named_parameters():
+        ref = fx.t("train.grad." + k)
+        assert prm.grad is not None, k
+        err = float((prm.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-4)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 1e-3, worst
+    # and forward() of the composition itself is the reference's call (base.py:47-50)
+    with torch.no_grad():
+        out = model(to_dev(fx.batch()))
+    assert out.design_out.zt.shape[0] == fx.meta["B"]
