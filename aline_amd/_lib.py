@@ -92,6 +92,7 @@ def _load():
         "aline_rollout_init": (C.c_int, [MP, RP, _fp, C.c_size_t, _fp]),
         "aline_rollout_step": (C.c_int, [MP, RP, C.c_int, _fp, C.c_size_t, _fp]),
         "aline_rollout_forward": (C.c_int, [MP, RP, _fp, C.c_size_t, _fp]),
+        "aline_rollout_path": (C.c_int, [MP, RP]),
         "aline_rollout_export": (C.c_int, [RP, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
         "aline_compute_ll": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, _fp, _fp]),
         "aline_eig_location_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_int,

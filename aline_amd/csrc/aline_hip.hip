@@ -11,6 +11,7 @@
 #include "wide.h"
 #include "wide_step.h"
 #include "x3.h"
+#include "s3.h"
 #include "backward.h"
 
 #include <algorithm>
@@ -36,7 +37,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sRaw, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -90,6 +91,14 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
     p.xLog = take((size_t)B * tpe * 16);
     p.xZimg = take((size_t)x3::img_pieces(((long)T * B * n_t + 15) / 16) * 4);
     p.xRaw = take((size_t)T * B * n_t * kRawStride);
+  }
+  if (T > 0 && m.d == s3::D && m.precision == ALINE_PREC_F16X3) {           // s3 path (s3.h): d = 32 split-f16 tile images
+    const size_t tpe = (N + 15) / 16, img = (size_t)s3::img_pieces((long)B * tpe) * 4;
+    p.sImg = take((size_t)s3::image_words(m.L, m.F, m.C));
+    p.sX0 = take(img); p.sXW = take(img);
+    p.sLog = take((size_t)B * tpe * 16);
+    p.sZimg = take((size_t)s3::img_pieces(((long)T * B * n_t + 15) / 16) * 4);
+    p.sRaw = take(1024);     // (diagnostic stamps of the S3_STAMPS build)
   }
   p.total = off;
   return p;
@@ -494,6 +503,49 @@ static int device_cus() {
     else n = 256;
   }
   return n;
+}
+
+template <int F>
+static int launch_s3_step_f(const Ctx &c, unsigned nwg, const s3::StepArgs &a) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, s3::STEP_LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL(s3::step_kernel<F>, dim3(nwg), dim3(s3::THREADS), s3::STEP_LDS, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+static int launch_s3_step(const Ctx &c, unsigned nwg, const s3::StepArgs &a) {
+  switch (a.F) {
+    case 32: return launch_s3_step_f<32>(c, nwg, a);
+    case 64: return launch_s3_step_f<64>(c, nwg, a);
+    case 96: return launch_s3_step_f<96>(c, nwg, a);
+    case 128: return launch_s3_step_f<128>(c, nwg, a);
+    default: return ALINE_EUNSUPPORTED;
+  }
+}
+template <int F>
+static int launch_s3_gmm_f(const Ctx &c, const s3::GmmArgs &a) {
+  const size_t smem = (size_t)s3::head_bytes(F) + (size_t)3 * a.C * s3::GROWS * sizeof(float);
+  static size_t attr = 0;
+  if (smem > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::gmm_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = smem;
+  }
+  const long per_wg = (long)s3::WAVES * s3::GT;
+  hipLaunchKernelGGL(s3::gmm_kernel<F>, dim3((unsigned)((a.ntiles + per_wg - 1) / per_wg)), dim3(s3::THREADS), smem, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+static int launch_s3_gmm(const Ctx &c, int F, const s3::GmmArgs &a) {
+  switch (F) {
+    case 32: return launch_s3_gmm_f<32>(c, a);
+    case 64: return launch_s3_gmm_f<64>(c, a);
+    case 96: return launch_s3_gmm_f<96>(c, a);
+    case 128: return launch_s3_gmm_f<128>(c, a);
+    default: return ALINE_EUNSUPPORTED;
+  }
 }
 
 template <int NOUT>
@@ -1042,14 +1094,114 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
   return ALINE_OK;
 }
 
+// The s3 path (s3.h): d = 32 / 4 heads at reference precision, any embedding mode, up to 160 keys per episode -- one
+// launch per design step, a workgroup owns two whole episodes.
+static bool s3_eligible(const aline_model &m, const aline_rollout &r) {
+  if (getenv("ALINE_DISABLE_S3")) return false;
+  if (m.precision != ALINE_PREC_F16X3 || m.d != s3::D || m.H != s3::H || m.F % 32 || m.F > s3::F_MAX || m.time_token) return false;
+  if (r.n_ctx0 < 1 || r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > s3::NK_MAX) return false;
+  return true;
+}
+
+static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes, void *stream) {
+  Ctx c;
+  TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
+  TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
+  if (r->P > 1024) return ALINE_EUNSUPPORTED;
+  const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, F = m->F, tpe = (N + 15) / 16, NP = 16 * tpe;
+  const long tiles = (long)r->B * tpe;
+  using s3::u32x4;
+  hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B, r->P, r->n_ctx0);
+  CHECK_LAUNCH();
+  s3::PackArgs pa{};
+  pa.L = m->L; pa.F = F; pa.C = m->C;
+  for (int l = 0; l < m->L; ++l) {
+    pa.in_proj_w[l] = m->in_proj_w[l]; pa.in_proj_b[l] = m->in_proj_b[l];
+    pa.out_proj_w[l] = m->out_proj_w[l]; pa.out_proj_b[l] = m->out_proj_b[l];
+    pa.lin1_w[l] = m->lin1_w[l]; pa.lin1_b[l] = m->lin1_b[l];
+    pa.lin2_w[l] = m->lin2_w[l]; pa.lin2_b[l] = m->lin2_b[l];
+    pa.n1w[l] = m->norm1_w[l]; pa.n1b[l] = m->norm1_b[l];
+    pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
+  }
+  pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
+  for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
+  unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.sImg));
+  pa.out = img;
+  hipLaunchKernelGGL(s3::pack_kernel, dim3(256), dim3(256), 0, c.st, pa);
+  CHECK_LAUNCH();
+  {   // step-invariant point embeddings (fp32 rows; the generic GEMM runs the same 3-term f16 split)
+    Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
+    TRY(do_embed_points(c, xs, r->point_y, r->P));
+  }
+  u32x4 *X0 = reinterpret_cast<u32x4 *>(c.at(c.pl.sX0)), *XW = reinterpret_cast<u32x4 *>(c.at(c.pl.sXW));
+  u32x4 *Zimg = reinterpret_cast<u32x4 *>(c.at(c.pl.sZimg));
+  float *logits = c.at(c.pl.sLog);
+  s3::AsmArgs aa{};
+  aa.g = c.g; aa.tpe = tpe; aa.Ex = c.at(c.pl.Ex); aa.Ey = c.at(c.pl.Ey); aa.ey_rows = r->P; aa.theta_tokens = m->theta_tokens; aa.X = X0;
+  hipLaunchKernelGGL(s3::assemble_kernel, grid1d((size_t)tiles * 64), dim3(256), 0, c.st, aa);
+  CHECK_LAUNCH();
+  const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
+  const unsigned nwg = (unsigned)((r->B + s3::EPW - 1) / s3::EPW);
+  for (int t = 0; t < r->T; ++t) {
+    c.g.n_ctx = r->n_ctx0 + t;
+    s3::StepArgs sa{};
+    sa.g = c.g; sa.tpe = tpe; sa.L = m->L; sa.F = F; sa.order = t > 0 ? r->n_ctx0 + t : 0;
+    sa.img = img; sa.X0 = X0; sa.XW = XW; sa.emb = aa; sa.emb.g = c.g;
+    sa.logits = logits; sa.NP = NP;
+    sa.zimg = want_gmm ? Zimg : nullptr; sa.zrow0 = (long)t * r->B * n_t;
+#ifdef S3_STAMPS
+    sa.stamps = want_gmm ? nullptr : reinterpret_cast<unsigned long long *>(c.at(c.pl.sRaw));
+#endif
+    const bool timed = t == r->T - 1;                          // bench.py times this launch of the dominant kernel
+    if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
+    TRY(launch_s3_step(c, nwg, sa));
+    if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
+    CHECK_LAUNCH();
+    SelectArgs sel{};
+    sel.g = c.g; sel.F = F; sel.logits = logits; sel.logit_stride = NP;
+    sel.mode = r->select_mode;
+    sel.uniform = r->uniform ? r->uniform + (size_t)t * r->B : nullptr;
+    sel.forced = r->forced_idx ? r->forced_idx + t : nullptr; sel.forced_stride = r->T;
+    sel.idx = r->idx ? r->idx + t : nullptr; sel.idx_stride = r->T;
+    sel.slot = r->slot ? r->slot + t : nullptr; sel.slot_stride = r->T;
+    sel.log_prob = r->log_prob ? r->log_prob + t : nullptr; sel.lp_stride = r->T;
+    const int zw = r->P - r->n_ctx0;
+    sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
+    sel.role_out = r->role;
+    hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
+    CHECK_LAUNCH();
+  }
+  if (want_gmm) {   // GMM heads of all T * B * n_t target rows, then the parameter maps + mixture log-likelihood
+    const long per_step = (long)r->B * n_t, total = per_step * r->T;
+    s3::GmmArgs ga{};
+    ga.Z = Zimg; ga.ntiles = (total + 15) / 16; ga.M = total; ga.C = m->C; ga.std_min = m->std_min;
+    ga.img = img + ((long)m->L * s3::layer_bytes(F) + s3::head_bytes(F)) / 4;
+    ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
+    ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
+    TRY(launch_s3_gmm(c, F, ga));
+  }
+  return ALINE_OK;
+}
+
+int aline_rollout_path(const aline_model *m, const aline_rollout *r) {
+  if (!m || !r) return ALINE_EINVAL;
+  TRY(validate_model(*m));
+  if (fused_eligible(*m, *r)) return ALINE_PATH_FUSED;
+  if (wide_eligible(*m, *r)) return ALINE_PATH_WIDE;
+  if (x3_eligible(*m, *r)) return ALINE_PATH_X3;
+  if (s3_eligible(*m, *r)) return ALINE_PATH_S3;
+  return ALINE_PATH_GENERIC;
+}
+
 int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
                           void *stream) {
-  if (m && r && validate_model(*m) == 0 && fused_eligible(*m, *r))
-    return rollout_fused(m, r, ws, ws_bytes, stream);
-  if (m && r && validate_model(*m) == 0 && wide_eligible(*m, *r))
-    return rollout_wide(m, r, ws, ws_bytes, stream);
-  if (m && r && validate_model(*m) == 0 && x3_eligible(*m, *r))
-    return rollout_x3(m, r, ws, ws_bytes, stream);
+  switch (aline_rollout_path(m, r)) {
+    case ALINE_PATH_FUSED: return rollout_fused(m, r, ws, ws_bytes, stream);
+    case ALINE_PATH_WIDE: return rollout_wide(m, r, ws, ws_bytes, stream);
+    case ALINE_PATH_X3: return rollout_x3(m, r, ws, ws_bytes, stream);
+    case ALINE_PATH_S3: return rollout_s3(m, r, ws, ws_bytes, stream);
+    default: break;     /* generic pipeline (its entry points report invalid arguments) */
+  }
   TRY(aline_rollout_init(m, r, ws, ws_bytes, stream));
   for (int t = 0; t < r->T; ++t) TRY(aline_rollout_step(m, r, t, ws, ws_bytes, stream));
   return ALINE_OK;
@@ -1145,7 +1297,8 @@ extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_ro
 // in-kernel stamps of the X3_STAMPS build land there, tools/x3_stamps.py).
 extern "C" size_t aline_debug_xraw_offset(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return 0;
-  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).xRaw * sizeof(float);
+  const Plan pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T);
+  return (m->d == s3::D ? pl.sRaw : pl.xRaw) * sizeof(float);     // (s3 path: S3_STAMPS build, tools/s3_stamps.py)
 }
 
 // Diagnostic only: byte offset of the wide path's acquisition-logit buffer [B * N] (tools/probes/relu_int_repro.py).

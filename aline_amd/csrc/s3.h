@@ -1,0 +1,673 @@
+// s3 path: d = 32 (4 heads of 8) at REFERENCE precision, any embedding mode (theta / data / mix), up to 160 keys.
+//
+// One launch per design step: a workgroup owns EPW = 2 whole episodes and runs every encoder layer of the step for
+// them -- only workgroup barriers separate the layers, the K / V of an episode never leave LDS, the activations make
+// one round trip per layer through an L2-resident work image.  Arithmetic as x3.h: every product a 3-term f16 split on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation; weights pre-scaled by 2^8 at pack time.
+//
+// Per layer and workgroup:
+//   weights   the layer's 8 + F/8 fragment pairs + fp32 parameters (50 KB at F = 128), LDS-DMA'd into LDS
+//   K / V     of the key rows (context rows, then the visible targets; model/encoder.py:83-126): key tiles spread
+//             over the 8 waves, results written to LDS as the A fragments the attention consumes
+//   tokens    2 x ceil(N / 16) token tiles spread over the 8 waves; a tile's Q projection, masked set-attention
+//             (key-tile loop, all scores of two heads in registers), out-projection, LN1, FFN, LN2 stay in registers;
+//             the last layer also emits the acquisition logits (model/head.py:27-33) and the target-row encodings
+// With hd = 8 a k-step of the MFMA spans all four heads: the scores of head h use the Q^T fragment with the other
+// heads' channels zeroed (2 registers x 2 lane groups survive), K stays whole and is read once per head PAIR; the PV
+// product of a head pair shares the V^T fragment and keeps, per lane group, the accumulator of the head it belongs to.
+#pragma once
+#include "x3.h"
+
+namespace s3 {
+
+using wide::group_sum4;
+using wide::u32x2;
+using wide::u32x4;
+using x3::f16x8;
+using x3::frag_value;
+using x3::glds16;
+using x3::group_max4;
+using x3::mfma3;
+using x3::split2;
+using x3::wait_vmcnt;
+
+constexpr int D = 32, H = 4, HD = 8, F_MAX = 128;
+constexpr int THREADS = 512, WAVES = THREADS / 64, EPW = 2;
+constexpr int NKP_MAX = 5, NKT_MAX = 2 * NKP_MAX, NK_MAX = 16 * NKT_MAX;     // key-tile pairs / tiles / keys per episode
+constexpr float WSCALE = 256.f, WINV = 1.f / 256.f;
+constexpr int PAIR_BYTES = 2048, PAIR_WORDS = 512;
+
+__host__ __device__ inline int round_kb(int bytes) { return (bytes + 1023) & ~1023; }
+// layer image: pairs Q0 Q1 K0 K1 V0 V1 O0 O1 | W1 [F/16] | W2 [(c, m): 2 c + m], then fp32
+// bq (pre-scaled) bk bv bo | b1 [F] | b2 ln1w ln1b ln2w ln2b; padded to whole KB (LDS-DMA pieces)
+__host__ __device__ inline int layer_pairs(int F) { return 8 + F / 8; }
+__host__ __device__ inline int layer_params(int F) { return 9 * D + F; }
+__host__ __device__ inline int layer_bytes(int F) { return round_kb(layer_pairs(F) * PAIR_BYTES + layer_params(F) * 4); }
+// head image (acquisition head / one GMM head): W1 pairs [F/16], then b1 [F] | w2 [3][F] | b2 [4]
+__host__ __device__ inline int head_pairs(int F) { return F / 16; }
+__host__ __device__ inline int head_params(int F) { return 4 * F + 4; }
+__host__ __device__ inline int head_bytes(int F) { return round_kb(head_pairs(F) * PAIR_BYTES + head_params(F) * 4); }
+__host__ __device__ inline long image_words(int L, int F, int C) { return ((long)L * layer_bytes(F) + (long)(1 + C) * head_bytes(F)) / 4; }
+
+// activation image in 16-byte pieces: [tile][hi | lo][lane = 16 g + row % 16]; a piece holds features 4 g + (0..3) and
+// 16 + 4 g + (0..3) of its token row (= the B fragment element order of the single k-step)
+__host__ __device__ inline long img_pieces(long tiles) { return tiles * 128; }
+__device__ __forceinline__ long xpiece(long tile, int hl, int lane) { return (tile * 2 + hl) * 64 + lane; }
+
+// LDS map of the step kernel (bytes)
+constexpr int W_OFF = 0, W_BYTES = 51200;                 // layer_bytes(F_MAX)
+constexpr int HEAD_OFF = W_OFF + W_BYTES, HEAD_BYTES = 19456;   // head_bytes(F_MAX)
+constexpr int KV_OFF = HEAD_OFF + HEAD_BYTES, KV_EP = NKT_MAX * 4096, KV_V = NKT_MAX * 2048;   // K pairs [kt] | V^T pairs [m][kb]
+constexpr int KEY_OFF = KV_OFF + EPW * KV_EP;             // keyrow [EPW][NK_MAX] | misc [16]
+constexpr int STEP_LDS = KEY_OFF + (EPW * NK_MAX + 16) * 4;
+static_assert(STEP_LDS <= 160 * 1024, "step kernel LDS");
+
+// (a, b) -> packed f16 hi halves, packed f16 lo halves (a - hi, b - hi: exact in fp32, then rounded).  The residuals are
+// one v_fma_mix_f32 each (f16 source operand read straight out of the packed register): 4 instructions per pair.
+__device__ __forceinline__ void split2m(float a, float b, unsigned &hi, unsigned &lo) {
+  const x3::f32x2 v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x3::f16x2));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(b));
+  const x3::f32x2 r = {r0, r1};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x3::f16x2));
+}
+// two accumulator tiles (features 16 m + 4 g + r, 16 (m + 1) + 4 g + r) -> the hi / lo B fragments of their k-step
+__device__ __forceinline__ void split_frag(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split2m(a[0], a[1], h0, l0);
+  split2m(a[2], a[3], h1, l1);
+  split2m(b[0], b[1], h2, l2);
+  split2m(b[2], b[3], h3, l3);
+  hi = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});
+  lo = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});
+}
+
+// ---- weights -> fragment pairs -----------------------------------------------------------------------------------
+struct PackArgs {
+  int L, F, C;
+  const float *in_proj_w[8], *in_proj_b[8], *out_proj_w[8], *out_proj_b[8], *lin1_w[8], *lin1_b[8], *lin2_w[8],
+      *lin2_b[8], *n1w[8], *n1b[8], *n2w[8], *n2b[8];
+  const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
+  const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
+  unsigned *out;
+};
+
+__global__ void pack_kernel(PackArgs a) {
+  const long lw = layer_bytes(a.F) / 4, hw = head_bytes(a.F) / 4, total = image_words(a.L, a.F, a.C);
+  const float qscale = rsqrtf((float)HD) * 1.44269504088896340736f;   // softmax runs in exp2
+  const int F = a.F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    unsigned v = 0;
+    if (i < a.L * lw) {
+      const int l = i / lw;
+      const long o = i % lw, nfw = (long)layer_pairs(F) * PAIR_WORDS;
+      if (o < nfw) {
+        const int p = o / PAIR_WORDS, e = o % PAIR_WORDS;
+        if (p < 6) v = x3::pair_word(a.in_proj_w[l] + (long)(p >> 1) * D * D, D, 16 * (p & 1), 0, e, (p < 2 ? qscale : 1.f) * WSCALE);
+        else if (p < 8) v = x3::pair_word(a.out_proj_w[l], D, 16 * (p & 1), 0, e, WSCALE);
+        else if (p < 8 + F / 16) v = x3::pair_word(a.lin1_w[l], D, 16 * (p - 8), 0, e, WSCALE);
+        else {
+          const int q = p - 8 - F / 16;
+          v = x3::pair_word(a.lin2_w[l], F, 16 * (q & 1), q >> 1, e, WSCALE);
+        }
+      } else {
+        const int p = o - nfw;
+        float f = 0.f;
+        if (p < 3 * D) f = a.in_proj_b[l][p] * (p < D ? qscale : 1.f);
+        else if (p < 4 * D) f = a.out_proj_b[l][p - 3 * D];
+        else if (p < 4 * D + F) f = a.lin1_b[l][p - 4 * D];
+        else if (p < layer_params(F)) {
+          const int q = p - 4 * D - F;
+          f = q < D ? a.lin2_b[l][q] : q < 2 * D ? a.n1w[l][q - D] : q < 3 * D ? a.n1b[l][q - 2 * D]
+            : q < 4 * D ? a.n2w[l][q - 3 * D] : a.n2b[l][q - 4 * D];
+        }
+        v = __float_as_uint(f);
+      }
+    } else {
+      const long oh = i - a.L * lw;
+      const int k = oh / hw;                          // 0: acquisition head, 1 + c: GMM head c
+      const long o = oh % hw, nfw = (long)head_pairs(F) * PAIR_WORDS;
+      const float *w1 = k == 0 ? a.acq_w1 : a.gmm_w1[k - 1], *b1 = k == 0 ? a.acq_b1 : a.gmm_b1[k - 1];
+      const float *w2 = k == 0 ? a.acq_w2 : a.gmm_w2[k - 1], *b2 = k == 0 ? a.acq_b2 : a.gmm_b2[k - 1];
+      const int nout = k == 0 ? 1 : 3;
+      if (o < nfw) {
+        v = x3::pair_word(w1, D, 16 * (int)(o / PAIR_WORDS), 0, (int)(o % PAIR_WORDS), WSCALE);
+      } else {
+        const int p = o - nfw;
+        const float f = p < F ? b1[p] : p < (1 + nout) * F ? w2[p - F] : (p >= 4 * F && p < 4 * F + nout) ? b2[p - 4 * F] : 0.f;
+        v = __float_as_uint(f);
+      }
+    }
+    a.out[i] = v;
+  }
+}
+
+// ---- X0 image from the cached fp32 point embeddings (model/embedder.py:128-214) ----------------------------------
+struct AsmArgs {
+  Geo g; int tpe;
+  const float *Ex, *Ey; int ey_rows; const float *theta_tokens;
+  u32x4 *X;
+};
+__device__ __forceinline__ void embed_row8(const AsmArgs &a, int b, int row, int c, f32x4 &lo, f32x4 &hi) {
+  const Geo &g = a.g;
+  if (row < g.P + g.n_td) {
+    const float *e = a.Ex + ((long)b * (g.P + g.n_td) + row) * D + c;
+    lo = *reinterpret_cast<const f32x4 *>(e); hi = *reinterpret_cast<const f32x4 *>(e + 16);
+    if (row < g.P && is_ctx(g, b, row)) {
+      const float *y = a.Ey + ((long)b * a.ey_rows + row) * D + c;
+      lo += *reinterpret_cast<const f32x4 *>(y); hi += *reinterpret_cast<const f32x4 *>(y + 16);
+    }
+  } else {
+    const float *t = a.theta_tokens + (row - g.P - g.n_td) * D + c;
+    lo = *reinterpret_cast<const f32x4 *>(t); hi = *reinterpret_cast<const f32x4 *>(t + 16);
+  }
+}
+__device__ __forceinline__ void store_split8(u32x4 *X, long tile, int lane, const f32x4 &lo4, const f32x4 &hi4) {
+  f16x8 h, l;
+  split_frag(lo4, hi4, h, l);
+  X[xpiece(tile, 0, lane)] = __builtin_bit_cast(u32x4, h);
+  X[xpiece(tile, 1, lane)] = __builtin_bit_cast(u32x4, l);
+}
+__global__ void assemble_kernel(AsmArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tiles = (long)a.g.B * a.tpe;
+  if (i >= tiles * 64) return;
+  const int lane = i & 63, gq = lane >> 4;
+  const long tile = i >> 6;
+  const int b = tile / a.tpe, row = (int)(tile % a.tpe) * 16 + (lane & 15);
+  f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+  if (row < a.g.N) embed_row8(a, b, row, 4 * gq, lo, hi);
+  store_split8(a.X, tile, lane, lo, hi);
+}
+
+// ---- helpers of the step kernel ------------------------------------------------------------------------------------
+// `bytes` (whole KB) from global to LDS, 1 KB pieces round-robin over the waves
+__device__ __forceinline__ void dma_copy(const char *src, char *dst, int bytes, int wave, int lane) {
+  for (int piece = wave; piece < (bytes >> 10); piece += WAVES) glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
+}
+struct Frag { f16x8 hi, lo; };
+__device__ __forceinline__ Frag lds_pair(const char *base, int pair, int lane) {
+  const char *p = base + pair * PAIR_BYTES + lane * 16;
+  return Frag{*reinterpret_cast<const f16x8 *>(p), *reinterpret_cast<const f16x8 *>(p + 1024)};
+}
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ float relu_s(float v) { return fmaxf(v, 0.f); }
+
+// (a, b) = LayerNorm over the 32 features of each token: 8 values per lane x 4 lane groups, fp32, two passes
+__device__ __forceinline__ void layer_norm32(f32x4 &a, f32x4 &b, const float *w, const float *bb, int g) {
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+  const float mean = group_sum4(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a[r] -= mean; b[r] -= mean; q = fmaf(a[r], a[r], q); q = fmaf(b[r], b[r], q); }
+  const float rstd = 1.f / sqrtf(group_sum4(q) * (1.f / D) + 1e-5f);
+  const f32x4 w0 = ld4(w + 4 * g), w1 = ld4(w + 16 + 4 * g), b0 = ld4(bb + 4 * g), b1 = ld4(bb + 16 + 4 * g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a[r] = fmaf(a[r] * rstd, w0[r], b0[r]); b[r] = fmaf(b[r] * rstd, w1[r], b1[r]); }
+}
+
+// softmax numerators of one head over NKT key tiles (exp2 domain), in place; returns 1 / denominator
+template <int NKT>
+__device__ __forceinline__ float softmax_tiles(f32x4 (&s)[NKT]) {
+  float m0 = fmaxf(s[0][0], s[0][1]), m1 = fmaxf(s[0][2], s[0][3]);
+#pragma unroll
+  for (int kt = 1; kt < NKT; ++kt) {        // two chains of v_max3_f32
+    m0 = fmaxf(fmaxf(m0, s[kt][0]), s[kt][1]);
+    m1 = fmaxf(fmaxf(m1, s[kt][2]), s[kt][3]);
+  }
+  const float mx = group_max4(fmaxf(m0, m1));
+  const x3::f32x2 m2 = {mx, mx};
+  x3::f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const x3::f32x2 d0 = (x3::f32x2){s[kt][0], s[kt][1]} - m2, d1 = (x3::f32x2){s[kt][2], s[kt][3]} - m2;
+    const x3::f32x2 e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+    const x3::f32x2 e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+    acc += e0;
+    acc += e1;
+    s[kt] = (f32x4){e0[0], e0[1], e1[0], e1[1]};
+  }
+  return 1.f / group_sum4(acc[0] + acc[1]);
+}
+
+// masked set-attention of one token tile against 2 NKP key tiles (model/encoder.py:8-46): S^T = K Q_h^T in the exp2
+// domain (scale folded into Wq), softmax over the keys of a token, O^T = V^T P.  kv: this episode's K / V^T pairs in
+// LDS (+ lane * 16); nv4 = (number of keys the lane's token sees) - 4 g.
+template <int NKP>
+__device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, const char *kv, int nv4, int g, f32x4 (&o)[2]) {
+  constexpr int NKT = 2 * NKP;
+  const u32x4 qhu = __builtin_bit_cast(u32x4, qh), qlu = __builtin_bit_cast(u32x4, ql);
+  const bool glo = g < 2;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    // heads 2 m (channels 16 m + 0..7: lane groups 0, 1) and 2 m + 1 (lane groups 2, 3): registers 2 m, 2 m + 1
+    u32x4 ah = {0u, 0u, 0u, 0u}, al = ah, bh = ah, bl = ah;
+    ah[2 * m] = glo ? qhu[2 * m] : 0u; ah[2 * m + 1] = glo ? qhu[2 * m + 1] : 0u;
+    al[2 * m] = glo ? qlu[2 * m] : 0u; al[2 * m + 1] = glo ? qlu[2 * m + 1] : 0u;
+    bh[2 * m] = glo ? 0u : qhu[2 * m]; bh[2 * m + 1] = glo ? 0u : qhu[2 * m + 1];
+    bl[2 * m] = glo ? 0u : qlu[2 * m]; bl[2 * m + 1] = glo ? 0u : qlu[2 * m + 1];
+    const f16x8 qah = __builtin_bit_cast(f16x8, ah), qal = __builtin_bit_cast(f16x8, al);
+    const f16x8 qbh = __builtin_bit_cast(f16x8, bh), qbl = __builtin_bit_cast(f16x8, bl);
+    f32x4 sa[NKT], sb[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const f16x8 kh = *reinterpret_cast<const f16x8 *>(kv + kt * PAIR_BYTES), kl = *reinterpret_cast<const f16x8 *>(kv + kt * PAIR_BYTES + 1024);
+      f32x4 mb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mb[r] = (16 * kt + r) < nv4 ? 0.f : -INFINITY;
+      sa[kt] = mb; sb[kt] = mb;
+      mfma3(sa[kt], kh, kl, qah, qal);
+      mfma3(sb[kt], kh, kl, qbh, qbl);
+    }
+    // the V^T pairs of this head pair are requested before the softmax arithmetic and land while it runs
+    f16x8 vh[NKP], vl[NKP];
+#pragma unroll
+    for (int kb = 0; kb < NKP; ++kb) {
+      const char *vp = kv + KV_V + (m * NKP_MAX + kb) * PAIR_BYTES;
+      vh[kb] = *reinterpret_cast<const f16x8 *>(vp); vl[kb] = *reinterpret_cast<const f16x8 *>(vp + 1024);
+    }
+    const float inva = softmax_tiles<NKT>(sa), invb = softmax_tiles<NKT>(sb);
+    f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = oa;
+#pragma unroll
+    for (int kb = 0; kb < NKP; ++kb) {
+      f16x8 ph, pl;
+      split_frag(sa[2 * kb], sa[2 * kb + 1], ph, pl);
+      mfma3(oa, vh[kb], vl[kb], ph, pl);
+      split_frag(sb[2 * kb], sb[2 * kb + 1], ph, pl);
+      mfma3(ob, vh[kb], vl[kb], ph, pl);
+    }
+    o[m] = glo ? oa * inva : ob * invb;
+  }
+}
+
+// ordered compaction of `n` candidates into list[base ..] by the 256 threads (4 waves) of a half workgroup; every
+// thread of the WORKGROUP must call it (barriers).  cnt[0..3]: wave counts of this half, *run: running total.
+template <class Pred, class Val>
+__device__ __forceinline__ void compact_half(int n, int htid, int hwave, int lane, int *cnt, int *run, int *list, int cap, Pred pred, Val val) {
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    const int i = c0 + htid;
+    const bool on = i < n && pred(i);
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) cnt[hwave] = __popcll(bal);
+    __syncthreads();
+    int off = *run;
+    for (int w = 0; w < hwave; ++w) off += cnt[w];
+    const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+    if (on && k < cap) list[k] = val(i);
+    __syncthreads();
+    if (htid == 0) *run = min(*run + cnt[0] + cnt[1] + cnt[2] + cnt[3], cap);
+    __syncthreads();
+  }
+}
+
+// In-kernel phase stamps (S3_STAMPS diagnostic build only, tools/s3_stamps.py): s_memtime deltas accumulated per wave.
+//   0 prologue (DMA issue, patched row, key lists, first barrier)   1 K / V tiles   2 barrier behind K / V
+//   3 tile load + Q projection   4 attention   5 out-projection .. LN2, stores, logits   6 barrier behind the tiles
+//   7 next layer's weights (DMA + wait + barrier)   8 whole kernel
+#ifdef S3_STAMPS
+#define S3_NSTAMP 9
+struct Stamps {
+  unsigned long long t_prev, acc[S3_NSTAMP];
+  __device__ __forceinline__ void start() { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory"); }
+  __device__ __forceinline__ void lap(int k) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    acc[k] += t - t_prev;
+    t_prev = t;
+  }
+};
+#define S3_LAP(k) stamps.lap(k)
+#else
+#define S3_LAP(k)
+#endif
+
+// ---- one design step of EPW episodes: every encoder layer + the acquisition logits ----------------------------------
+struct StepArgs {
+  Geo g; int tpe, L, F;
+  int order;                       // > 0: role value of the point chosen at the previous step (its X0 row becomes Ex + Ey)
+  const unsigned *img;             // L layer images, then the head images
+  u32x4 *X0, *XW;                  // input image (patched in place) / work image
+  AsmArgs emb;                     // sources of the patched row
+  float *logits; int NP;           // logits[b * NP + row]
+  u32x4 *zimg; long zrow0;         // dense-row image of the target rows of all steps (null: not wanted)
+#ifdef S3_STAMPS
+  unsigned long long *stamps;      // [8 waves][S3_NSTAMP] of workgroup 0
+#endif
+};
+
+template <int F>
+__global__ __launch_bounds__(THREADS) void step_kernel(StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const Geo &G = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = wave >> 2, hwave = wave & 3, htid = tid & 255;
+  const int tpe = a.tpe, n_t = G.n_td + G.n_th;
+  constexpr int NH = F / 16;                       // hidden tiles (= W1 pairs = W2 pairs)
+  const int lbytes = layer_bytes(F);
+  char *wl = lds + W_OFF, *whd = lds + HEAD_OFF;
+  int *keyrow = reinterpret_cast<int *>(lds + KEY_OFF), *misc = keyrow + EPW * NK_MAX;
+  // misc: [0,1] context keys of episode 0 / 1   [2,3] all keys   [4..11] wave counts   [12,13] running totals
+  //       [14] next K / V job   [15] next token-tile job (work queues: the waves of a SIMD do not run at the same pace)
+  const char *gimg = reinterpret_cast<const char *>(a.img);
+#ifdef S3_STAMPS
+  Stamps stamps{};
+  stamps.start();
+  const unsigned long long t_begin = stamps.t_prev;
+#endif
+  dma_copy(gimg, wl, lbytes, wave, lane);
+  dma_copy(gimg + (long)a.L * lbytes, whd, head_bytes(F), wave, lane);
+  const int b_half = blockIdx.x * EPW + half;
+  const bool ep_ok = b_half < G.B;
+  const int bh = min(b_half, G.B - 1);
+  if (a.order > 0 && hwave == 0 && ep_ok) {      // the point chosen at the previous step enters the context
+    int slot = -1;
+    for (int p = lane; p < G.P; p += 64)
+      if (G.role[(long)bh * G.P + p] == a.order) slot = p;
+    slot = __reduce_max_sync(~0ull, slot);
+    if (slot >= 0 && lane < 4) {
+      f32x4 lo, hi;
+      embed_row8(a.emb, bh, slot, 4 * lane, lo, hi);
+      store_split8(a.X0, (long)bh * tpe + (slot >> 4), lane * 16 + (slot & 15), lo, hi);
+    }
+  }
+  if (htid == 0) misc[12 + half] = 0;
+  if (tid == 0) { misc[14] = 0; misc[15] = 0; }
+  __syncthreads();
+  compact_half(G.P, htid, hwave, lane, misc + 4 + 4 * half, misc + 12 + half, keyrow + half * NK_MAX, NK_MAX,
+               [&](int p) { return ep_ok && is_ctx(G, bh, p); }, [](int p) { return p; });
+  if (htid == 0) misc[half] = misc[12 + half];
+  compact_half(n_t, htid, hwave, lane, misc + 4 + 4 * half, misc + 12 + half, keyrow + half * NK_MAX, NK_MAX,
+               [&](int j) { return ep_ok && (!G.tmask || G.tmask[j]); }, [&](int j) { return G.P + j; });
+  if (htid == 0) misc[2 + half] = misc[12 + half];
+  wait_vmcnt<0>();
+  __syncthreads();
+  S3_LAP(0);
+
+  for (int l = 0; l < a.L; ++l) {
+    const bool last = l == a.L - 1;
+    const u32x4 *xin = l == 0 ? a.X0 : a.XW;
+    const float *prm = reinterpret_cast<const float *>(wl + layer_pairs(F) * PAIR_BYTES);
+    const float *bq = prm, *bk = prm + D, *bv = prm + 2 * D, *bo = prm + 3 * D, *b1 = prm + 4 * D, *b2 = b1 + F;
+    const float *ln1w = b2 + D, *ln1b = ln1w + D, *ln2w = ln1b + D, *ln2b = ln2w + D;
+    // ---- K / V of the key rows -> LDS ---------------------------------------------------------------------------
+    const int nk2_0 = 2 * ((misc[2] + 31) >> 5), nk2_1 = 2 * ((misc[3] + 31) >> 5);
+    for (;;) {
+      int job = 0;
+      if (lane == 0) job = atomicAdd(misc + 14, 1);
+      job = __builtin_amdgcn_readfirstlane(job);
+      if (job >= nk2_0 + nk2_1) break;
+      const int e = job >= nk2_0, kt = job - e * nk2_0;
+      const int b = min(blockIdx.x * EPW + e, G.B - 1);
+      const int key = 16 * kt + tok;
+      const int row = key < misc[2 + e] ? keyrow[e * NK_MAX + key] : -1;
+      f16x8 xh = {0, 0, 0, 0, 0, 0, 0, 0}, xl = xh;
+      if (row >= 0) {
+        const long tl = (long)b * tpe + (row >> 4);
+        xh = __builtin_bit_cast(f16x8, xin[xpiece(tl, 0, 16 * g + (row & 15))]);
+        xl = __builtin_bit_cast(f16x8, xin[xpiece(tl, 1, 16 * g + (row & 15))]);
+      }
+      char *kv = lds + KV_OFF + e * KV_EP + lane * 16;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      {   // K^T = Wk KX^T: rows = channels, columns = keys -> the A fragment pair of key tile kt
+        f32x4 y0 = z4, y1 = z4;
+        const Frag w0 = lds_pair(wl, 2, lane), w1 = lds_pair(wl, 3, lane);
+        mfma3(y0, w0.hi, w0.lo, xh, xl);
+        mfma3(y1, w1.hi, w1.lo, xh, xl);
+        f16x8 fh, fl;
+        split_frag(y0 * WINV + ld4(bk + 4 * g), y1 * WINV + ld4(bk + 16 + 4 * g), fh, fl);
+        *reinterpret_cast<f16x8 *>(kv + kt * PAIR_BYTES) = fh;
+        *reinterpret_cast<f16x8 *>(kv + kt * PAIR_BYTES + 1024) = fl;
+      }
+      // V = KX Wv^T with the operands swapped (rows = keys, columns = channels): accumulator i holds
+      // V[key 16 kt + 4 g + r][channel 16 i + tok] = half (kt & 1) of this lane's piece of the V^T pair (i, kt / 2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x4 v = z4;
+        const Frag w = lds_pair(wl, 4 + i, lane);
+        mfma3(v, xh, xl, w.hi, w.lo);
+        const float bvv = bv[16 * i + tok];
+        unsigned h0, l0, h1, l1;
+        split2(v[0] * WINV + bvv, v[1] * WINV + bvv, h0, l0);
+        split2(v[2] * WINV + bvv, v[3] * WINV + bvv, h1, l1);
+        char *vp = kv + KV_V + (i * NKP_MAX + (kt >> 1)) * PAIR_BYTES + 8 * (kt & 1);
+        *reinterpret_cast<u32x2 *>(vp) = (u32x2){h0, h1};
+        *reinterpret_cast<u32x2 *>(vp + 1024) = (u32x2){l0, l1};
+      }
+    }
+    S3_LAP(1);
+    __syncthreads();
+    if (tid == 0) misc[14] = 0;
+    S3_LAP(2);
+    // ---- token tiles ------------------------------------------------------------------------------------------------
+    const int n_heavy = min((G.P + 15) >> 4, tpe), n_light = tpe - n_heavy;     // tiles with candidate rows / target rows only
+    for (;;) {
+      int job = 0;
+      if (lane == 0) job = atomicAdd(misc + 15, 1);
+      job = __builtin_amdgcn_readfirstlane(job);
+      if (job >= EPW * tpe) break;
+      int e, j;
+      if (job < EPW * n_heavy) { e = job / n_heavy; j = job - e * n_heavy; }
+      else { const int q = job - EPW * n_heavy; e = q / n_light; j = n_heavy + q - e * n_light; }
+      const int b = blockIdx.x * EPW + e;
+      if (b >= G.B) continue;
+      const long tl = (long)b * tpe + j;
+      const int r = 16 * j + tok, rc = min(r, G.N - 1);
+      const f16x8 xh = __builtin_bit_cast(f16x8, xin[xpiece(tl, 0, lane)]), xl = __builtin_bit_cast(f16x8, xin[xpiece(tl, 1, lane)]);
+      const int n_ck = misc[e], n_ak = misc[2 + e];
+      const bool isq = rc < G.P && !is_ctx(G, b, rc);
+      const bool hasq = 16 * j < G.P;                 // (wave-uniform) some row of the tile may see the targets
+      const int nkp = max(1, ((hasq ? n_ak : n_ck) + 31) >> 5);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      // Q^T = Wq X^T (pre-scaled by log2(e) / sqrt(hd))
+      f16x8 qh, ql;
+      {
+        f32x4 y0 = z4, y1 = z4;
+        const Frag w0 = lds_pair(wl, 0, lane), w1 = lds_pair(wl, 1, lane);
+        mfma3(y0, w0.hi, w0.lo, xh, xl);
+        mfma3(y1, w1.hi, w1.lo, xh, xl);
+        split_frag(y0 * WINV + ld4(bq + 4 * g), y1 * WINV + ld4(bq + 16 + 4 * g), qh, ql);
+      }
+      S3_LAP(3);
+      f32x4 o[2];
+      {
+        const char *kv = lds + KV_OFF + e * KV_EP + lane * 16;
+        const int nv4 = (isq ? n_ak : n_ck) - 4 * g;
+        switch (nkp) {
+          case 1: attention<1>(qh, ql, kv, nv4, g, o); break;
+          case 2: attention<2>(qh, ql, kv, nv4, g, o); break;
+          case 3: attention<3>(qh, ql, kv, nv4, g, o); break;
+          case 4: attention<4>(qh, ql, kv, nv4, g, o); break;
+          default: attention<5>(qh, ql, kv, nv4, g, o); break;
+        }
+      }
+#ifdef S3_STAMPS
+      asm volatile("" :: "v"(o[0]), "v"(o[1]));
+#endif
+      S3_LAP(4);
+      // X1 = LN1(X + bo + Wo A)
+      f32x4 x1a, x1b;
+      f16x8 x1h, x1l;
+      {
+        f16x8 ah, al;
+        split_frag(o[0], o[1], ah, al);
+        f32x4 y0 = z4, y1 = z4;
+        const Frag w0 = lds_pair(wl, 6, lane), w1 = lds_pair(wl, 7, lane);
+        mfma3(y0, w0.hi, w0.lo, ah, al);
+        mfma3(y1, w1.hi, w1.lo, ah, al);
+        x1a = y0 * WINV + ld4(bo + 4 * g) + frag_value(xh, xl, 0);
+        x1b = y1 * WINV + ld4(bo + 16 + 4 * g) + frag_value(xh, xl, 1);
+        layer_norm32(x1a, x1b, ln1w, ln1b, g);
+        split_frag(x1a, x1b, x1h, x1l);
+      }
+      // X2 = LN2(X1 + b2 + W2 relu(W1 X1 + b1)): all F hidden units of the tile in registers
+      f32x4 y0 = z4, y1 = z4;
+      {
+        f32x4 hid[NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+          const Frag u = lds_pair(wl, 8 + i, lane);
+          hid[i] = z4;
+          mfma3(hid[i], u.hi, u.lo, x1h, x1l);
+        }
+        f16x8 hh[NH / 2], hl[NH / 2];
+#pragma unroll
+        for (int c = 0; c < NH / 2; ++c) {
+          f32x4 h0 = hid[2 * c] * WINV + ld4(b1 + 32 * c + 4 * g), h1 = hid[2 * c + 1] * WINV + ld4(b1 + 32 * c + 16 + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { h0[q] = relu_s(h0[q]); h1[q] = relu_s(h1[q]); }
+          split_frag(h0, h1, hh[c], hl[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NH / 2; ++c) {
+          const Frag v0 = lds_pair(wl, 8 + NH + 2 * c, lane), v1 = lds_pair(wl, 8 + NH + 2 * c + 1, lane);
+          mfma3(y0, v0.hi, v0.lo, hh[c], hl[c]);
+          mfma3(y1, v1.hi, v1.lo, hh[c], hl[c]);
+        }
+      }
+      f32x4 x2a = y0 * WINV + ld4(b2 + 4 * g) + x1a, x2b = y1 * WINV + ld4(b2 + 16 + 4 * g) + x1b;
+      layer_norm32(x2a, x2b, ln2w, ln2b, g);
+      f16x8 oh, ol;
+      split_frag(x2a, x2b, oh, ol);
+      if (!last) {
+        a.XW[xpiece(tl, 0, lane)] = __builtin_bit_cast(u32x4, oh);
+        a.XW[xpiece(tl, 1, lane)] = __builtin_bit_cast(u32x4, ol);
+      } else {
+        if (a.zimg && r >= G.P && r < G.N) {
+          const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
+          a.zimg[xpiece(zr >> 4, 0, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, oh);
+          a.zimg[xpiece(zr >> 4, 1, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, ol);
+        }
+        if (hasq) {   // acquisition logits of the candidate rows (model/head.py:27-33)
+          const float *hp = reinterpret_cast<const float *>(whd + head_pairs(F) * PAIR_BYTES);   // b1 | w2 | .. | b2
+          float plog = 0.f;
+          f32x4 hid[NH];
+#pragma unroll
+          for (int i = 0; i < NH; ++i) {
+            const Frag u = lds_pair(whd, i, lane);
+            hid[i] = z4;
+            mfma3(hid[i], u.hi, u.lo, oh, ol);
+          }
+#pragma unroll
+          for (int i = 0; i < NH; ++i) {
+            const f32x4 hv = hid[i] * WINV + ld4(hp + 16 * i + 4 * g), wv = ld4(hp + F + 16 * i + 4 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) plog = fmaf(relu_s(hv[q]), wv[q], plog);
+          }
+          const float v = group_sum4(plog) + hp[4 * F];
+          if (g == 0 && r < G.P) a.logits[(long)b * a.NP + r] = v;
+        }
+      }
+      S3_LAP(5);
+    }
+    __syncthreads();
+    if (tid == 0) misc[15] = 0;
+    S3_LAP(6);
+    if (!last) {
+      dma_copy(gimg + (long)(l + 1) * lbytes, wl, lbytes, wave, lane);
+      wait_vmcnt<0>();
+      __syncthreads();
+      S3_LAP(7);
+    }
+  }
+#ifdef S3_STAMPS
+  if (a.stamps && blockIdx.x == 0 && lane == 0) {
+    stamps.acc[8] = stamps.t_prev - t_begin;
+    for (int k = 0; k < S3_NSTAMP; ++k) a.stamps[wave * S3_NSTAMP + k] = stamps.acc[k];
+  }
+#endif
+}
+
+// ---- the C GMM heads (model/head.py:152-186) over the dense-row image of all steps' target rows --------------------
+// raw_c[j] = w2_c[j] . relu(W1_c z + b1_c) + b2_c[j]; a wave keeps GT tiles in registers and walks the components,
+// whose images take turns in LDS; the raw outputs of the workgroup's 512 rows collect in LDS and one thread per row
+// turns them into the mixture parameters (mean, softplus std + std_min, softmax weight: head.py:264-265 with
+// dim_y == 1) and the log-likelihood of the row's target value (utils/eval.py:200-207).
+constexpr int GT = 4, GROWS = WAVES * GT * 16;
+struct GmmArgs {
+  const u32x4 *Z; long ntiles, M;
+  const unsigned *img; int C; float std_min;      // img: the first GMM head image
+  float *mean, *sd, *wgt;                         // [M, C] or null
+  const float *value; long value_mod;             // value[row % value_mod] or null
+  float *ll;                                      // [M] or null
+};
+template <int F>
+__global__ __launch_bounds__(THREADS) void gmm_kernel(GmmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NH = F / 16;
+  const int hb = head_bytes(F);
+  float *raw = reinterpret_cast<float *>(lds + hb);          // [3 C][GROWS]
+  const long tile0 = ((long)blockIdx.x * WAVES + wave) * GT;
+  f16x8 zh[GT], zl[GT];
+#pragma unroll
+  for (int i = 0; i < GT; ++i) {
+    const long tl = min(tile0 + i, a.ntiles - 1);
+    zh[i] = __builtin_bit_cast(f16x8, a.Z[xpiece(tl, 0, lane)]);
+    zl[i] = __builtin_bit_cast(f16x8, a.Z[xpiece(tl, 1, lane)]);
+  }
+  const float *hp = reinterpret_cast<const float *>(lds + head_pairs(F) * PAIR_BYTES);   // b1 | w2 [3] | b2
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < a.C; ++c) {
+    __syncthreads();
+    dma_copy(reinterpret_cast<const char *>(a.img) + (long)c * hb, lds, hb, wave, lane);
+    wait_vmcnt<0>();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < GT; ++i) {
+      f32x4 hid[NH];
+#pragma unroll
+      for (int t = 0; t < NH; ++t) {
+        const Frag u = lds_pair(lds, t, lane);
+        hid[t] = z4;
+        mfma3(hid[t], u.hi, u.lo, zh[i], zl[i]);
+      }
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NH; ++t) {
+        const f32x4 hv = hid[t] * WINV + ld4(hp + 16 * t + 4 * g);
+        const f32x4 w0 = ld4(hp + F + 16 * t + 4 * g), w1 = ld4(hp + 2 * F + 16 * t + 4 * g), w2 = ld4(hp + 3 * F + 16 * t + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float rl = relu_s(hv[q]);
+          p0 = fmaf(rl, w0[q], p0); p1 = fmaf(rl, w1[q], p1); p2 = fmaf(rl, w2[q], p2);
+        }
+      }
+      p0 = group_sum4(p0) + hp[4 * F]; p1 = group_sum4(p1) + hp[4 * F + 1]; p2 = group_sum4(p2) + hp[4 * F + 2];
+      if (g == 0) {
+        const int rl = (wave * GT + i) * 16 + tok;
+        raw[(3 * c) * GROWS + rl] = p0; raw[(3 * c + 1) * GROWS + rl] = p1; raw[(3 * c + 2) * GROWS + rl] = p2;
+      }
+    }
+  }
+  __syncthreads();
+  const long row = (long)blockIdx.x * GROWS + tid;
+  if (row >= a.M) return;
+  const float *rr = raw + tid;
+  float mxw = -INFINITY;
+  for (int c = 0; c < a.C; ++c) mxw = fmaxf(mxw, rr[(3 * c + 2) * GROWS]);
+  float sw = 0.f;
+  for (int c = 0; c < a.C; ++c) sw += __expf(rr[(3 * c + 2) * GROWS] - mxw);
+  const bool want_ll = a.ll && a.value;
+  const float v = want_ll ? a.value[row % a.value_mod] : 0.f;
+  float mx2 = -INFINITY;
+  for (int c = 0; c < a.C; ++c) {
+    const float mean = rr[(3 * c) * GROWS], sd = softplus_f(rr[(3 * c + 1) * GROWS]) + a.std_min, w = __expf(rr[(3 * c + 2) * GROWS] - mxw) / sw;
+    if (a.mean) a.mean[row * a.C + c] = mean;
+    if (a.sd) a.sd[row * a.C + c] = sd;
+    if (a.wgt) a.wgt[row * a.C + c] = w;
+    const float zz = (v - mean) / sd;
+    const float lp = -0.5f * zz * zz - logf(sd) - 0.91893853320467274178f + logf(w);
+    raw[(3 * c) * GROWS + tid] = lp;     // (this thread's own column)
+    mx2 = fmaxf(mx2, lp);
+  }
+  if (want_ll) {
+    float se = 0.f;
+    for (int c = 0; c < a.C; ++c) se += __expf(rr[(3 * c) * GROWS] - mx2);
+    a.ll[row] = mx2 + logf(se);
+  }
+}
+
+}  // namespace s3

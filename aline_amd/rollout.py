@@ -83,6 +83,17 @@ class Rollout:
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._graph = None
 
+    PATHS = {0: "generic pipeline", 1: "fused::rollout_f32_kernel", 2: "wide::wide_step_kernel",
+             3: "x3::layer_kernel", 4: "s3::step_kernel"}
+
+    @property
+    def path(self):
+        """The implementation aline_rollout_forward picks for this model / batch (named by its dominant kernel)."""
+        rc = _lib.lib.aline_rollout_path(C.byref(self.m), C.byref(self.r))
+        if rc < 0:
+            _lib.check(rc, "rollout_path")
+        return self.PATHS[rc]
+
     # ------------------------------------------------------------------------------------------
     def refresh_uniform(self):
         if self.uniform is not None:

@@ -158,6 +158,14 @@ int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void
                        size_t ws_bytes, void *stream);             /* forward + select + update */
 int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
                           void *stream);                            /* init + T steps */
+/* Which implementation aline_rollout_forward runs for (m, r): the generic per-stage pipeline or one of the fused
+ * paths.  Negative: error code. */
+enum { ALINE_PATH_GENERIC = 0,   /* stage kernels + GEMMs, any configuration */
+       ALINE_PATH_FUSED = 1,     /* fused_rollout.h: d = 32, theta mode, F32, whole rollout in one launch */
+       ALINE_PATH_WIDE = 2,      /* wide.h: d = 256, BF16 */
+       ALINE_PATH_X3 = 3,        /* x3.h: d = 256, F16X3 (reference precision on the f16 matrix pipe) */
+       ALINE_PATH_S3 = 4 };      /* s3.h: d = 32, F16X3, any embedding mode, one launch per design step */
+int aline_rollout_path(const aline_model *m, const aline_rollout *r);
 /* Task.update_batch equivalent for callers that want the reference layout back
  * (tasks/base_task.py:133-154): context_x/y [B,n_ctx0+T,*] in order of entry, query remainder. */
 int aline_rollout_export(const aline_rollout *r, int n_ctx, float *context_x, float *context_y,

@@ -52,7 +52,12 @@ def roofline(geo, precision, B, dt):
     return r
 
 
+ONLY_PRECS = None
+
+
 def run(name, model, batch, T, steps, meta):
+    if ONLY_PRECS is not None and meta["precision"] not in ONLY_PRECS:
+        return
     ro = Rollout(model, batch, T, select="sample", keep_zt=False, keep_posterior=True)
     ro.run()
     torch.cuda.synchronize()
@@ -67,7 +72,7 @@ def run(name, model, batch, T, steps, meta):
     dt = (time.perf_counter() - t0) / steps
     B, nq = ro.B, ro.n_q0
     out = {"config": name, "ms_per_rollout": dt * 1e3, "designs_per_s": B * T * nq / dt, "B": B, "T": T,
-           "n_query_init": nq, "n_tokens": ro.P + ro.n_t, **{k: v for k, v in meta.items() if k != "geo"}}
+           "n_query_init": nq, "n_tokens": ro.P + ro.n_t, **{k: v for k, v in meta.items() if k != "geo"}, "path": ro.path}
     if "geo" in meta:
         out["roofline"] = roofline(dict(meta["geo"], T=T), meta["precision"], B, dt)
     print(json.dumps(out), flush=True)
@@ -77,7 +82,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="1,2,3,5")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--precs", default="", help="comma list: only these precisions (default: all)")
     args = ap.parse_args()
+    global ONLY_PRECS
+    ONLY_PRECS = set(args.precs.split(",")) if args.precs else None
     want = set(args.configs.split(","))
     dev = torch.device("cuda")
     torch.manual_seed(123)
@@ -93,6 +101,8 @@ def main():
         geo = dict(dx=2, dy=1, d=32, F=128, H=4, L=3, C=10, n_c0=1, n_q0=200, n_td=0, n_th=2, n_s=2)
         run("cfg2 location_finding B=1000 T=30 d=32", build(2, 32, 128, 4, 2, "theta", "f32"), batch, 30, args.steps,
             {"d": 32, "precision": "f32", "path": path_of(32, 128, 4, "theta", "f32", 32), "geo": geo})
+        run("cfg2 location_finding B=1000 T=30 d=32 f16x3", build(2, 32, 128, 4, 2, "theta", "f16x3"), batch, 30, args.steps,
+            {"d": 32, "precision": "f16x3", "path": "", "geo": geo})
         for prec in ("f16x3", "bf16"):
             run(f"cfg2 location_finding B=1000 T=30 d=256 F=1024 H=8 {prec}", build(2, 256, 1024, 8, 2, "theta", prec), batch, 30,
                 args.steps, {"d": 256, "precision": prec, "path": path_of(256, 1024, 8, "theta", prec, 32),
