@@ -505,23 +505,57 @@ static int device_cus() {
   return n;
 }
 
-template <int F>
-static int launch_s3_step_f(const Ctx &c, unsigned nwg, const s3::StepArgs &a) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, s3::STEP_LDS);
-    attr = true;
+// Launch shape of the s3 step kernel: 16 waves per workgroup (4 per SIMD, 128 registers) while an episode never holds
+// more than 64 keys, 8 waves (256 registers: all scores of a head pair over 160 keys) otherwise; as many episodes per
+// workgroup as keeps every CU busy and the token tiles spread evenly over the waves.
+struct S3Shape { int nw, nkp, epw; unsigned nwg; size_t lds; };     // nkp: key-tile pairs an episode's LDS slot holds
+static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
+  S3Shape s{};
+  const int n_t = r.n_target_data + m.n_theta, N = r.P + n_t, tpe = (N + 15) / 16;
+  const int nkeys = r.n_ctx0 + r.T - 1 + n_t;
+  const int need = std::max(1, (nkeys + 31) / 32);
+  s.nw = need <= 2 ? 16 : 8;
+  if (const char *e = getenv("ALINE_S3_WAVES")) s.nw = atoi(e) == 16 && need <= 2 ? 16 : 8;
+  s.nkp = s.nw == 16 ? 2 : s3::NKP_MAX;
+  const int per_ep = s3::kv_ep_bytes(s.nkp) + 32 * s.nkp * 4;
+  const int epw_max = std::max(1, std::min(s3::EPW_MAX, (s3::LDS_LIMIT - s3::KV_OFF - s3::MISC_INTS * 4) / per_ep));
+  const int cus = device_cus();
+  double best = 1e30;
+  for (int e = 1; e <= epw_max; ++e) {
+    const long nwg = (r.B + e - 1) / e;
+    const double rounds = (double)((nwg + cus - 1) / cus);                    // workgroup rounds over the chip
+    const double slots = std::ceil((double)e * tpe / s.nw) + 0.35;             // tile rounds of a workgroup (+ its fixed work)
+    const double cost = rounds * slots;
+    if (cost < best - 1e-9) { best = cost; s.epw = e; }
   }
-  hipLaunchKernelGGL(s3::step_kernel<F>, dim3(nwg), dim3(s3::THREADS), s3::STEP_LDS, c.st, a);
+  if (const char *e = getenv("ALINE_S3_EPW")) s.epw = std::max(1, std::min(epw_max, atoi(e)));
+  s.nwg = (unsigned)((r.B + s.epw - 1) / s.epw);
+  s.lds = (size_t)s3::step_lds_bytes(s.epw, s.nkp);
+  return s;
+}
+
+template <int F, int NW, int MAXNKP>
+static int launch_s3_step_v(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {
+  constexpr bool PF = NW == 16;      // next tile's rows requested a tile ahead (the 8-wave variant has no registers for it)
+  static size_t attr = 0;
+  if (sh.lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F, NW, MAXNKP, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
+    attr = sh.lds;
+  }
+  hipLaunchKernelGGL((s3::step_kernel<F, NW, MAXNKP, PF>), dim3(sh.nwg), dim3(NW * 64), sh.lds, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
-static int launch_s3_step(const Ctx &c, unsigned nwg, const s3::StepArgs &a) {
+template <int F>
+static int launch_s3_step_f(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {
+  return sh.nw == 16 ? launch_s3_step_v<F, 16, 2>(c, sh, a) : launch_s3_step_v<F, 8, s3::NKP_MAX>(c, sh, a);
+}
+static int launch_s3_step(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {
   switch (a.F) {
-    case 32: return launch_s3_step_f<32>(c, nwg, a);
-    case 64: return launch_s3_step_f<64>(c, nwg, a);
-    case 96: return launch_s3_step_f<96>(c, nwg, a);
-    case 128: return launch_s3_step_f<128>(c, nwg, a);
+    case 32: return launch_s3_step_f<32>(c, sh, a);
+    case 64: return launch_s3_step_f<64>(c, sh, a);
+    case 96: return launch_s3_step_f<96>(c, sh, a);
+    case 128: return launch_s3_step_f<128>(c, sh, a);
     default: return ALINE_EUNSUPPORTED;
   }
 }
@@ -1141,11 +1175,12 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   hipLaunchKernelGGL(s3::assemble_kernel, grid1d((size_t)tiles * 64), dim3(256), 0, c.st, aa);
   CHECK_LAUNCH();
   const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
-  const unsigned nwg = (unsigned)((r->B + s3::EPW - 1) / s3::EPW);
+  const S3Shape sh = s3_shape(*m, *r);
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
     s3::StepArgs sa{};
     sa.g = c.g; sa.tpe = tpe; sa.L = m->L; sa.F = F; sa.order = t > 0 ? r->n_ctx0 + t : 0;
+    sa.epw = sh.epw; sa.nk2 = 2 * std::min(sh.nkp, (r->n_ctx0 + t + n_t + 31) / 32);
     sa.img = img; sa.X0 = X0; sa.XW = XW; sa.emb = aa; sa.emb.g = c.g;
     sa.logits = logits; sa.NP = NP;
     sa.zimg = want_gmm ? Zimg : nullptr; sa.zrow0 = (long)t * r->B * n_t;
@@ -1154,7 +1189,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
 #endif
     const bool timed = t == r->T - 1;                          // bench.py times this launch of the dominant kernel
     if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
-    TRY(launch_s3_step(c, nwg, sa));
+    TRY(launch_s3_step(c, sh, sa));
     if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
     CHECK_LAUNCH();
     SelectArgs sel{};
@@ -1470,7 +1505,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
   if (!m || !r || !gr || !ws || t_chunk < 1) return ALINE_EINVAL;
   if (do_head && (!g_logp || (!g_ll && !g_pm && !g_ps && !g_pw))) return ALINE_EINVAL;
   TRY(validate_model(*m, io.stages));
-  if (m->precision != ALINE_PREC_F32 || m->time_token) return ALINE_EUNSUPPORTED;
+  // (the forward activations are recomputed here in exact fp32 whichever reference-precision mode rolled the episodes out)
+  if ((m->precision != ALINE_PREC_F32 && m->precision != ALINE_PREC_F16X3) || m->time_token) return ALINE_EUNSUPPORTED;
   if (!r->role || (do_head && (!r->slot || !r->target_all)) || (do_emb && (!r->point_x || !r->point_y))) return ALINE_EINVAL;
   if (io.stages != ST_ALL && r->T != 1) return ALINE_EINVAL;
   if ((do_enc && !do_emb && !io.x_in) || (do_head && !do_enc && !io.z_in) || (!do_head && !io.d_in) ||

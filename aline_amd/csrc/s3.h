@@ -24,7 +24,6 @@ using wide::group_sum4;
 using wide::u32x2;
 using wide::u32x4;
 using x3::f16x8;
-using x3::frag_value;
 using x3::glds16;
 using x3::group_max4;
 using x3::mfma3;
@@ -32,8 +31,9 @@ using x3::split2;
 using x3::wait_vmcnt;
 
 constexpr int D = 32, H = 4, HD = 8, F_MAX = 128;
-constexpr int THREADS = 512, WAVES = THREADS / 64, EPW = 2;
+constexpr int THREADS = 512, WAVES = THREADS / 64;                          // (pack / GMM kernels; the step kernel: 8 or 16 waves)
 constexpr int NKP_MAX = 5, NKT_MAX = 2 * NKP_MAX, NK_MAX = 16 * NKT_MAX;     // key-tile pairs / tiles / keys per episode
+constexpr int EPW_MAX = 16;                                                  // episodes per workgroup
 constexpr float WSCALE = 256.f, WINV = 1.f / 256.f;
 constexpr int PAIR_BYTES = 2048, PAIR_WORDS = 512;
 
@@ -54,13 +54,17 @@ __host__ __device__ inline long image_words(int L, int F, int C) { return ((long
 __host__ __device__ inline long img_pieces(long tiles) { return tiles * 128; }
 __device__ __forceinline__ long xpiece(long tile, int hl, int lane) { return (tile * 2 + hl) * 64 + lane; }
 
-// LDS map of the step kernel (bytes)
+// LDS map of the step kernel (bytes): layer image | acquisition-head image | per episode K pairs [2 nkp] and V^T pairs
+// [m 2][nkp] | per episode key list [32 nkp] | misc.  nkp = key-tile PAIRS kept per episode (the rollout's bound), epw =
+// episodes per workgroup: both chosen by the host (step_plan).
 constexpr int W_OFF = 0, W_BYTES = 51200;                 // layer_bytes(F_MAX)
 constexpr int HEAD_OFF = W_OFF + W_BYTES, HEAD_BYTES = 19456;   // head_bytes(F_MAX)
-constexpr int KV_OFF = HEAD_OFF + HEAD_BYTES, KV_EP = NKT_MAX * 4096, KV_V = NKT_MAX * 2048;   // K pairs [kt] | V^T pairs [m][kb]
-constexpr int KEY_OFF = KV_OFF + EPW * KV_EP;             // keyrow [EPW][NK_MAX] | misc [16]
-constexpr int STEP_LDS = KEY_OFF + (EPW * NK_MAX + 16) * 4;
-static_assert(STEP_LDS <= 160 * 1024, "step kernel LDS");
+constexpr int KV_OFF = HEAD_OFF + HEAD_BYTES;
+constexpr int MISC_INTS = 2 * EPW_MAX + 32;               // n_ck [epw] | n_ak [epw] | wave counts [4][4] | running [4] | queues [2]
+__host__ __device__ inline int kv_ep_bytes(int nkp) { return nkp * 8192; }
+__host__ __device__ inline int step_lds_bytes(int epw, int nkp) { return KV_OFF + epw * (kv_ep_bytes(nkp) + 32 * nkp * 4) + MISC_INTS * 4; }
+constexpr int LDS_LIMIT = 160 * 1024;
+static_assert(KV_OFF + (NKT_MAX * 4096 + NK_MAX * 4) * 2 + MISC_INTS * 4 <= LDS_LIMIT, "two episodes of 160 keys must fit");
 
 // (a, b) -> packed f16 hi halves, packed f16 lo halves (a - hi, b - hi: exact in fp32, then rounded).  The residuals are
 // one v_fma_mix_f32 each (f16 source operand read straight out of the packed register): 4 instructions per pair.
@@ -72,6 +76,20 @@ __device__ __forceinline__ void split2m(float a, float b, unsigned &hi, unsigned
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(b));
   const x3::f32x2 r = {r0, r1};
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x3::f16x2));
+}
+// the fp32 values a fragment pair stands for, elements 4 hf .. 4 hf + 3: hi + lo, one v_fma_mix_f32 each (both f16
+// operands read straight out of the packed registers)
+__device__ __forceinline__ f32x4 frag_value(const f16x8 &hi, const f16x8 &lo, int hf) {
+  const u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
+  f32x4 v;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    float a, b;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(h[2 * hf + w]), "v"(l[2 * hf + w]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(b) : "v"(h[2 * hf + w]), "v"(l[2 * hf + w]));
+    v[2 * w] = a; v[2 * w + 1] = b;
+  }
+  return v;
 }
 // two accumulator tiles (features 16 m + 4 g + r, 16 (m + 1) + 4 g + r) -> the hi / lo B fragments of their k-step
 __device__ __forceinline__ void split_frag(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo) {
@@ -202,7 +220,7 @@ __device__ __forceinline__ void layer_norm32(f32x4 &a, f32x4 &b, const float *w,
   float q = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) { a[r] -= mean; b[r] -= mean; q = fmaf(a[r], a[r], q); q = fmaf(b[r], b[r], q); }
-  const float rstd = 1.f / sqrtf(group_sum4(q) * (1.f / D) + 1e-5f);
+  const float rstd = __builtin_amdgcn_rsqf(group_sum4(q) * (1.f / D) + 1e-5f);     // (v_rsq_f32: 1 ulp)
   const f32x4 w0 = ld4(w + 4 * g), w1 = ld4(w + 16 + 4 * g), b0 = ld4(bb + 4 * g), b1 = ld4(bb + 16 + 4 * g);
 #pragma unroll
   for (int r = 0; r < 4; ++r) { a[r] = fmaf(a[r] * rstd, w0[r], b0[r]); b[r] = fmaf(b[r] * rstd, w1[r], b1[r]); }
@@ -218,25 +236,23 @@ __device__ __forceinline__ float softmax_tiles(f32x4 (&s)[NKT]) {
     m1 = fmaxf(fmaxf(m1, s[kt][2]), s[kt][3]);
   }
   const float mx = group_max4(fmaxf(m0, m1));
-  const x3::f32x2 m2 = {mx, mx};
-  x3::f32x2 acc = {0.f, 0.f};
+  float acc0 = 0.f, acc1 = 0.f;        // (plain v_sub / v_add: full rate; the packed forms are not, and cost register moves)
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
-    const x3::f32x2 d0 = (x3::f32x2){s[kt][0], s[kt][1]} - m2, d1 = (x3::f32x2){s[kt][2], s[kt][3]} - m2;
-    const x3::f32x2 e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
-    const x3::f32x2 e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
-    acc += e0;
-    acc += e1;
-    s[kt] = (f32x4){e0[0], e0[1], e1[0], e1[1]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+    acc0 += s[kt][0] + s[kt][1];
+    acc1 += s[kt][2] + s[kt][3];
   }
-  return 1.f / group_sum4(acc[0] + acc[1]);
+  return __builtin_amdgcn_rcpf(group_sum4(acc0 + acc1));                         // (v_rcp_f32: 1 ulp)
 }
 
 // masked set-attention of one token tile against 2 NKP key tiles (model/encoder.py:8-46): S^T = K Q_h^T in the exp2
 // domain (scale folded into Wq), softmax over the keys of a token, O^T = V^T P.  kv: this episode's K / V^T pairs in
-// LDS (+ lane * 16); nv4 = (number of keys the lane's token sees) - 4 g.
-template <int NKP>
+// LDS (+ lane * 16; V^T pairs [m][nkp] at kv_v); nv4 = (number of keys the lane's token sees) - 4 g.
+template <int NKP, int CAP>
 __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, const char *kv, int nv4, int g, f32x4 (&o)[2]) {
+  constexpr int kv_v = CAP * 4096, nkp = CAP;     // LDS slot of an episode: K pairs [2 CAP] | V^T pairs [m][CAP]
   constexpr int NKT = 2 * NKP;
   const u32x4 qhu = __builtin_bit_cast(u32x4, qh), qlu = __builtin_bit_cast(u32x4, ql);
   const bool glo = g < 2;
@@ -265,7 +281,7 @@ __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, cons
     f16x8 vh[NKP], vl[NKP];
 #pragma unroll
     for (int kb = 0; kb < NKP; ++kb) {
-      const char *vp = kv + KV_V + (m * NKP_MAX + kb) * PAIR_BYTES;
+      const char *vp = kv + kv_v + (m * nkp + kb) * PAIR_BYTES;
       vh[kb] = *reinterpret_cast<const f16x8 *>(vp); vl[kb] = *reinterpret_cast<const f16x8 *>(vp + 1024);
     }
     const float inva = softmax_tiles<NKT>(sa), invb = softmax_tiles<NKT>(sb);
@@ -278,12 +294,16 @@ __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, cons
       split_frag(sb[2 * kb], sb[2 * kb + 1], ph, pl);
       mfma3(ob, vh[kb], vl[kb], ph, pl);
     }
-    o[m] = glo ? oa * inva : ob * invb;
+    {
+      const float inv = glo ? inva : invb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[m][r] = (glo ? oa[r] : ob[r]) * inv;
+    }
   }
 }
 
-// ordered compaction of `n` candidates into list[base ..] by the 256 threads (4 waves) of a half workgroup; every
-// thread of the WORKGROUP must call it (barriers).  cnt[0..3]: wave counts of this half, *run: running total.
+// ordered compaction of `n` candidates into list[base ..] by a 256-thread group (4 waves) of the workgroup; every
+// thread of the WORKGROUP must call it (barriers).  cnt[0..3]: wave counts of this group, *run: running total.
 template <class Pred, class Val>
 __device__ __forceinline__ void compact_half(int n, int htid, int hwave, int lane, int *cnt, int *run, int *list, int cap, Pred pred, Val val) {
   for (int c0 = 0; c0 < n; c0 += 256) {
@@ -326,6 +346,8 @@ struct Stamps {
 // ---- one design step of EPW episodes: every encoder layer + the acquisition logits ----------------------------------
 struct StepArgs {
   Geo g; int tpe, L, F;
+  int epw;                         // episodes per workgroup (the LDS slot of an episode holds the variant's MAXNKP key-tile pairs)
+  int nk2;                         // key tiles (even) to compute this step: 2 ceil(bound of the key count / 32) <= 2 nkp
   int order;                       // > 0: role value of the point chosen at the previous step (its X0 row becomes Ex + Ey)
   const unsigned *img;             // L layer images, then the head images
   u32x4 *X0, *XW;                  // input image (patched in place) / work image
@@ -337,50 +359,57 @@ struct StepArgs {
 #endif
 };
 
-template <int F>
-__global__ __launch_bounds__(THREADS) void step_kernel(StepArgs a) {
+template <int F, int NW, int MAXNKP, bool PREFETCH>
+__global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const Geo &G = a.g;
+  constexpr int NGRP = NW / 4;                     // 256-thread groups: one episode each in the prologue
   const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = wave >> 2, hwave = wave & 3, htid = tid & 255;
-  const int tpe = a.tpe, n_t = G.n_td + G.n_th;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, hwave = wave & 3, htid = tid & 255;
+  const int tpe = a.tpe, n_t = G.n_td + G.n_th, epw = a.epw;
+  constexpr int nkp = MAXNKP;                      // key-tile pairs an episode's LDS slot holds
   constexpr int NH = F / 16;                       // hidden tiles (= W1 pairs = W2 pairs)
   const int lbytes = layer_bytes(F);
   char *wl = lds + W_OFF, *whd = lds + HEAD_OFF;
-  int *keyrow = reinterpret_cast<int *>(lds + KEY_OFF), *misc = keyrow + EPW * NK_MAX;
-  // misc: [0,1] context keys of episode 0 / 1   [2,3] all keys   [4..11] wave counts   [12,13] running totals
-  //       [14] next K / V job   [15] next token-tile job (work queues: the waves of a SIMD do not run at the same pace)
+  constexpr int kv_ep = nkp * 8192, kv_v = nkp * 4096, nkcap = 32 * nkp;
+  int *keyrow = reinterpret_cast<int *>(lds + KV_OFF + epw * kv_ep), *misc = keyrow + epw * nkcap;
+  int *n_ck = misc, *n_ak = misc + EPW_MAX, *wcnt = misc + 2 * EPW_MAX, *run = wcnt + 16, *queue = run + 4;
   const char *gimg = reinterpret_cast<const char *>(a.img);
 #ifdef S3_STAMPS
   Stamps stamps{};
   stamps.start();
   const unsigned long long t_begin = stamps.t_prev;
 #endif
-  dma_copy(gimg, wl, lbytes, wave, lane);
-  dma_copy(gimg + (long)a.L * lbytes, whd, head_bytes(F), wave, lane);
-  const int b_half = blockIdx.x * EPW + half;
-  const bool ep_ok = b_half < G.B;
-  const int bh = min(b_half, G.B - 1);
-  if (a.order > 0 && hwave == 0 && ep_ok) {      // the point chosen at the previous step enters the context
-    int slot = -1;
-    for (int p = lane; p < G.P; p += 64)
-      if (G.role[(long)bh * G.P + p] == a.order) slot = p;
-    slot = __reduce_max_sync(~0ull, slot);
-    if (slot >= 0 && lane < 4) {
-      f32x4 lo, hi;
-      embed_row8(a.emb, bh, slot, 4 * lane, lo, hi);
-      store_split8(a.X0, (long)bh * tpe + (slot >> 4), lane * 16 + (slot & 15), lo, hi);
+  for (int piece = wave; piece < (lbytes >> 10); piece += NW) glds16(gimg + piece * 1024 + lane * 16, wl + piece * 1024);
+  for (int piece = wave; piece < (head_bytes(F) >> 10); piece += NW) glds16(gimg + (long)a.L * lbytes + piece * 1024 + lane * 16, whd + piece * 1024);
+  if (tid == 0) { queue[0] = 0; queue[1] = 0; }
+  // per episode: the patched row, then the key list (context rows in slot order, then the visible targets)
+  for (int e0 = 0; e0 < epw; e0 += NGRP) {
+    const int e = e0 + grp;
+    const int b_e = blockIdx.x * epw + e;
+    const bool ep_ok = e < epw && b_e < G.B;
+    const int bh = min(b_e, G.B - 1);
+    if (a.order > 0 && hwave == 0 && ep_ok) {      // the point chosen at the previous step enters the context
+      int slot = -1;
+      for (int p = lane; p < G.P; p += 64)
+        if (G.role[(long)bh * G.P + p] == a.order) slot = p;
+      slot = __reduce_max_sync(~0ull, slot);
+      if (slot >= 0 && lane < 4) {
+        f32x4 lo, hi;
+        embed_row8(a.emb, bh, slot, 4 * lane, lo, hi);
+        store_split8(a.X0, (long)bh * tpe + (slot >> 4), lane * 16 + (slot & 15), lo, hi);
+      }
     }
+    int *list = keyrow + min(e, epw - 1) * nkcap;
+    if (htid == 0) run[grp] = 0;
+    __syncthreads();
+    compact_half(G.P, htid, hwave, lane, wcnt + 4 * grp, run + grp, list, nkcap,
+                 [&](int p) { return ep_ok && is_ctx(G, bh, p); }, [](int p) { return p; });
+    if (htid == 0 && e < epw) n_ck[e] = run[grp];
+    compact_half(n_t, htid, hwave, lane, wcnt + 4 * grp, run + grp, list, nkcap,
+                 [&](int j) { return ep_ok && (!G.tmask || G.tmask[j]); }, [&](int j) { return G.P + j; });
+    if (htid == 0 && e < epw) n_ak[e] = run[grp];
   }
-  if (htid == 0) misc[12 + half] = 0;
-  if (tid == 0) { misc[14] = 0; misc[15] = 0; }
-  __syncthreads();
-  compact_half(G.P, htid, hwave, lane, misc + 4 + 4 * half, misc + 12 + half, keyrow + half * NK_MAX, NK_MAX,
-               [&](int p) { return ep_ok && is_ctx(G, bh, p); }, [](int p) { return p; });
-  if (htid == 0) misc[half] = misc[12 + half];
-  compact_half(n_t, htid, hwave, lane, misc + 4 + 4 * half, misc + 12 + half, keyrow + half * NK_MAX, NK_MAX,
-               [&](int j) { return ep_ok && (!G.tmask || G.tmask[j]); }, [&](int j) { return G.P + j; });
-  if (htid == 0) misc[2 + half] = misc[12 + half];
   wait_vmcnt<0>();
   __syncthreads();
   S3_LAP(0);
@@ -392,23 +421,24 @@ __global__ __launch_bounds__(THREADS) void step_kernel(StepArgs a) {
     const float *bq = prm, *bk = prm + D, *bv = prm + 2 * D, *bo = prm + 3 * D, *b1 = prm + 4 * D, *b2 = b1 + F;
     const float *ln1w = b2 + D, *ln1b = ln1w + D, *ln2w = ln1b + D, *ln2b = ln2w + D;
     // ---- K / V of the key rows -> LDS ---------------------------------------------------------------------------
-    const int nk2_0 = 2 * ((misc[2] + 31) >> 5), nk2_1 = 2 * ((misc[3] + 31) >> 5);
+    const int nk2 = a.nk2;
     for (;;) {
       int job = 0;
-      if (lane == 0) job = atomicAdd(misc + 14, 1);
+      if (lane == 0) job = atomicAdd(queue, 1);
       job = __builtin_amdgcn_readfirstlane(job);
-      if (job >= nk2_0 + nk2_1) break;
-      const int e = job >= nk2_0, kt = job - e * nk2_0;
-      const int b = min(blockIdx.x * EPW + e, G.B - 1);
+      if (job >= epw * nk2) break;
+      int e = 0, kt = job;
+      while (kt >= nk2) { kt -= nk2; ++e; }
+      const int b = min(blockIdx.x * epw + e, G.B - 1);
       const int key = 16 * kt + tok;
-      const int row = key < misc[2 + e] ? keyrow[e * NK_MAX + key] : -1;
+      const int row = key < n_ak[e] ? keyrow[e * nkcap + key] : -1;
       f16x8 xh = {0, 0, 0, 0, 0, 0, 0, 0}, xl = xh;
       if (row >= 0) {
         const long tl = (long)b * tpe + (row >> 4);
         xh = __builtin_bit_cast(f16x8, xin[xpiece(tl, 0, 16 * g + (row & 15))]);
         xl = __builtin_bit_cast(f16x8, xin[xpiece(tl, 1, 16 * g + (row & 15))]);
       }
-      char *kv = lds + KV_OFF + e * KV_EP + lane * 16;
+      char *kv = lds + KV_OFF + e * kv_ep + lane * 16;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       {   // K^T = Wk KX^T: rows = channels, columns = keys -> the A fragment pair of key tile kt
         f32x4 y0 = z4, y1 = z4;
@@ -429,36 +459,59 @@ __global__ __launch_bounds__(THREADS) void step_kernel(StepArgs a) {
         mfma3(v, xh, xl, w.hi, w.lo);
         const float bvv = bv[16 * i + tok];
         unsigned h0, l0, h1, l1;
-        split2(v[0] * WINV + bvv, v[1] * WINV + bvv, h0, l0);
-        split2(v[2] * WINV + bvv, v[3] * WINV + bvv, h1, l1);
-        char *vp = kv + KV_V + (i * NKP_MAX + (kt >> 1)) * PAIR_BYTES + 8 * (kt & 1);
+        split2m(v[0] * WINV + bvv, v[1] * WINV + bvv, h0, l0);
+        split2m(v[2] * WINV + bvv, v[3] * WINV + bvv, h1, l1);
+        char *vp = kv + kv_v + (i * nkp + (kt >> 1)) * PAIR_BYTES + 8 * (kt & 1);
         *reinterpret_cast<u32x2 *>(vp) = (u32x2){h0, h1};
         *reinterpret_cast<u32x2 *>(vp + 1024) = (u32x2){l0, l1};
       }
     }
     S3_LAP(1);
     __syncthreads();
-    if (tid == 0) misc[14] = 0;
+    if (tid == 0) queue[0] = 0;
     S3_LAP(2);
-    // ---- token tiles ------------------------------------------------------------------------------------------------
-    const int n_heavy = min((G.P + 15) >> 4, tpe), n_light = tpe - n_heavy;     // tiles with candidate rows / target rows only
-    for (;;) {
+    // ---- token tiles: a work queue (the waves of a SIMD do not run at the same pace), the tiles with candidate rows (which
+    // may see the targets) first; the next tile's rows are requested before the current tile is computed -------------
+    const int n_heavy = min((G.P + 15) >> 4, tpe), n_light = tpe - n_heavy, n_jobs = epw * tpe;
+    auto tile_of = [&](int job, int &e, int &j) {       // (scalar: a subtract loop over <= 16 episodes instead of a division)
+      const bool heavy = job < epw * n_heavy;
+      const int per = heavy ? n_heavy : n_light;
+      int q = heavy ? job : job - epw * n_heavy;
+      e = 0;
+      while (q >= per) { q -= per; ++e; }
+      j = heavy ? q : n_heavy + q;
+    };
+    auto next_job = [&]() {
       int job = 0;
-      if (lane == 0) job = atomicAdd(misc + 15, 1);
-      job = __builtin_amdgcn_readfirstlane(job);
-      if (job >= EPW * tpe) break;
+      if (lane == 0) job = atomicAdd(queue + 1, 1);
+      return __builtin_amdgcn_readfirstlane(job);
+    };
+    auto load_rows = [&](int job, f16x8 &h, f16x8 &lo_) {
       int e, j;
-      if (job < EPW * n_heavy) { e = job / n_heavy; j = job - e * n_heavy; }
-      else { const int q = job - EPW * n_heavy; e = q / n_light; j = n_heavy + q - e * n_light; }
-      const int b = blockIdx.x * EPW + e;
+      tile_of(min(job, n_jobs - 1), e, j);
+      const long tl = (long)min(blockIdx.x * epw + e, G.B - 1) * tpe + j;
+      h = __builtin_bit_cast(f16x8, xin[xpiece(tl, 0, lane)]);
+      lo_ = __builtin_bit_cast(f16x8, xin[xpiece(tl, 1, lane)]);
+    };
+    int job = next_job();
+    f16x8 xh_next, xl_next;
+    if (PREFETCH) load_rows(job, xh_next, xl_next);
+    while (job < n_jobs) {
+      int e, j;
+      tile_of(job, e, j);
+      const int b = blockIdx.x * epw + e;
+      f16x8 xh, xl;
+      if (PREFETCH) { xh = xh_next; xl = xl_next; }
+      else load_rows(job, xh, xl);
+      job = next_job();
+      if (PREFETCH) load_rows(job, xh_next, xl_next);
       if (b >= G.B) continue;
       const long tl = (long)b * tpe + j;
       const int r = 16 * j + tok, rc = min(r, G.N - 1);
-      const f16x8 xh = __builtin_bit_cast(f16x8, xin[xpiece(tl, 0, lane)]), xl = __builtin_bit_cast(f16x8, xin[xpiece(tl, 1, lane)]);
-      const int n_ck = misc[e], n_ak = misc[2 + e];
+      const int nck = n_ck[e], nak = n_ak[e];
       const bool isq = rc < G.P && !is_ctx(G, b, rc);
       const bool hasq = 16 * j < G.P;                 // (wave-uniform) some row of the tile may see the targets
-      const int nkp = max(1, ((hasq ? n_ak : n_ck) + 31) >> 5);
+      const int nkp_t = max(1, ((hasq ? nak : nck) + 31) >> 5);
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       // Q^T = Wq X^T (pre-scaled by log2(e) / sqrt(hd))
       f16x8 qh, ql;
@@ -472,15 +525,14 @@ __global__ __launch_bounds__(THREADS) void step_kernel(StepArgs a) {
       S3_LAP(3);
       f32x4 o[2];
       {
-        const char *kv = lds + KV_OFF + e * KV_EP + lane * 16;
-        const int nv4 = (isq ? n_ak : n_ck) - 4 * g;
-        switch (nkp) {
-          case 1: attention<1>(qh, ql, kv, nv4, g, o); break;
-          case 2: attention<2>(qh, ql, kv, nv4, g, o); break;
-          case 3: attention<3>(qh, ql, kv, nv4, g, o); break;
-          case 4: attention<4>(qh, ql, kv, nv4, g, o); break;
-          default: attention<5>(qh, ql, kv, nv4, g, o); break;
-        }
+        const char *kv = lds + KV_OFF + e * kv_ep + lane * 16;
+        const int nv4 = (isq ? nak : nck) - 4 * g;
+        bool done = false;     // (the host never asks for more key tiles than the variant holds)
+        if constexpr (MAXNKP >= 5) { if (nkp_t >= 5) { attention<5, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
+        if constexpr (MAXNKP >= 4) { if (!done && nkp_t == 4) { attention<4, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
+        if constexpr (MAXNKP >= 3) { if (!done && nkp_t == 3) { attention<3, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
+        if constexpr (MAXNKP >= 2) { if (!done && nkp_t >= 2) { attention<2, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
+        if (!done) attention<1, MAXNKP>(qh, ql, kv, nv4, g, o);
       }
 #ifdef S3_STAMPS
       asm volatile("" :: "v"(o[0]), "v"(o[1]));
@@ -562,10 +614,10 @@ __global__ __launch_bounds__(THREADS) void step_kernel(StepArgs a) {
       S3_LAP(5);
     }
     __syncthreads();
-    if (tid == 0) misc[15] = 0;
+    if (tid == 0) queue[1] = 0;
     S3_LAP(6);
     if (!last) {
-      dma_copy(gimg + (long)(l + 1) * lbytes, wl, lbytes, wave, lane);
+      for (int piece = wave; piece < (lbytes >> 10); piece += NW) glds16(gimg + (long)(l + 1) * lbytes + piece * 1024 + lane * 16, wl + piece * 1024);
       wait_vmcnt<0>();
       __syncthreads();
       S3_LAP(7);

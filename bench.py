@@ -232,6 +232,30 @@ def measure_d256(args, device, batch, precision):
     return out
 
 
+def measure_alt(args, device, batch, precision):
+    """The same workload under another arithmetic mode (sub-measurement, not `value`): f32 = exact fp32 MFMA attention /
+    projections + 6-pass split-bf16 FFN, the whole rollout in one launch (fused_rollout.h)."""
+    from aline_amd.rollout import Rollout
+    import copy
+    a2 = copy.copy(args)
+    a2.precision = precision
+    model = build_model(a2, device).train()
+    ro = Rollout(model, batch, args.T, select="sample", keep_zt=False, keep_posterior=True)
+    ro.run()
+    torch.cuda.synchronize(device)
+    ro.capture()
+    ro.refresh_uniform(); ro.replay()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ro.refresh_uniform()
+        ro.replay()
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    return {"precision": precision, "path": ro.path, "ms_per_rollout": ms,
+            "value": args.batch * args.T * args.n_query / (ms * 1e-3), "unit": "designs/s"}
+
+
 def query_gmm_ms_per_rollout(args, model, device):
     """Time of posterior_out_query (model/head.py:366: the C GMM heads on the n_query candidate rows) for all T steps of a
     rollout, through the per-step entry point on encodings of the shapes the rollout sees (n_query - t candidates at step
@@ -268,7 +292,9 @@ def main():
     ap.add_argument("--d-ff", type=int, default=128)
     ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16", "bf16x3", "f16x3"],
+                    help="arithmetic of the matrix products: f16x3 (default) and f32 are the reference-precision modes")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 (fused fp32-MFMA kernel) sub-measurement (N = 1 only)")
     ap.add_argument("--graph", type=int, default=1, help="replay the rollout from one HIP graph")
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -384,8 +410,8 @@ def main():
     ev = HipEvents()
     ro.r.ev_kernel_start, ro.r.ev_kernel_stop = ev.a, ev.b
     kms = []
-    has_kernel_events = ((args.d_model == 32 and args.d_ff == 128 and args.heads == 4 and args.precision == "f32")
-                         or (args.d_model == 256 and args.heads == 8 and args.precision in ("bf16", "f16x3")))
+    path = ro.path
+    has_kernel_events = path != "generic pipeline"
     for _ in range(max(3, args.steps) if has_kernel_events else 0):
         ro.refresh_uniform()
         ro.run()
@@ -399,10 +425,10 @@ def main():
     kernel_ms = sum(kms) / len(kms) if kms else 0.0
     fl_ep = algorithmic_flops_per_episode(2, 1, args.d_model, args.d_ff, args.heads, args.layers, 10,
                                           1, args.n_query, 0, 2, 2, args.T, with_query_gmm=False)
-    fused = (args.d_model == 32 and args.d_ff == 128 and args.heads == 4 and args.precision == "f32"
-             and kernel_ms > 0.0)
-    wide = args.d_model == 256 and args.heads == 8 and args.precision == "bf16" and kernel_ms > 0.0
-    x3 = args.d_model == 256 and args.heads == 8 and args.precision == "f16x3" and kernel_ms > 0.0
+    fused = path == "fused::rollout_f32_kernel" and kernel_ms > 0.0
+    wide = path == "wide::wide_step_kernel" and kernel_ms > 0.0
+    x3 = path == "x3::layer_kernel" and kernel_ms > 0.0
+    s3 = path == "s3::step_kernel" and kernel_ms > 0.0
     extra = {}
     if fused:
         fl_k = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
@@ -470,6 +496,30 @@ def main():
                  "peak_note": "dense f16 MFMA peak (MI355X_MICROARCH.md).  Every product is a 3-term f16 split (reference "
                               "precision), i.e. 3 MFMA passes per algorithmic multiply-add: the pipe can deliver at most "
                               "peak / 3 in this mode (instruction_mix_peak); frac_vs_instruction_mix_peak = matrix-pipe utilisation"}
+    elif s3:
+        # dominant kernel of the s3 path: s3::step_kernel -- one launch = every encoder layer + the acquisition logits of ONE
+        # design step for all B episodes (T launches per rollout); the events bracket the launch of the last step
+        fl_all = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
+        fl_last = fl_all - fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2,
+                                                          args.T - 1)
+        per_launch = fl_last * args.batch
+        achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
+        kname, peak, traffic = "s3::step_kernel<128, 16, 2, true>", PEAK_BF16_DENSE_TFLOPS, None
+        extra = {"launches_per_rollout": args.T, "mfma_passes_per_product": 3,
+                 "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / 3,
+                 "frac_vs_instruction_mix_peak": achieved_tflops * 3 / PEAK_BF16_DENSE_TFLOPS,
+                 "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
+                 "limiting_resource": "vector issue, not the matrix pipe: at d = 32 a token tile needs ~900 vector instructions per "
+                                      "layer (f16 hi/lo splits of every activation, LayerNorm, softmax) beside ~100 MFMAs; PMC of "
+                                      "this launch (profiles/r02_s3_f16x3_d32_pmc_summary.txt): VALU busy 67 %, matrix pipe busy 28 %",
+                 "peak_note": "dense f16 MFMA peak (MI355X_MICROARCH.md).  Every product is a 3-term f16 split (reference "
+                              "precision): the pipe can deliver at most peak / 3 in this mode (instruction_mix_peak)"}
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_s3_f16x3_d32_pmc_traffic.json")))
+            traffic = tr["hbm_bytes_per_launch"] if args.batch == 1000 and args.T == 30 else None
+            extra["traffic_source"] = "rocprofv3 PMC (profiles/r02_s3_f16x3_d32_pmc_traffic.json), not re-measured in this run"
+        except Exception:
+            traffic = None
     else:   # generic pipeline: many kernels per step; report the whole graph as a lower bound
         achieved_tflops = fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12
         kname, per_launch, kernel_ms = "whole rollout graph (generic pipeline, all kernels)", fl_ep * args.batch, dev_ms / args.steps
@@ -490,7 +540,8 @@ def main():
                    "n_tokens": 1 + args.n_query + 2, "d_model": args.d_model, "d_ff": args.d_ff,
                    "heads": args.heads, "layers": args.layers, "components": 10,
                    "posterior_out_query": "lazy (not computed; same in the CPU baseline)",
-                   "hip_graph": bool(args.graph), "exact_designs_per_rollout": exact,
+                   "hip_graph": bool(args.graph), "exact_designs_per_rollout": exact, "path": path,
+                   "precision": args.precision,
                    "parallelism": f"episode-dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved_tflops / peak, "traffic": traffic, "kernel": kname,
@@ -500,7 +551,7 @@ def main():
                      **extra},
     }
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms per rollout")
-    if args.train_steps > 0 and args.precision == "f32":
+    if args.train_steps > 0 and args.precision in ("f32", "f16x3"):
         # secondary measurement (not `value`): one optimiser step of train_aline.py:55-152 -- sampled
         # rollout, REINFORCE terms, native backward of all T steps, ONE flat-bucket RCCL all-reduce of the
         # gradients (N > 1), inf-norm clipping, AdamW.
@@ -521,7 +572,7 @@ def main():
             tdt = float(tt.item())
         out["train_step"] = {"value": world * designs_per_rollout * args.train_steps / tdt, "unit": "designs/s",
                              "ms_per_step": tdt / args.train_steps * 1e3, "steps": args.train_steps,
-                             "includes": "fused forward rollout + generic fp32 backward of all T steps + "
+                             "includes": f"forward rollout ({path}) + generic fp32 backward of all T steps + "
                                          "flat-bucket gradient all-reduce (N>1) + inf-norm clip + AdamW",
                              "collective": "1 all-reduce / optimiser step" if world > 1 else "none (N=1)",
                              "rccl_allreduce_calls": train_mod.ALLREDUCE_CALLS - ar0,
@@ -539,6 +590,9 @@ def main():
                                     "is `value` with the C GMM heads evaluated on the candidate rows at all T steps through the "
                                     "per-step entry point, on encodings of the rollout's shapes (SURVEY 8-d: with and without)"}
         log(f"query GMM of all T steps: {qms:.2f} ms")
+    if world == 1 and not args.no_f32 and args.precision != "f32" and args.d_model == 32:
+        out["f32"] = measure_alt(args, device, batch, "f32")
+        log(f"f32 [{out['f32']['path']}]: {out['f32']['ms_per_rollout']:.2f} ms per rollout")
     if world == 1 and not args.no_d256 and args.d_model != 256:
         out["d256"] = {}
         for prec in ("f16x3", "bf16"):

@@ -6,7 +6,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 #   tools/pmc_all.sh x3    -> x3::layer_kernel            (--d-model 256 --d-ff 1024 --heads 8 --precision f16x3)
 if [ "$1" = "d256" ]; then ARGS="--d-model 256 --d-ff 1024 --heads 8 --precision bf16";
-elif [ "$1" = "x3" ]; then ARGS="--d-model 256 --d-ff 1024 --heads 8 --precision f16x3"; else ARGS=""; fi
+elif [ "$1" = "x3" ]; then ARGS="--d-model 256 --d-ff 1024 --heads 8 --precision f16x3";
+#   tools/pmc_all.sh s3    -> s3::step_kernel             (--precision f16x3: the headline shape at reference precision on the f16 pipe)
+elif [ "$1" = "s3" ]; then ARGS="--precision f16x3"; else ARGS=""; fi
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" \

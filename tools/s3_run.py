@@ -1,0 +1,27 @@
+"""One eager rollout of the s3 path at the cfg2 (headline) or cfg3 shape: a minimal target for rocprofv3 --pmc passes.
+    python tools/s3_run.py [2|3] [T]"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from aline_amd import Aline, Embedder, Encoder, OutputHead
+from aline_amd.rollout import Rollout
+from aline_amd.tasks import GPTask, HiddenLocation
+from aline_amd.utils import create_target_mask
+torch.manual_seed(0)
+dev = torch.device("cuda")
+cfg = sys.argv[1] if len(sys.argv) > 1 else "2"
+if cfg == "3":
+    m = Aline(Embedder(2, 1, 32, 128, 3, "mix"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128))
+    batch = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=200, n_target_theta=3, n_target_data=100, device=dev).sample_batch(512)
+    batch["target_mask"] = create_target_mask("split", "mix", 100, 3, None, None, None, None, "data")
+    T = 50
+else:
+    m = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128))
+    batch = HiddenLocation(n_query_init=200, device=dev).sample_batch(1000)
+    T = 30
+T = int(sys.argv[2]) if len(sys.argv) > 2 else T
+m = m.cuda().set_precision("f16x3").train()
+ro = Rollout(m, batch, T, select="sample", keep_posterior=True)
+assert ro.path == "s3::step_kernel", ro.path
+ro.run(); torch.cuda.synchronize()
+ro.refresh_uniform(); ro.run(); torch.cuda.synchronize()
+print("ok", float(ro.target_ll.mean()))
