@@ -24,6 +24,8 @@ using wide::group_sum4;
 using wide::u32x2;
 using wide::u32x4;
 using x3::f16x8;
+using x3::frag_value;
+using x3::split_frag;
 using x3::glds16;
 using x3::group_max4;
 using x3::mfma3;
@@ -65,42 +67,6 @@ __host__ __device__ inline int kv_ep_bytes(int nkp) { return nkp * 8192; }
 __host__ __device__ inline int step_lds_bytes(int epw, int nkp) { return KV_OFF + epw * (kv_ep_bytes(nkp) + 32 * nkp * 4) + MISC_INTS * 4; }
 constexpr int LDS_LIMIT = 160 * 1024;
 static_assert(KV_OFF + (NKT_MAX * 4096 + NK_MAX * 4) * 2 + MISC_INTS * 4 <= LDS_LIMIT, "two episodes of 160 keys must fit");
-
-// (a, b) -> packed f16 hi halves, packed f16 lo halves (a - hi, b - hi: exact in fp32, then rounded).  The residuals are
-// one v_fma_mix_f32 each (f16 source operand read straight out of the packed register): 4 instructions per pair.
-__device__ __forceinline__ void split2m(float a, float b, unsigned &hi, unsigned &lo) {
-  const x3::f32x2 v = {a, b};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x3::f16x2));
-  float r0, r1;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(a));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(b));
-  const x3::f32x2 r = {r0, r1};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x3::f16x2));
-}
-// the fp32 values a fragment pair stands for, elements 4 hf .. 4 hf + 3: hi + lo, one v_fma_mix_f32 each (both f16
-// operands read straight out of the packed registers)
-__device__ __forceinline__ f32x4 frag_value(const f16x8 &hi, const f16x8 &lo, int hf) {
-  const u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
-  f32x4 v;
-#pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    float a, b;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(h[2 * hf + w]), "v"(l[2 * hf + w]));
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(b) : "v"(h[2 * hf + w]), "v"(l[2 * hf + w]));
-    v[2 * w] = a; v[2 * w + 1] = b;
-  }
-  return v;
-}
-// two accumulator tiles (features 16 m + 4 g + r, 16 (m + 1) + 4 g + r) -> the hi / lo B fragments of their k-step
-__device__ __forceinline__ void split_frag(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo) {
-  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-  split2m(a[0], a[1], h0, l0);
-  split2m(a[2], a[3], h1, l1);
-  split2m(b[0], b[1], h2, l2);
-  split2m(b[2], b[3], h3, l3);
-  hi = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});
-  lo = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});
-}
 
 // ---- weights -> fragment pairs -----------------------------------------------------------------------------------
 struct PackArgs {
@@ -459,8 +425,8 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         mfma3(v, xh, xl, w.hi, w.lo);
         const float bvv = bv[16 * i + tok];
         unsigned h0, l0, h1, l1;
-        split2m(v[0] * WINV + bvv, v[1] * WINV + bvv, h0, l0);
-        split2m(v[2] * WINV + bvv, v[3] * WINV + bvv, h1, l1);
+        split2(v[0] * WINV + bvv, v[1] * WINV + bvv, h0, l0);
+        split2(v[2] * WINV + bvv, v[3] * WINV + bvv, h1, l1);
         char *vp = kv + kv_v + (i * nkp + (kt >> 1)) * PAIR_BYTES + 8 * (kt & 1);
         *reinterpret_cast<u32x2 *>(vp) = (u32x2){h0, h1};
         *reinterpret_cast<u32x2 *>(vp + 1024) = (u32x2){l0, l1};

@@ -51,15 +51,17 @@ __device__ __forceinline__ void mfma3(f32x4 &acc, const f16x8 &ah, const f16x8 &
   XMFMA(acc, ah, bh);
 }
 
-// (a, b) -> packed hi halves, packed lo halves (round to nearest even both times)
+// (a, b) -> packed f16 hi halves, packed f16 lo halves (a - hi, b - hi: exact in fp32, then rounded; round to nearest
+// even both times).  The residuals are one v_fma_mix_f32 each (its f16 operand read straight out of the packed register):
+// 4 instructions per pair instead of the 6 of convert-back-and-subtract.
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
   const f32x2 v = {a, b};
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  const f32x2 hf = __builtin_convertvector(h, f32x2);
-  const f32x2 r = {a - hf[0], b - hf[1]};
-  const f16x2 l = __builtin_convertvector(r, f16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(b));
+  const f32x2 r = {r0, r1};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 // two accumulator tiles (features 16 m + 4 g + r, 16 (m+1) + 4 g + r) -> the hi / lo B fragments of their k-step
 __device__ __forceinline__ void split_frag(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo) {
@@ -71,11 +73,18 @@ __device__ __forceinline__ void split_frag(const f32x4 &a, const f32x4 &b, f16x8
   hi = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});
   lo = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});
 }
-// the fp32 values a fragment pair stands for: elements 4 hf .. 4 hf + 3
+// the fp32 values a fragment pair stands for, elements 4 hf .. 4 hf + 3: hi + lo, one v_fma_mix_f32 each (both f16
+// operands read straight out of the packed registers)
 __device__ __forceinline__ f32x4 frag_value(const f16x8 &hi, const f16x8 &lo, int hf) {
+  const u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
   f32x4 v;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = (float)hi[4 * hf + r] + (float)lo[4 * hf + r];
+  for (int w = 0; w < 2; ++w) {
+    float a, b;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(h[2 * hf + w]), "v"(l[2 * hf + w]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(b) : "v"(h[2 * hf + w]), "v"(l[2 * hf + w]));
+    v[2 * w] = a; v[2 * w + 1] = b;
+  }
   return v;
 }
 __device__ __forceinline__ float group_max4(float v) {
@@ -466,7 +475,7 @@ __device__ __forceinline__ void layer_norm(f32x4 (&v)[NMT], const float *lw, con
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[mt][r] -= mean; q = fmaf(v[mt][r], v[mt][r], q); }
-  const float rstd = 1.f / sqrtf(group_sum4(q) * (1.f / D) + 1e-5f);
+  const float rstd = __builtin_amdgcn_rsqf(group_sum4(q) * (1.f / D) + 1e-5f);     // (v_rsq_f32: 1 ulp)
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
     const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + 16 * mt + 4 * g), bv = *reinterpret_cast<const f32x4 *>(lb + 16 * mt + 4 * g);
@@ -595,7 +604,7 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], c
         s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
         sum += s[kt][r];
       }
-    const float inv = 1.f / group_sum4(sum);
+    const float inv = __builtin_amdgcn_rcpf(group_sum4(sum));                          // (v_rcp_f32: 1 ulp)
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 o0 = z4, o1 = z4;
 #pragma unroll

@@ -511,7 +511,7 @@ def main():
                  "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
                  "limiting_resource": "vector issue, not the matrix pipe: at d = 32 a token tile needs ~900 vector instructions per "
                                       "layer (f16 hi/lo splits of every activation, LayerNorm, softmax) beside ~100 MFMAs; PMC of "
-                                      "this launch (profiles/r02_s3_f16x3_d32_pmc_summary.txt): VALU busy 67 %, matrix pipe busy 28 %",
+                                      "this launch (profiles/r02_s3_f16x3_d32_pmc_summary.txt): VALU busy 67 %, matrix pipe busy 31 %",
                  "peak_note": "dense f16 MFMA peak (MI355X_MICROARCH.md).  Every product is a 3-term f16 split (reference "
                               "precision): the pipe can deliver at most peak / 3 in this mode (instruction_mix_peak)"}
         try:
