@@ -18,14 +18,14 @@ DIMS = {"dim_x": 2, "dim_y": 1, "d": 256, "F": 1024, "n_head": 8, "L": 2, "C": 1
         "embedding_type": "theta", "time_token": False}
 
 
-def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None):
+def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, dims=None, full=False):
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
     for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     try:
-        model, _ = native_model(DIMS, 11, prec)
+        model, _ = native_model(dims or DIMS, 11, prec)
         torch.manual_seed(seed)
         task = HiddenLocation(device=torch.device("cuda"), n_query_init=n_query)
         batch = task.sample_batch(B)
@@ -36,6 +36,8 @@ def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None):
                               for _ in range(B)]).to("cuda")     # index into the queries remaining at step t
         ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None).run()
         torch.cuda.synchronize()
+        if full:
+            return {k: getattr(ro, k).float().cpu().clone() for k in ("target_ll", "log_prob", "post_mean", "post_std", "post_weight")}
         return ro.target_ll.float().cpu().clone(), ro.log_prob.float().cpu().clone(), ro.idx.cpu().clone()
     finally:
         for k in env:
@@ -121,3 +123,24 @@ def test_block_kernels_cross_check():
     ll_b2, lp_b2, _ = _run("bf16", {"ALINE_WIDE_BLOCKS": "1"}, 3, 200, 6)
     assert (ll_s - ll_b).abs().max() < 0.1 and (lp_s - lp_b).abs().max() < 5e-2
     assert torch.equal(ll_b, ll_b2) and torch.equal(lp_b, lp_b2)
+
+
+@pytest.mark.parametrize("C", [10, 16])
+def test_wide_posterior_rows_are_the_right_rows(C):
+    """Structure-sensitive check of the GMM stage (the absolute bf16 bounds above would let an indexing slip through):
+    per component, the posterior parameters of the wide path follow those of the fp32 pipeline row by row -- a
+    misplaced row or component (e.g. a raw-output stride too small for C = 16: 48 floats per row) destroys the
+    correlation, bf16 rounding does not -- and the mixture weights of every row still sum to one."""
+    dims = dict(DIMS, C=C)
+    w = _run("bf16", {}, 3, 60, 4, dims=dims, full=True)
+    f = _run("f32", {}, 3, 60, 4, dims=dims, full=True)
+    assert w["post_mean"].shape[-1] == C
+    assert (w["post_weight"].sum(-1) - 1).abs().max() < 1e-5
+    assert (w["post_std"] > 0).all()
+    for k in ("post_mean", "post_std", "post_weight"):
+        a, b = w[k].reshape(-1, C), f[k].reshape(-1, C)
+        for c in range(C):
+            corr = torch.corrcoef(torch.stack([a[:, c], b[:, c]]))[0, 1]
+            assert corr > 0.98, (k, c, float(corr))
+        rel = (a - b).abs().median() / b.abs().median()
+        assert rel < 0.05, (k, float(rel))
