@@ -149,3 +149,44 @@ def test_error_codes_before_any_launch(lib):
     assert L.aline_rollout_forward(byref(m), byref(r), ws, 1 << 40, None) == -1
     assert L.aline_eig_finalize(0x1000, 1, 4, None, None, ws, 1 << 20, None) == -1  # needs L >= 1
     assert L.aline_cholesky_upper(None, 4, 1, None, None) == -1
+
+
+def test_rollout_path_selection_is_pure_host(lib):
+    """aline_rollout_path: which implementation aline_rollout_forward takes -- host logic only, so the dispatch rules
+     are testable without a GPU."""
+    from aline_amd import _lib
+    L = _lib.lib
+    byref = ctypes.byref
+    GENERIC, FUSED, WIDE, X3, S3 = 0, 1, 2, 3, 4
+
+    def rollout(B=1000, P=201, n_ctx0=1, n_td=0, T=30):
+        r = _lib.AlineRollout()
+        r.B, r.P, r.n_ctx0, r.n_target_data, r.T = B, P, n_ctx0, n_td, T
+        return r
+
+    m = _small_model()                                      # d = 32, F = 128, 4 heads, theta mode
+    m.precision = _lib.PREC["f32"]
+    assert L.aline_rollout_path(byref(m), byref(rollout())) == FUSED          # round 1's exact-fp32 kernel
+    m.precision = _lib.PREC["f16x3"]
+    assert L.aline_rollout_path(byref(m), byref(rollout())) == S3             # the benchmarked path
+    assert L.aline_rollout_path(byref(m), byref(rollout(T=160))) == GENERIC   # 1 + 159 + 2 keys > 160
+    m.n_theta, m.embedding_type = 3, 2                                       # mix mode (cfg3): 1 + 49 + 103 keys
+    assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == S3
+    m.precision = _lib.PREC["f32"]
+    assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == GENERIC    # fused kernel: theta mode only
+    m.precision = _lib.PREC["f16x3"]
+    m.time_token = 1
+    assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == GENERIC
+    m.time_token = 0
+    m.H = 8                                                                   # head_dim 4: not an s3 shape
+    assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == GENERIC
+    w = _small_model()
+    w.d, w.F, w.H = 256, 1024, 8
+    w.precision = _lib.PREC["f16x3"]
+    assert L.aline_rollout_path(byref(w), byref(rollout())) == X3
+    w.precision = _lib.PREC["bf16"]
+    assert L.aline_rollout_path(byref(w), byref(rollout())) == WIDE
+    assert L.aline_rollout_path(byref(w), byref(rollout(T=70))) == GENERIC    # 72 keys > 64
+    w.d = 48
+    assert L.aline_rollout_path(byref(w), byref(rollout())) == -2             # ALINE_EUNSUPPORTED, as the forward would say
+    assert L.aline_rollout_path(None, byref(rollout())) == -1
