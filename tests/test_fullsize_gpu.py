@@ -93,3 +93,61 @@ def test_partial_workgroup_and_small_batches():
         fu = _rollout(model, batch, 5, True, select="argmax")
         ge = _rollout(model, batch, 5, False, select="forced", forced_idx=fu.idx)
         assert float((ge.target_ll - fu.target_ll).abs().max()) < 1e-4
+
+
+def test_fullsize_s3_headline_matches_exact_fp32_kernel():
+    """The benchmarked path (precision f16x3 -> s3::step_kernel, 3-term f16 split) against round 1's exact-fp32 fused
+    kernel on all 1000 episodes x 30 steps of the headline config, teacher-forced with the designs s3 picked."""
+    B, T, nq = 1000, 30, 200
+    model, batch = _model_and_batch(B, nq)
+    model.eval()
+    model.set_precision("f16x3")
+    s3 = _rollout(model, batch, T, True, select="argmax", keep_zt=True)
+    assert s3.path == "s3::step_kernel"
+    role = s3.role.cpu()
+    assert (role > 0).sum(1).eq(1 + T).all()
+    zt = s3.zt.cpu()
+    assert torch.allclose(zt.sum(-1), torch.ones(T, B), atol=1e-5)
+    model.set_precision("f32")
+    fu = _rollout(model, batch, T, True, select="forced", forced_idx=s3.idx, keep_zt=True)
+    assert fu.path == "fused::rollout_f32_kernel"
+    assert float((fu.target_ll - s3.target_ll).abs().max()) < 1e-4    # NLL bound of the north star, every target
+    assert float((fu.log_prob - s3.log_prob).abs().max()) < 2e-4
+    assert float((fu.zt - s3.zt).abs().max()) < 5e-5
+    assert (fu.slot == s3.slot).all()
+    free = _rollout(model, batch, T, True, select="argmax")
+    assert float((free.idx == s3.idx).float().mean()) > 0.98          # (fp-order ties excepted)
+
+
+def test_fullsize_cfg3_s3_matches_generic_fp32():
+    """BASELINE configs[2] per GPU (al_mix dx = 2, B = 512 of 4096, T = 50, n_query = 200, 100 data + 3 theta targets,
+    split mask on the data targets: up to 150 keys, 304 token rows): s3 against the generic exact-fp32 pipeline."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import GPTask
+    from aline_amd.utils import create_target_mask
+    B, T, nq = 512, 50, 200
+    torch.manual_seed(2)
+    model = Aline(Embedder(2, 1, 32, 128, 3, "mix"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda().eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    task = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=nq, n_target_theta=3, n_target_data=100,
+                  device=torch.device("cuda"))
+    batch = task.sample_batch(B)
+    batch["target_mask"] = create_target_mask("split", "mix", 100, 3, None, None, None, None, "data")
+    model.set_precision("f16x3")
+    s3 = Rollout(model, batch, T, select="argmax", keep_zt=True)
+    assert s3.path == "s3::step_kernel"
+    s3.run()
+    model.set_precision("f32")
+    ge = Rollout(model, batch, T, select="forced", forced_idx=s3.idx, keep_zt=True)
+    assert ge.path == "generic pipeline"
+    ge.run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(s3.target_ll).all()
+    assert (s3.role.cpu() > 0).sum(1).eq(1 + T).all()
+    d = (ge.target_ll - s3.target_ll).abs()
+    assert float(d.mean(-1).max()) < 1e-4 and float(d.max()) < 5e-4, (float(d.mean(-1).max()), float(d.max()))
+    assert float((ge.log_prob - s3.log_prob).abs().max()) < 2e-4
+    assert (ge.slot == s3.slot).all()
