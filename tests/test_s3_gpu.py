@@ -92,6 +92,8 @@ def close(a, b):
     ("data", 3, 50, 6, {"n_td": 30}),                       # data mode: no theta tokens
     ("mix", 2, 40, 4, {"n_td": 20, "F": 64, "L": 2, "C": 3}),   # narrower FFN, fewer layers / components
     ("mix", 2, 40, 4, {"n_td": 20, "F": 32, "L": 1, "C": 16}),
+    ("mix", 2, 40, 4, {"n_td": 20, "F": 96, "C": 16}),          # the largest GMM stage: 16 heads x 3 outputs x 512 rows in LDS
+    ("theta", 1, 700, 3, {}),                                   # one episode of 703 rows (44 tiles) in a workgroup
     ("mix", 3, 60, 30, {"n_td": 100, "n_ctx": 5}),   # 138 keys at the last step
 ])
 def test_s3_matches_fp32_pipeline(emb, B, n_query, T, kw):
