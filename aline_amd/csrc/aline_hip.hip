@@ -37,7 +37,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sRaw, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sRaw, KeyIdx, Kcnt, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -66,6 +66,8 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   p.QKV = take(M * 3 * d);
   p.A = take(M * d);
   p.Tm = take(M * d);
+  p.KeyIdx = take(M);              // key rows of every episode (generic pipeline: K / V projections on these rows only)
+  p.Kcnt = take((size_t)B * 2);
   p.Wacq = take(F * d);
   p.scalar = take(64);
   p.Wpack = take((size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS +
@@ -196,7 +198,7 @@ int do_assemble(const Ctx &c, int ey_rows, float *X) {
 }
 
 template <int HD>
-int launch_attention(const Ctx &c, const float *qkv, float *out, int max_keys) {
+int launch_attention(const Ctx &c, const float *qkv, float *out, int max_keys, const float *kvc = nullptr, const int *kcnt = nullptr) {
   size_t smem = (size_t)max_keys * (2 * HD * sizeof(float) + sizeof(int));
   if (smem > 160 * 1024 - 1024) return ALINE_EUNSUPPORTED;
   if (smem > 48 * 1024)
@@ -204,7 +206,7 @@ int launch_attention(const Ctx &c, const float *qkv, float *out, int max_keys) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const unsigned nthr = (unsigned)std::min(512, std::max(256, (c.g.N + 63) / 64 * 64));   // one token row per thread when N <= 512
   hipLaunchKernelGGL(attention_kernel<HD>, dim3((unsigned)((c.g.B + 7) / 8 * 8 * c.m->H)), dim3(nthr), smem, c.st, c.g, c.m->d,
-                     qkv, out, max_keys);
+                     qkv, out, max_keys, kvc, kcnt);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -252,17 +254,37 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::layer_tail_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fused::LAYER_FLOATS * sizeof(float)));
   }
-  for (int l = 0; l < m.L; ++l) {
-    TRY(launch_gemm(m.precision, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, 3 * d, M,
-                                           3 * d, d, false), 1, c.st));
+  // Q for every token row, K / V for the key rows only (context points + visible targets: max_keys of the N rows of an
+  // episode, e.g. 34 of 205 at cfg5): the key list is the same for all layers of a step
+  const bool compact_kv = max_keys < c.g.N && !getenv("ALINE_FULL_QKV");
+  int *keyidx = reinterpret_cast<int *>(c.at(c.pl.KeyIdx)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.Kcnt));
+  float *KVc = QKV + (size_t)M * d;
+  const int Mk = c.g.B * max_keys;
+  if (compact_kv) {
+    hipLaunchKernelGGL(key_list_kernel, dim3(c.g.B), dim3(256), 0, c.st, c.g, max_keys, keyidx, kcnt);
     CHECK_LAUNCH();
+  }
+  for (int l = 0; l < m.L; ++l) {
+    if (compact_kv) {
+      TRY(launch_gemm(m.precision, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, d, M, d, d, false), 1, c.st));
+      CHECK_LAUNCH();
+      GemmArgs ka = gemm_args(cur, d, m.in_proj_w[l] + (size_t)d * d, m.in_proj_b[l] + d, d, KVc, 2 * d, Mk, 2 * d, d, false);
+      ka.row_index = keyidx;
+      TRY(launch_gemm(m.precision, ka, 1, c.st));
+      CHECK_LAUNCH();
+    } else {
+      TRY(launch_gemm(m.precision, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, 3 * d, M,
+                                             3 * d, d, false), 1, c.st));
+      CHECK_LAUNCH();
+    }
+    const float *kvc = compact_kv ? KVc : nullptr;
     switch (hd) {
-      case 4: TRY(launch_attention<4>(c, QKV, A, max_keys)); break;
-      case 8: TRY(launch_attention<8>(c, QKV, A, max_keys)); break;
-      case 16: TRY(launch_attention<16>(c, QKV, A, max_keys)); break;
-      case 32: TRY(launch_attention<32>(c, QKV, A, max_keys)); break;
-      case 64: TRY(launch_attention<64>(c, QKV, A, max_keys)); break;
-      case 128: TRY(launch_attention<128>(c, QKV, A, max_keys)); break;
+      case 4: TRY(launch_attention<4>(c, QKV, A, max_keys, kvc, kcnt)); break;
+      case 8: TRY(launch_attention<8>(c, QKV, A, max_keys, kvc, kcnt)); break;
+      case 16: TRY(launch_attention<16>(c, QKV, A, max_keys, kvc, kcnt)); break;
+      case 32: TRY(launch_attention<32>(c, QKV, A, max_keys, kvc, kcnt)); break;
+      case 64: TRY(launch_attention<64>(c, QKV, A, max_keys, kvc, kcnt)); break;
+      case 128: TRY(launch_attention<128>(c, QKV, A, max_keys, kvc, kcnt)); break;
       default: return ALINE_EUNSUPPORTED;
     }
     if (tail) {

@@ -22,6 +22,7 @@
 
 struct GemmArgs {
   const float *X; int ldx; int R_in, G_in, off_in;
+  const int *row_index;            // optional gather: GEMM row m reads X row row_index[m] (< 0: a zero row)
   const float *W[GEMM_MAX_GROUPS]; const float *bias[GEMM_MAX_GROUPS]; int ldw;
   float *Y; int ldy; int R_out, G_out, off_out; int col_per_group;
   int M, N, K; int relu; int accum;   // accum: Y += result
@@ -121,6 +122,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     aok[i] = m < a.M;
     int mm = aok[i] ? m : 0;
     long src = (long)(mm / a.R_in) * a.G_in + a.off_in + (mm % a.R_in);
+    if (a.row_index) {
+      const int ri = a.row_index[mm];
+      aok[i] = aok[i] && ri >= 0;
+      src = ri >= 0 ? ri : 0;
+    }
     arow[i] = a.X + src * a.ldx + (idx & 7) * 4;
   }
 

@@ -70,13 +70,54 @@ __global__ void assemble_kernel(Geo g, int d, const float *__restrict__ Ex, cons
   X[i] = v;
 }
 
+// ---- key rows of every episode (model/encoder.py:83-126): context points in slot order, then the visible targets.
+// keyidx[b * max_keys + j] = global token row (b * N + row) of key j, -1 beyond the episode's keys; kcnt[2 b] = context
+// keys, kcnt[2 b + 1] = all keys.  The K / V projections of the generic pipeline run on these rows only.
+__global__ __launch_bounds__(256) void key_list_kernel(Geo g, int max_keys, int *__restrict__ keyidx, int *__restrict__ kcnt) {
+  __shared__ int wave_cnt[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int *list = keyidx + (long)b * max_keys;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < g.P; c0 += 256) {
+    const int row = c0 + tid;
+    const bool key = row < g.P && is_ctx(g, b, row);
+    const unsigned long long bal = __ballot(key);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+    if (key && k < max_keys) list[k] = b * g.N + row;
+    __syncthreads();
+    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  __shared__ int s_all;
+  if (tid == 0) {
+    int n = min(s_base, max_keys);
+    kcnt[2 * b] = n;
+    const int n_t = g.n_td + g.n_th;
+    for (int j = 0; j < n_t; ++j)
+      if ((!g.tmask || g.tmask[j]) && n < max_keys) list[n++] = b * g.N + g.P + j;
+    kcnt[2 * b + 1] = n;
+    s_all = n;
+  }
+  __syncthreads();
+  for (int j = s_all + tid; j < max_keys; j += 256) list[j] = -1;
+}
+
 // ---- G2-G4: masked set-attention (model/encoder.py:8-46 and :83-126 without materialising the
 // [N, N] mask).  Keys = context rows, plus (for query rows only) the selected target rows.
 // One workgroup per (episode, head): K_h, V_h of the key rows are staged in LDS once, every
 // thread then owns token rows and runs an online softmax over the keys.
 template <int HD>
 __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const float *__restrict__ QKV,
-                                                        float *__restrict__ Aout, int max_keys) {
+                                                        float *__restrict__ Aout, int max_keys,
+                                                        const float *__restrict__ KVc = nullptr, const int *__restrict__ kcnt = nullptr) {
+  // KVc != null: Q rows are [M, d] at QKV, K | V of the key rows only are [B * max_keys, 2 d] at KVc in key-list order
+  // with the counts in kcnt (key_list_kernel) -- no compaction here
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *Ks = reinterpret_cast<float *>(smem_raw);          // [max_keys][HD]
   float *Vs = Ks + (size_t)max_keys * HD;                   // [max_keys][HD]
@@ -89,10 +130,11 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
   if (b >= g.B) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   const int n_t = g.n_td + g.n_th;
+  const int qld = KVc ? d : 3 * d;
   // ordered compaction of the key rows: context points in slot order, then selected targets
-  if (tid == 0) s_base = 0;
+  if (tid == 0) s_base = KVc ? kcnt[2 * b] : 0;
   __syncthreads();
-  for (int c0 = 0; c0 < g.N; c0 += nthr) {
+  for (int c0 = 0; c0 < (KVc ? 0 : g.N); c0 += nthr) {
     int row = c0 + tid;
     bool key = false;
     if (row < g.P) key = is_ctx(g, b, row);
@@ -110,8 +152,10 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
   __syncthreads();
   if (tid == 0) {
     int n = n_ck;
-    for (int j = 0; j < n_t; ++j)
-      if (!g.tmask || g.tmask[j]) keyrow[n++] = g.P + j;
+    if (KVc) n = kcnt[2 * b + 1];
+    else
+      for (int j = 0; j < n_t; ++j)
+        if (!g.tmask || g.tmask[j]) keyrow[n++] = g.P + j;
     s_base = n;
   }
   __syncthreads();
@@ -119,9 +163,15 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
   const long ep = (long)b * g.N;
   for (int i = tid; i < n_ak * HD; i += nthr) {
     int j = i / HD, c = i % HD;
-    const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
-    Ks[j * HD + c] = src[d];
-    Vs[j * HD + c] = src[2 * d];
+    if (KVc) {
+      const float *src = KVc + ((long)b * max_keys + j) * 2 * d + h * HD + c;
+      Ks[j * HD + c] = src[0];
+      Vs[j * HD + c] = src[d];
+    } else {
+      const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
+      Ks[j * HD + c] = src[d];
+      Vs[j * HD + c] = src[2 * d];
+    }
   }
   __syncthreads();
   const float scale = rsqrtf((float)HD) * 1.44269504088896340736f;   // 1/sqrt(hd) * log2(e)
@@ -129,7 +179,7 @@ __global__ __launch_bounds__(512) void attention_kernel(Geo g, int d, const floa
     const bool isq = row < g.P && !is_ctx(g, b, row);
     const int nk = isq ? n_ak : n_ck;
     float q[HD], o[HD];
-    const float *qp = QKV + (ep + row) * 3 * d + h * HD;
+    const float *qp = QKV + (ep + row) * qld + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {            // rows are 16-byte aligned (d, HD multiples of 4)
       const float4 qv = *reinterpret_cast<const float4 *>(qp + c);
