@@ -67,7 +67,7 @@ class AlineRollout(C.Structure):
         + [(n, _fp) for n in ("uniform", "forced_idx")]
         + [("time_token_T", C.c_int32)]
         + [(n, _fp) for n in ("idx", "slot", "log_prob", "target_ll", "zt", "post_mean", "post_std",
-                              "post_weight", "ev_kernel_start", "ev_kernel_stop")]
+                              "post_weight", "ev_kernel_start", "ev_kernel_stop", "postq_mean", "postq_std", "postq_weight")]
     )
 
 
@@ -115,7 +115,7 @@ def _load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.aline_abi_version() != 1:
+    if lib.aline_abi_version() != 2:
         raise RuntimeError("aline_amd: libaline_hip.so ABI version mismatch")
     return lib, sig
 

@@ -37,7 +37,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sRaw, KeyIdx, Kcnt, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -100,6 +100,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
     p.sX0 = take(img); p.sXW = take(img);
     p.sLog = take((size_t)B * tpe * 16);
     p.sZimg = take((size_t)s3::img_pieces(((long)T * B * n_t + 15) / 16) * 4);
+    p.sZq = take(query_gmm ? (size_t)s3::img_pieces(((long)T * B * P + 15) / 16) * 4 : 0);     // candidate rows of all steps (posterior_out_query)
     p.sRaw = take(1024);     // (diagnostic stamps of the S3_STAMPS build)
   }
   p.total = off;
@@ -675,6 +676,8 @@ int aline_step_forward(const aline_model *m, const aline_step *s, void *ws, size
 }
 
 // ---- rollout (static slots) --------------------------------------------------------------------
+static bool wants_postq(const aline_rollout &r) { return r.postq_mean || r.postq_std || r.postq_weight; }
+
 static int rollout_ctx(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
                        void *stream, Ctx &c) {
   if (!m || !r || !ws) return ALINE_EINVAL;
@@ -689,7 +692,7 @@ static int rollout_ctx(const aline_model *m, const aline_rollout *r, void *ws, s
   c.g.tmask = r->target_mask;
   c.g.inst_B = 0; c.g.inst_t0 = 0; c.g.n_ctx0 = r->n_ctx0;
   c.m = m;
-  c.pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T);
+  c.pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, wants_postq(*r), r->T);
   if (ws_bytes < c.pl.total * sizeof(float)) return ALINE_EWORKSPACE;
   c.ws = static_cast<float *>(ws);
   c.st = static_cast<hipStream_t>(stream);
@@ -698,7 +701,7 @@ static int rollout_ctx(const aline_model *m, const aline_rollout *r, void *ws, s
 
 size_t aline_rollout_workspace_bytes(const aline_model *m, const aline_rollout *r) {
   if (!m || !r || validate_model(*m, 0) != 0) return 0;
-  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).total * sizeof(float);
+  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, wants_postq(*r), r->T).total * sizeof(float);
 }
 
 int aline_rollout_init(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
@@ -750,11 +753,18 @@ int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void
   io.post_std = r->post_std ? r->post_std + po * m->C : nullptr;
   io.post_weight = r->post_weight ? r->post_weight + po * m->C : nullptr;
   io.target_ll = r->target_ll ? r->target_ll + po : nullptr;
+  // posterior_out_query by slot (all P point rows; the rows that are context points hold unspecified values)
+  const size_t pq = (size_t)t * r->B * r->P * m->C;
+  io.postq_mean = r->postq_mean ? r->postq_mean + pq : nullptr;
+  io.postq_std = r->postq_std ? r->postq_std + pq : nullptr;
+  io.postq_weight = r->postq_weight ? r->postq_weight + pq : nullptr;
+  io.q_off = 0; io.q_rows = r->P;
   return do_head(c, X, io);
 }
 
 // The fused per-episode kernel (fused_rollout.h) covers the small-width theta-mode models.
 static bool fused_eligible(const aline_model &m, const aline_rollout &r) {
+  if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
   if (getenv("ALINE_DISABLE_FUSED")) return false;
   if (m.precision != ALINE_PREC_F32) return false;
   if (m.d != fused::D || m.F != fused::F || m.H != fused::H || m.time_token) return false;
@@ -841,6 +851,7 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
 
 // The wide path (wide.h) covers d = 256 / head_dim 32 in bf16: streamed-weight fused blocks.
 static bool wide_eligible(const aline_model &m, const aline_rollout &r) {
+  if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
   if (getenv("ALINE_DISABLE_WIDE")) return false;
   if (m.precision != ALINE_PREC_BF16 || m.d != wide::D || m.H != wide::H || m.F % 64 || m.time_token) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > wide::WNK) return false;
@@ -1021,6 +1032,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
 
 // The x3 path (x3.h): d = 256 / 8 heads at reference precision -- every product a 3-term f16 split on the matrix pipe.
 static bool x3_eligible(const aline_model &m, const aline_rollout &r) {
+  if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
   if (getenv("ALINE_DISABLE_X3")) return false;
   if (m.precision != ALINE_PREC_F16X3 || m.d != x3::D || m.H != x3::H || m.F % 32 || m.time_token) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > x3::WNK) return false;
@@ -1198,6 +1210,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   CHECK_LAUNCH();
   const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
   const S3Shape sh = s3_shape(*m, *r);
+  u32x4 *Zq = wants_postq(*r) ? reinterpret_cast<u32x4 *>(c.at(c.pl.sZq)) : nullptr;   // candidate rows of all steps
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
     s3::StepArgs sa{};
@@ -1206,6 +1219,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     sa.img = img; sa.X0 = X0; sa.XW = XW; sa.emb = aa; sa.emb.g = c.g;
     sa.logits = logits; sa.NP = NP;
     sa.zimg = want_gmm ? Zimg : nullptr; sa.zrow0 = (long)t * r->B * n_t;
+    sa.zq = Zq; sa.zq_row0 = (long)t * r->B * r->P;
 #ifdef S3_STAMPS
     sa.stamps = want_gmm ? nullptr : reinterpret_cast<unsigned long long *>(c.at(c.pl.sRaw));
 #endif
@@ -1235,6 +1249,14 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     ga.img = img + ((long)m->L * s3::layer_bytes(F) + s3::head_bytes(F)) / 4;
     ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
     ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
+    TRY(launch_s3_gmm(c, F, ga));
+  }
+  if (Zq) {         // posterior_out_query (model/head.py:366): the same heads on the candidate rows of all steps
+    const long total = (long)r->T * r->B * r->P;
+    s3::GmmArgs ga{};
+    ga.Z = Zq; ga.ntiles = (total + 15) / 16; ga.M = total; ga.C = m->C; ga.std_min = m->std_min;
+    ga.img = img + ((long)m->L * s3::layer_bytes(F) + s3::head_bytes(F)) / 4;
+    ga.mean = r->postq_mean; ga.sd = r->postq_std; ga.wgt = r->postq_weight;
     TRY(launch_s3_gmm(c, F, ga));
   }
   return ALINE_OK;

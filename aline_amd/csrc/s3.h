@@ -320,6 +320,7 @@ struct StepArgs {
   AsmArgs emb;                     // sources of the patched row
   float *logits; int NP;           // logits[b * NP + row]
   u32x4 *zimg; long zrow0;         // dense-row image of the target rows of all steps (null: not wanted)
+  u32x4 *zq; long zq_row0;         // dense-row image of the P point rows of all steps (null: posterior_out_query not wanted)
 #ifdef S3_STAMPS
   unsigned long long *stamps;      // [8 waves][S3_NSTAMP] of workgroup 0
 #endif
@@ -556,6 +557,11 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
           const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
           a.zimg[xpiece(zr >> 4, 0, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, oh);
           a.zimg[xpiece(zr >> 4, 1, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, ol);
+        }
+        if (a.zq && r < G.P) {
+          const long zr = a.zq_row0 + (long)b * G.P + r;
+          a.zq[xpiece(zr >> 4, 0, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, oh);
+          a.zq[xpiece(zr >> 4, 1, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, ol);
         }
         if (hasq) {   // acquisition logits of the candidate rows (model/head.py:27-33)
           const float *hp = reinterpret_cast<const float *>(whd + head_pairs(F) * PAIR_BYTES);   // b1 | w2 | .. | b2

@@ -18,7 +18,8 @@ class Rollout:
     """
 
     def __init__(self, model, batch, T, select="argmax", forced_idx=None, uniform=None,
-                 time_token_T=0, keep_zt=False, keep_posterior=True, time_token_reverse=False):
+                 time_token_T=0, keep_zt=False, keep_posterior=True, time_token_reverse=False,
+                 keep_query_posterior=False):
         self.model = model
         self.m = model.model_struct()
         g = _native._get
@@ -53,6 +54,12 @@ class Rollout:
             self.post_weight = torch.empty_like(self.post_mean)
         else:
             self.post_mean = self.post_std = self.post_weight = None
+        # posterior_out_query of every step, by slot (model/head.py:366; lazy in the step API, optional here)
+        self.postq_mean = self.postq_std = self.postq_weight = None
+        if keep_query_posterior:
+            self.postq_mean = torch.empty(T, B, P, C_, device=dev)
+            self.postq_std = torch.empty_like(self.postq_mean)
+            self.postq_weight = torch.empty_like(self.postq_mean)
         r = self.r = _lib.AlineRollout()
         r.B, r.P, r.n_ctx0, r.n_target_data, r.T = B, P, n_c0, n_td, T
         r.point_x, r.point_y, r.role = self.px.data_ptr(), self.py.data_ptr(), self.role.data_ptr()
@@ -77,6 +84,8 @@ class Rollout:
         r.zt = _lib.ptr(self.zt)
         r.post_mean, r.post_std, r.post_weight = (_lib.ptr(self.post_mean), _lib.ptr(self.post_std),
                                                   _lib.ptr(self.post_weight))
+        r.postq_mean, r.postq_std, r.postq_weight = (_lib.ptr(self.postq_mean), _lib.ptr(self.postq_std),
+                                                     _lib.ptr(self.postq_weight))
         nbytes = _lib.lib.aline_rollout_workspace_bytes(C.byref(self.m), C.byref(r))
         if nbytes == 0:
             raise RuntimeError("aline_amd: unsupported model/batch configuration")

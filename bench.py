@@ -256,24 +256,24 @@ def measure_alt(args, device, batch, precision):
             "value": args.batch * args.T * args.n_query / (ms * 1e-3), "unit": "designs/s"}
 
 
-def query_gmm_ms_per_rollout(args, model, device):
-    """Time of posterior_out_query (model/head.py:366: the C GMM heads on the n_query candidate rows) for all T steps of a
-    rollout, through the per-step entry point on encodings of the shapes the rollout sees (n_query - t candidates at step
-    t).  The product computes it lazily (no caller in train_aline.py / utils/eval.py reads it) and the fused rollout kernel
-    keeps encodings on chip, so this is what evaluating it at every step would add."""
-    from aline_amd.utils import AttrDict
-    d = args.d_model
-    z_all = torch.randn(args.batch, 1 + args.n_query + 2 + args.T, d, device=device)
-    def one_pass():
-        for t in range(args.T):
-            n_c, n_q = 1 + t, args.n_query - t
-            fb = AttrDict(context_x=torch.empty(args.batch, n_c, 2, device=device), query_x=torch.empty(args.batch, n_q, 2, device=device),
-                          target_all=torch.empty(args.batch, 2, 1, device=device), target_mask=None)
-            model.head._query_posterior(fb, z_all[:, :n_c + n_q + 2].contiguous())
-    one_pass(); torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); one_pass(); e1.record(); torch.cuda.synchronize(device)
-    return e0.elapsed_time(e1)
+def rollout_ms_with_query_gmm(args, model, batch, device):
+    """The same rollout with posterior_out_query (model/head.py:366: the C GMM heads on the candidate rows) of all T steps
+    computed as well (`aline_rollout.postq_*`): ms per rollout, replayed from one HIP graph like the timed region.  The
+    product computes it lazily in the step API (no caller in train_aline.py / utils/eval.py reads it) and `value` does not
+    include it; SURVEY 8-d asks for the figure with and without."""
+    from aline_amd.rollout import Rollout
+    ro = Rollout(model, batch, args.T, select="sample", keep_zt=False, keep_posterior=True, keep_query_posterior=True)
+    ro.run()
+    torch.cuda.synchronize(device)
+    ro.capture()
+    ro.refresh_uniform(); ro.replay()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ro.refresh_uniform()
+        ro.replay()
+    torch.cuda.synchronize(device)
+    return (time.perf_counter() - t0) / args.steps * 1e3, ro.path
 
 
 def log(msg):
@@ -579,17 +579,17 @@ def main():
                              "rccl_allreduce_per_step": (train_mod.ALLREDUCE_CALLS - ar0) / args.train_steps}
         log(f"train step: {tdt / args.train_steps * 1e3:.1f} ms")
     if not args.no_query_gmm and args.precision in ("f32", "f16x3"):
-        qms = query_gmm_ms_per_rollout(args, model, device)
+        qms, qpath = rollout_ms_with_query_gmm(args, model, batch, device)
         if dist is not None:
             tq = torch.tensor([qms], device=device, dtype=torch.float64)
             dist.all_reduce(tq, op=dist.ReduceOp.MAX)
             qms = float(tq.item())
-        out["value_with_query_gmm"] = world * designs_per_rollout / ((dt / args.steps) + qms * 1e-3)
-        out["query_gmm"] = {"ms_per_rollout": qms,
-                            "note": "posterior_out_query (model/head.py:366) is lazy in the product and is NOT part of `value`; this "
-                                    "is `value` with the C GMM heads evaluated on the candidate rows at all T steps through the "
-                                    "per-step entry point, on encodings of the rollout's shapes (SURVEY 8-d: with and without)"}
-        log(f"query GMM of all T steps: {qms:.2f} ms")
+        out["value_with_query_gmm"] = world * designs_per_rollout / (qms * 1e-3)
+        out["query_gmm"] = {"ms_per_rollout": qms, "path": qpath,
+                            "note": "posterior_out_query (model/head.py:366) is lazy in the step API and is NOT part of `value`; this "
+                                    "is the same rollout with the C GMM heads also evaluated on the candidate rows of all T steps "
+                                    "(aline_rollout.postq_*: [T, B, P, C] by slot), timed like `value` (SURVEY 8-d: with and without)"}
+        log(f"rollout with the query GMM of all T steps: {qms:.2f} ms")
     if world == 1 and not args.no_f32 and args.precision != "f32" and args.d_model == 32:
         out["f32"] = measure_alt(args, device, batch, "f32")
         log(f"f32 [{out['f32']['path']}]: {out['f32']['ms_per_rollout']:.2f} ms per rollout")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALINE_ABI_VERSION 1
+#define ALINE_ABI_VERSION 2
 #define ALINE_MAX_LAYERS 8
 #define ALINE_MAX_COMPONENTS 16
 
@@ -127,6 +127,10 @@ typedef struct aline_rollout {
   /* optional hipEvent_t pair recorded on `stream` right before / after the dominant kernel of
    * aline_rollout_forward (bench.py times that kernel with them); NULL = not recorded */
   void *ev_kernel_start, *ev_kernel_stop;
+  /* posterior_out_query (model/head.py:366) of every step, by slot: [T,B,P,C]; the slots that are context points at
+   * a step hold unspecified values there.  NULL = not computed (no caller in train_aline.py / utils/eval.py reads
+   * it).  Served by the s3 and generic paths (a request routes the rollout to one of them). */
+  float *postq_mean, *postq_std, *postq_weight;
 } aline_rollout;
 
 /* ABI / build info. */

@@ -37,7 +37,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_errors(lib):
     lib.aline_abi_version.restype = ctypes.c_int
-    assert lib.aline_abi_version() == 1
+    assert lib.aline_abi_version() == 2
     lib.aline_error_string.restype = ctypes.c_char_p
     assert lib.aline_error_string(0) == b"ok"
     assert b"workspace" in lib.aline_error_string(-3)
@@ -57,8 +57,8 @@ int main(void) {{
          offsetof(aline_model, acq_w1), offsetof(aline_model, gmm_b2));
   printf("%zu %zu %zu\\n", offsetof(aline_step, select_mode), offsetof(aline_step, idx),
          offsetof(aline_step, encoding));
-  printf("%zu %zu %zu\\n", offsetof(aline_rollout, select_mode), offsetof(aline_rollout, time_token_T),
-         offsetof(aline_rollout, ev_kernel_stop));
+  printf("%zu %zu %zu %zu\\n", offsetof(aline_rollout, select_mode), offsetof(aline_rollout, time_token_T),
+         offsetof(aline_rollout, ev_kernel_stop), offsetof(aline_rollout, postq_weight));
   return 0;
 }}''')
     exe = tmp_path / "layout"
@@ -69,7 +69,7 @@ int main(void) {{
     exp = [ctypes.sizeof(M), ctypes.sizeof(S), ctypes.sizeof(R),
            M.x_w1.offset, M.in_proj_w.offset, M.acq_w1.offset, M.gmm_b2.offset,
            S.select_mode.offset, S.idx.offset, S.encoding.offset,
-           R.select_mode.offset, R.time_token_T.offset, R.ev_kernel_stop.offset]
+           R.select_mode.offset, R.time_token_T.offset, R.ev_kernel_stop.offset, R.postq_weight.offset]
     assert got == exp
 
 

@@ -42,7 +42,7 @@ def make_batch(emb, B, n_query, seed, dx=2, n_td=20, n_ctx=1):
     return task.sample_batch(B)
 
 
-def run(prec, env, emb, B, n_query, T, seed=5, select="forced", target_mask=None, want_path=None, **kw):
+def run(prec, env, emb, B, n_query, T, seed=5, select="forced", target_mask=None, want_path=None, postq=False, **kw):
     from aline_amd.rollout import Rollout
     for k in ENV_KEYS:
         os.environ.pop(k, None)
@@ -57,12 +57,21 @@ def run(prec, env, emb, B, n_query, T, seed=5, select="forced", target_mask=None
         g = torch.Generator(device="cpu").manual_seed(seed)
         forced = torch.stack([torch.stack([torch.randint(0, n_query - t, (1,), generator=g)[0] for t in range(T)])
                               for _ in range(B)]).to("cuda")
-        ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None, keep_zt=True)
+        ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None, keep_zt=True,
+                     keep_query_posterior=postq)
         if want_path is not None:
             assert ro.path == want_path, ro.path
         ro.run()
         torch.cuda.synchronize()
-        return {"ll": ro.target_ll.float().cpu().clone(), "lp": ro.log_prob.float().cpu().clone(),
+        extra = {}
+        if postq:
+            n_c0 = ro.n_c0
+            role = ro.role.cpu()
+            # slot p is a candidate at step t unless it entered the context at a step < t (role = order of entry)
+            cand = torch.stack([~((role > 0) & (role <= n_c0 + t)) for t in range(T)])          # [T, B, P]
+            extra = {"qmean": ro.postq_mean.cpu().clone(), "qstd": ro.postq_std.cpu().clone(),
+                     "qw": ro.postq_weight.cpu().clone(), "cand": cand}
+        return {**extra, "ll": ro.target_ll.float().cpu().clone(), "lp": ro.log_prob.float().cpu().clone(),
                 "idx": ro.idx.cpu().clone(), "zt": ro.zt.float().cpu().clone(),
                 "mean": ro.post_mean.float().cpu().clone(), "std": ro.post_std.float().cpu().clone(),
                 "w": ro.post_weight.float().cpu().clone()}
@@ -151,3 +160,21 @@ def test_s3_fallbacks():
         os.environ.pop("ALINE_DISABLE_S3", None)
     b = run("f16x3", {}, "mix", 3, 50, 5, want_path="s3::step_kernel")
     close(a, b)
+
+
+@pytest.mark.parametrize("emb,kw", [("theta", {}), ("mix", {"n_td": 30})])
+def test_rollout_query_posterior(emb, kw):
+    """posterior_out_query of every step (model/head.py:366) from the rollout API, by slot: the s3 path (GMM heads on the
+    candidate-row image after the loop) against the generic exact-fp32 pipeline (per-step head GEMMs); a request for it
+    keeps the rollout off the fused fp32 kernel, which leaves encodings on chip."""
+    a = run("f16x3", {}, emb, 3, 50, 5, postq=True, want_path="s3::step_kernel", **kw)
+    b = run("f32", {}, emb, 3, 50, 5, postq=True, want_path="generic pipeline", **kw)
+    close(a, b)
+    cand = a["cand"]
+    assert (cand == b["cand"]).all() and cand.float().mean() > 0.8
+    m = cand[..., None].float()
+    assert torch.isfinite(a["qmean"][cand]).all() and (a["qstd"][cand] > 0).all()
+    assert ((a["qw"].sum(-1) - 1).abs() * cand).max() < 1e-5
+    assert ((a["qmean"] - b["qmean"]).abs() * m).max() < 2e-4
+    assert ((a["qw"] - b["qw"]).abs() * m).max() < 1e-4
+    assert (((a["qstd"] - b["qstd"]).abs() / b["qstd"]) * m).max() < 1e-3
