@@ -117,6 +117,32 @@ def test_rollout_api_teacher_forced(golden, name, precision, nll_tol):
     assert maxdiff(cy, fx.t(f"{mode}.final_context_y")) == 0.0
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_rollout_query_posterior_matches_reference(golden, name, precision):
+    """posterior_out_query (model/head.py:366) of the first and the last step from the rollout API (`postq_*`, by slot)
+    against what the reference's forward returned at those steps (fixture `pq_*`, rows = the remaining queries in
+    their order-preserving compaction, tasks/base_task.py:114-117)."""
+    from aline_amd.rollout import Rollout
+    fx = golden(name)
+    dims, T = fx.meta["dims"], fx.meta["T"]
+    model, _ = native_model(dims, fx.meta["wseed"], precision)
+    ro = Rollout(model, to_dev(fx.batch()), T, select="forced", forced_idx=fx.forced_idx("train"),
+                 time_token_T=T if dims.get("time_token") else 0, keep_query_posterior=True).run()
+    torch.cuda.synchronize()
+    assert ro.path in ("s3::step_kernel", "generic pipeline")        # a request keeps the rollout off the other fused paths
+    role = ro.role.cpu()
+    tp = tols(dims)["p"]
+    for t in (0, T - 1):
+        cand = ~((role > 0) & (role <= ro.n_c0 + t))                  # slot is still a query at step t
+        for b in range(ro.B):
+            sl = torch.where(cand[b])[0]
+            for got, key in ((ro.postq_mean, "pq_means"), (ro.postq_std, "pq_stds"), (ro.postq_weight, "pq_weights")):
+                ref = fx.t(f"train.{key}_{t}")[b]
+                assert ref.shape[0] == len(sl)
+                assert maxdiff(got[t, b, sl], ref) < 2 * tp, (key, t, b)
+
+
 @pytest.mark.parametrize("name", ["cfg2_location_d32", "cfg1_almix_d1_data", "cfg4_ces"])
 def test_rollout_argmax_matches_reference_designs(golden, name):
     """Free-running eval rollout: design sequence agrees with the reference's argmax trajectory."""

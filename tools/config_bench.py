@@ -93,8 +93,10 @@ def main():
         task = GPTask(dim_x=1, embedding_type="mix", n_context_init=1, n_query_init=32, n_target_theta=2,
                       n_target_data=100, device=dev)
         geo = dict(dx=1, dy=1, d=32, F=128, H=4, L=3, C=10, n_c0=1, n_q0=32, n_td=100, n_th=2, n_s=102, embedding_type="mix")
-        run("cfg1 al_mix dx=1 B=8 T=5", build(1, 32, 128, 4, 2, "mix", "f32"), task.sample_batch(8), 5, args.steps,
-            {"d": 32, "precision": "f32", "path": path_of(32, 128, 4, "mix", "f32", 0), "geo": geo})
+        b1 = task.sample_batch(8)
+        for prec in ("f32", "f16x3"):
+            run(f"cfg1 al_mix dx=1 B=8 T=5 {prec}", build(1, 32, 128, 4, 2, "mix", prec), b1, 5, args.steps,
+                {"d": 32, "precision": prec, "path": "", "geo": geo})
     if "2" in want:
         task = HiddenLocation(n_query_init=200, device=dev)
         batch = task.sample_batch(1000)
