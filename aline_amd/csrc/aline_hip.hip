@@ -583,6 +583,22 @@ static int launch_s3_step(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a
   }
 }
 template <int F>
+static int launch_s3_embed_f(const Ctx &c, const s3::EmbArgs &a) {
+  const long ntiles = ((long)a.B * a.rows_per_ep + 15) / 16;
+  hipLaunchKernelGGL(s3::embed_kernel<F>, dim3((unsigned)std::min<long>((ntiles + 3) / 4, 2048)), dim3(256), 0, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+static int launch_s3_embed(const Ctx &c, int F, const s3::EmbArgs &a) {
+  switch (F) {
+    case 32: return launch_s3_embed_f<32>(c, a);
+    case 64: return launch_s3_embed_f<64>(c, a);
+    case 96: return launch_s3_embed_f<96>(c, a);
+    case 128: return launch_s3_embed_f<128>(c, a);
+    default: return ALINE_EUNSUPPORTED;
+  }
+}
+template <int F>
 static int launch_s3_gmm_f(const Ctx &c, const s3::GmmArgs &a) {
   const size_t smem = (size_t)s3::head_bytes(F) + (size_t)3 * a.C * s3::GROWS * sizeof(float);
   static size_t attr = 0;
@@ -1197,9 +1213,21 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   pa.out = img;
   hipLaunchKernelGGL(s3::pack_kernel, dim3(256), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
-  {   // step-invariant point embeddings (fp32 rows; the generic GEMM runs the same 3-term f16 split)
-    Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
-    TRY(do_embed_points(c, xs, r->point_y, r->P));
+  {   // step-invariant point embeddings (fp32 rows): x-embedder on the points + target-data rows, y-embedder on the points
+    s3::EmbArgs ex{};
+    ex.src = Src3{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
+    ex.rows_per_ep = r->P + r->n_target_data; ex.B = r->B; ex.K = m->dim_x;
+    ex.w1 = m->x_w1; ex.b1 = m->x_b1; ex.w2 = m->x_w2; ex.b2 = m->x_b2; ex.E = c.at(c.pl.Ex);
+    s3::EmbArgs ey{};
+    ey.src = Src3{{r->point_y, nullptr, nullptr}, {r->P, 0, 0}};
+    ey.rows_per_ep = r->P; ey.B = r->B; ey.K = m->dim_y;
+    ey.w1 = m->y_w1; ey.b1 = m->y_b1; ey.w2 = m->y_w2; ey.b2 = m->y_b2; ey.E = c.at(c.pl.Ey);
+    if (getenv("ALINE_S3_GENERIC_EMBED")) {       // (A/B: the generic hidden-layer kernel + GEMM pair)
+      TRY(do_embed_points(c, ex.src, r->point_y, r->P));
+    } else {
+      TRY(launch_s3_embed(c, F, ex));
+      TRY(launch_s3_embed(c, F, ey));
+    }
   }
   u32x4 *X0 = reinterpret_cast<u32x4 *>(c.at(c.pl.sX0)), *XW = reinterpret_cast<u32x4 *>(c.at(c.pl.sXW));
   u32x4 *Zimg = reinterpret_cast<u32x4 *>(c.at(c.pl.sZimg));

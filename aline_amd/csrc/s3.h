@@ -179,6 +179,70 @@ __device__ __forceinline__ Frag lds_pair(const char *base, int pair, int lane) {
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ float relu_s(float v) { return fmaxf(v, 0.f); }
 
+// ---- point embedders (model/embedder.py:47-57): E = W2 relu(W1 x + b1) + b2 for every point / target-data row ---------
+// One kernel instead of the generic pair (hidden layer kernel + GEMM): the F hidden units of a 16-row tile stay in
+// registers (first layer on the VALU: K = dim_x or dim_y <= 8 inputs), the second layer is the usual 3-term f16 split.
+// A workgroup packs the W2 fragment pairs it needs into LDS itself (16 KB at F = 128).
+struct EmbArgs {
+  Src3 src; int rows_per_ep, B, K;
+  const float *w1, *b1, *w2, *b2;       // [F, K], [F], [D, F], [D]
+  float *E;                             // [B * rows_per_ep, D] fp32 rows
+};
+template <int F>
+__global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
+  constexpr int NH = F / 16, PAIRS = F / 16;
+  __shared__ __attribute__((aligned(16))) unsigned wimg[PAIRS * PAIR_WORDS];
+  __shared__ float prm[D + F + F * 8];                       // b2 | b1 | w1 [F][K]
+  const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4, wave = tid >> 6;
+  for (int e = tid; e < PAIRS * PAIR_WORDS; e += 256) {      // pair (c, m) = k-step c of output tile m
+    const int p = e / PAIR_WORDS;
+    wimg[e] = x3::pair_word(a.w2, F, 16 * (p & 1), p >> 1, e % PAIR_WORDS, WSCALE);
+  }
+  for (int i = tid; i < D; i += 256) prm[i] = a.b2[i];
+  for (int i = tid; i < F; i += 256) prm[D + i] = a.b1[i];
+  for (int i = tid; i < F * a.K; i += 256) prm[D + F + i] = a.w1[i];
+  __syncthreads();
+  const float *b2 = prm, *b1 = prm + D, *w1 = prm + D + F;
+  const long total = (long)a.B * a.rows_per_ep, ntiles = (total + 15) / 16;
+  const int K = a.K;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long row = 16 * tile + tok, rr = min(row, total - 1);
+    const int b = rr / a.rows_per_ep, p = rr % a.rows_per_ep;
+    const float *x;
+    if (p < a.src.n[0]) x = a.src.p[0] + ((long)b * a.src.n[0] + p) * K;
+    else if (p < a.src.n[0] + a.src.n[1]) x = a.src.p[1] + ((long)b * a.src.n[1] + (p - a.src.n[0])) * K;
+    else x = a.src.p[2] + ((long)b * a.src.n[2] + (p - a.src.n[0] - a.src.n[1])) * K;
+    float xin[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xin[k] = k < K ? x[k] : 0.f;
+    f32x4 hid[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = 16 * i + 4 * g + r;
+        float acc = b1[u];
+        for (int k = 0; k < K; ++k) acc = fmaf(xin[k], w1[u * K + k], acc);
+        hid[i][r] = relu_s(acc);
+      }
+    f32x4 y0 = z4, y1 = z4;
+#pragma unroll
+    for (int c = 0; c < NH / 2; ++c) {
+      f16x8 hh, hl;
+      split_frag(hid[2 * c], hid[2 * c + 1], hh, hl);
+      const Frag v0 = lds_pair(reinterpret_cast<const char *>(wimg), 2 * c, lane), v1 = lds_pair(reinterpret_cast<const char *>(wimg), 2 * c + 1, lane);
+      mfma3(y0, v0.hi, v0.lo, hh, hl);
+      mfma3(y1, v1.hi, v1.lo, hh, hl);
+    }
+    if (row < total) {
+      float *e = a.E + row * D;
+      *reinterpret_cast<f32x4 *>(e + 4 * g) = y0 * WINV + ld4(b2 + 4 * g);
+      *reinterpret_cast<f32x4 *>(e + 16 + 4 * g) = y1 * WINV + ld4(b2 + 16 + 4 * g);
+    }
+  }
+}
+
 // (a, b) = LayerNorm over the 32 features of each token: 8 values per lane x 4 lane groups, fp32, two passes
 __device__ __forceinline__ void layer_norm32(f32x4 &a, f32x4 &b, const float *w, const float *bb, int g) {
   const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
