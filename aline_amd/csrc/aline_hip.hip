@@ -37,7 +37,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, total;
+  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -68,6 +68,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   p.Tm = take(M * d);
   p.KeyIdx = take(M);              // key rows of every episode (generic pipeline: K / V projections on these rows only)
   p.Kcnt = take((size_t)B * 2);
+  p.X0 = take(T > 0 ? M * d : 0);   // rollouts: the embedded input, kept across the steps (one row per episode changes)
   p.Wacq = take(F * d);
   p.scalar = take(64);
   p.Wpack = take((size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS +
@@ -740,9 +741,15 @@ int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void
   TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
   const int n_t = c.g.n_td + c.g.n_th;
   c.g.n_ctx = r->n_ctx0 + t;
-  float *X = c.at(c.pl.X);
-  TRY(do_assemble(c, r->P, X));
-  TRY(do_encoder(c, X, nullptr, r->n_ctx0 + t + n_t));
+  float *X = c.at(c.pl.X), *X0 = c.at(c.pl.X0);
+  if (t == 0) {
+    TRY(do_assemble(c, r->P, X0));
+  } else {        // only the row of the point chosen at step t - 1 changes (it became a context point: + Ey)
+    hipLaunchKernelGGL(patch_row_kernel, dim3(r->B), dim3(256), 0, c.st, c.g, m->d, c.at(c.pl.Ex), c.at(c.pl.Ey), r->P,
+                       r->n_ctx0 + t, X0);
+    CHECK_LAUNCH();
+  }
+  TRY(do_encoder(c, X0, nullptr, r->n_ctx0 + t + n_t));
   HeadIO io{};
   if (m->time_token) {
     float *sc = c.at(c.pl.scalar);

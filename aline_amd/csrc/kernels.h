@@ -70,6 +70,23 @@ __global__ void assemble_kernel(Geo g, int d, const float *__restrict__ Ex, cons
   X[i] = v;
 }
 
+// Between two steps of a rollout the embedded input changes in ONE row per episode: the point chosen at the previous
+// step (role == order) became a context point, its row becomes Ex + Ey.  One workgroup per episode.
+__global__ __launch_bounds__(256) void patch_row_kernel(Geo g, int d, const float *__restrict__ Ex, const float *__restrict__ Ey,
+                                                        int ey_rows, int order, float *__restrict__ X) {
+  __shared__ int s_slot;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_slot = -1;
+  __syncthreads();
+  for (int p = tid; p < g.P; p += 256)
+    if (g.role[(long)b * g.P + p] == order) s_slot = p;
+  __syncthreads();
+  const int slot = s_slot;
+  if (slot < 0) return;
+  for (int c = tid; c < d; c += 256)
+    X[((long)b * g.N + slot) * d + c] = Ex[((long)b * (g.P + g.n_td) + slot) * d + c] + Ey[((long)b * ey_rows + slot) * d + c];
+}
+
 // ---- key rows of every episode (model/encoder.py:83-126): context points in slot order, then the visible targets.
 // keyidx[b * max_keys + j] = global token row (b * N + row) of key j, -1 beyond the episode's keys; kcnt[2 b] = context
 // keys, kcnt[2 b + 1] = all keys.  The K / V projections of the generic pipeline run on these rows only.
