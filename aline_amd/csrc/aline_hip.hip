@@ -221,6 +221,10 @@ static int launch_add_layernorm(hipStream_t st, const float *a, const float *b, 
     const unsigned grid = (unsigned)std::min<long>((M + rpb - 1) / rpb, 256 * 32);
     if (d == 32) hipLaunchKernelGGL(add_layernorm_narrow_kernel<8>, dim3(grid), dim3(256), 0, st, a, b, w, bias, out, M, usave);
     else hipLaunchKernelGGL(add_layernorm_narrow_kernel<16>, dim3(grid), dim3(256), 0, st, a, b, w, bias, out, M, usave);
+  } else if (d == 256 || d == 512) {
+    const unsigned grid = (unsigned)std::min<long>((M + 3) / 4, 256 * 16);
+    if (d == 256) hipLaunchKernelGGL(add_layernorm_wide_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, out, M, usave);
+    else hipLaunchKernelGGL(add_layernorm_wide_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, out, M, usave);
   } else {
     hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, a, b, w, bias, out, M, d, usave);
   }

@@ -274,6 +274,47 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
   for (int c = lane; c < d; c += 64, ++n) out[row * d + c] = (v[n] - mean) * rstd * w[c] + bias[c];
 }
 
+// Wide-row variant (d = 256 NV: 256, 512): one wave per row, NV float4 per lane (16 B / lane loads and stores), a wave
+// walks the rows grid-stride -- the scalar 4 B / lane kernel above runs at 3.9 TB/s at d = 512, this one is HBM-bound.
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_wide_kernel(const float *__restrict__ a, const float *__restrict__ b2,
+                                                                 const float *__restrict__ w, const float *__restrict__ bias,
+                                                                 float *__restrict__ out, long rows, float *__restrict__ usave) {
+  constexpr int d = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  float4 wv[NV], bv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    wv[i] = *reinterpret_cast<const float4 *>(w + 4 * (lane + 64 * i));
+    bv[i] = *reinterpret_cast<const float4 *>(bias + 4 * (lane + 64 * i));
+  }
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 x = *reinterpret_cast<const float4 *>(a + row * d + 4 * (lane + 64 * i));
+      const float4 y = *reinterpret_cast<const float4 *>(b2 + row * d + 4 * (lane + 64 * i));
+      v[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      if (usave) *reinterpret_cast<float4 *>(usave + row * d + 4 * (lane + 64 * i)) = v[i];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float t0 = v[i].x - mean, t1 = v[i].y - mean, t2 = v[i].z - mean, t3 = v[i].w - mean;
+      ss += (t0 * t0 + t1 * t1) + (t2 * t2 + t3 * t3);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      *reinterpret_cast<float4 *>(out + row * d + 4 * (lane + 64 * i)) =
+          make_float4((v[i].x - mean) * rstd * wv[i].x + bv[i].x, (v[i].y - mean) * rstd * wv[i].y + bv[i].y,
+                      (v[i].z - mean) * rstd * wv[i].z + bv[i].z, (v[i].w - mean) * rstd * wv[i].w + bv[i].w);
+  }
+}
+
 // Narrow-row variant (d = 4 * LPR, LPR = 8 or 16 lanes per row, float4 per lane): a wave normalises 64 / LPR
 // rows at a time and the row statistics are LPR-lane xor reductions.  At d = 32 the one-wave-per-row kernel above
 // leaves half of the lanes idle and runs at ~1 TB/s; this one is HBM-bound.
