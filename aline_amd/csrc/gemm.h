@@ -102,7 +102,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, grp = blockIdx.z;
+  // Workgroup -> (row block, column block): the column blocks of one row block read the same A rows; they get ids 8
+  // apart so that they run on the same XCD at about the same time (ids go round-robin over the 8 XCDs) and the rows
+  // come out of that XCD's L2 after the first read instead of N / BN times out of HBM.
+  int mb = blockIdx.x, nb = blockIdx.y;
+  if (gridDim.y > 1) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, per = 8 * gridDim.y;
+    const int chunk = lin / per, within = lin - chunk * per;
+    const int rows_in_chunk = min(8, (int)gridDim.x - chunk * 8);
+    mb = chunk * 8 + within % rows_in_chunk;
+    nb = within / rows_in_chunk;
+  }
+  const int m0 = mb * BM, n0 = nb * BN, grp = blockIdx.z;
   const float *__restrict__ W = a.W[grp];
 
   f32x4 acc[TM][TN];
@@ -282,8 +293,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
           for (int o = SEGS / 2; o > 0; o >>= 1) pj[j] += __shfl_xor(pj[j], o, 64);
         if (seg == 0) {
           const long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
-          float *op = a.red_out + blockIdx.y * a.red_block_stride + dst * a.red_stride + grp * a.red_nout;
-          for (int j = 0; j < a.red_nout; ++j) op[j] = pj[j] + (blockIdx.y == 0 && a.red_b[grp] ? a.red_b[grp][j] : 0.f);
+          float *op = a.red_out + nb * a.red_block_stride + dst * a.red_stride + grp * a.red_nout;
+          for (int j = 0; j < a.red_nout; ++j) op[j] = pj[j] + (nb == 0 && a.red_b[grp] ? a.red_b[grp][j] : 0.f);
         }
       }
       continue;
