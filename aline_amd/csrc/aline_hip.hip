@@ -12,6 +12,7 @@
 #include "wide_step.h"
 #include "x3.h"
 #include "s3.h"
+#include "attn3.h"
 #include "backward.h"
 
 #include <algorithm>
@@ -284,6 +285,14 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
       CHECK_LAUNCH();
     }
     const float *kvc = compact_kv ? KVc : nullptr;
+    // head_dim 32 / 64 outside the exact-fp32 mode, up to 64 keys: the attention on the matrix pipe (attn3.h)
+    if (compact_kv && (hd == 32 || hd == 64) && max_keys <= 16 * attn3::MAX_KT && m.precision != ALINE_PREC_F32 &&
+        !getenv("ALINE_VALU_ATTENTION")) {
+      const dim3 grid((unsigned)((c.g.B + 7) / 8 * 8 * m.H));
+      if (hd == 64) hipLaunchKernelGGL(attn3::attention_kernel<64>, grid, dim3(256), 0, c.st, c.g, d, QKV, KVc, kcnt, A, max_keys);
+      else hipLaunchKernelGGL(attn3::attention_kernel<32>, grid, dim3(256), 0, c.st, c.g, d, QKV, KVc, kcnt, A, max_keys);
+      CHECK_LAUNCH();
+    } else
     switch (hd) {
       case 4: TRY(launch_attention<4>(c, QKV, A, max_keys, kvc, kcnt)); break;
       case 8: TRY(launch_attention<8>(c, QKV, A, max_keys, kvc, kcnt)); break;

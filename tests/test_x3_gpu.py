@@ -19,7 +19,7 @@ LL_TOL, LP_TOL = 1e-4, 1e-4
 def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, dims=DIMS):
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
-    for k in ("ALINE_DISABLE_X3",):
+    for k in ("ALINE_DISABLE_X3", "ALINE_VALU_ATTENTION"):
         os.environ.pop(k, None)
     os.environ.update(env)
     try:
@@ -96,3 +96,17 @@ def test_x3_is_reproducible():
     a = _run("f16x3", {}, 9, 200, 6)
     b = _run("f16x3", {}, 9, 200, 6)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("d,extra_env", [(512, {}), (256, {"ALINE_DISABLE_X3": "1"})])
+def test_generic_mfma_attention_matches_valu_attention(d, extra_env):
+    """Generic pipeline at head_dim 64 (d = 512, the cfg5 shape) and 32: the attention on the matrix pipe (attn3.h, 3-term
+    f16 split, K / V of the key rows only) against the fp32 VALU attention kernel, same GEMMs around it; and against the
+    exact-fp32 pipeline at the reference bound."""
+    dims = dict(DIMS, d=d, F=128, L=2)
+    ll_m, lp_m, _ = _run("f16x3", dict(extra_env), 3, 70, 5, dims=dims)
+    ll_v, lp_v, _ = _run("f16x3", dict(extra_env, ALINE_VALU_ATTENTION="1"), 3, 70, 5, dims=dims)
+    ll_f, lp_f, _ = _run("f32", {}, 3, 70, 5, dims=dims)
+    assert torch.isfinite(ll_m).all()
+    assert (ll_m - ll_v).abs().max() < 5e-5 and (lp_m - lp_v).abs().max() < 5e-5
+    assert (ll_m - ll_f).abs().max() < LL_TOL and (lp_m - lp_f).abs().max() < LP_TOL
