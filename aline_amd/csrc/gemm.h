@@ -101,7 +101,7 @@ __device__ __forceinline__ void lds_store4(typename LdsTile<PREC>::T *base, int 
 }
 
 template <int PREC, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
   using LT = LdsTile<PREC>;
   using T = typename LT::T;
   constexpr int LD = LT::LD;
