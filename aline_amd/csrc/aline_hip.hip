@@ -1562,7 +1562,7 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
   if (smem > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_bwd_kernel<HD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(attention_bwd_kernel<HD>, dim3((unsigned)((c.g.B + 7) / 8 * 8 * c.m->H)), dim3(256), smem, c.st, c.g, c.m->d, qkv,
+  hipLaunchKernelGGL(attention_bwd_kernel<HD>, dim3((unsigned)c.g.B), dim3(256), smem, c.st, c.g, c.m->d, qkv,
                      dA, dqkv, max_keys);
   CHECK_LAUNCH();
   return ALINE_OK;

@@ -225,8 +225,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   int *keyrow = reinterpret_cast<int *>(dKV + (size_t)max_keys * 2 * HD);     // [max_keys]
   __shared__ int wave_cnt[4];
   __shared__ int s_base;
-  // workgroup id -> (episode, head) as in attention_kernel: the heads of an episode share an XCD's L2
-  const int H = d / HD, b = (blockIdx.x / (8 * H)) * 8 + blockIdx.x % 8, h = (blockIdx.x / 8) % H;
+  // one workgroup per instance, the heads one after the other: the key list is built once and the four 32-byte head
+  // slices of a QKV row are read by the same CU back to back (a workgroup per (instance, head) spent most of its time
+  // in the prologue: 60 000 workgroups of ~5 us of arithmetic per call)
+  const int H = d / HD, b = blockIdx.x;
   if (b >= g.B) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_t = g.n_td + g.n_th;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   __syncthreads();
   const int n_ak = s_base;
   const long ep = (long)b * g.N;
+  for (int h = 0; h < H; ++h) {
   for (int i = tid; i < n_ak * HD; i += 256) {
     int j = i / HD, c = i % HD;
     const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
@@ -345,6 +348,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     dst[d] = dKV[j * 2 * HD + c];            // Qs already carries the 1/sqrt(hd)
     dst[2 * d] = dKV[j * 2 * HD + HD + c];
   }
+  __syncthreads();     // the staging arrays are reused by the next head
+  }   // heads
 }
 
 // Acquisition head backward, first part (model/head.py:27-33 + log-softmax of the chosen design):
