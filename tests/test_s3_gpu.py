@@ -103,6 +103,8 @@ def close(a, b):
     ("mix", 2, 40, 4, {"n_td": 20, "F": 32, "L": 1, "C": 16}),
     ("mix", 2, 40, 4, {"n_td": 20, "F": 96, "C": 16}),          # the largest GMM stage: 16 heads x 3 outputs x 512 rows in LDS
     ("theta", 1, 700, 3, {}),                                   # one episode of 703 rows (44 tiles) in a workgroup
+    ("theta", 2, 20, 1, {}),                                    # a single step (the stage modules' shape)
+    ("mix", 2, 30, 3, {"n_td": 10, "n_ctx": 12}),               # more initial context points than a key tile
     ("mix", 3, 60, 30, {"n_td": 100, "n_ctx": 5}),   # 138 keys at the last step
 ])
 def test_s3_matches_fp32_pipeline(emb, B, n_query, T, kw):
