@@ -277,13 +277,13 @@ __device__ __forceinline__ float softmax_tiles(f32x4 (&s)[NKT]) {
   return __builtin_amdgcn_rcpf(group_sum4(acc0 + acc1));                         // (v_rcp_f32: 1 ulp)
 }
 
-// masked set-attention of one token tile against 2 NKP key tiles (model/encoder.py:8-46): S^T = K Q_h^T in the exp2
+// masked set-attention of one token tile against NKT key tiles (model/encoder.py:8-46): S^T = K Q_h^T in the exp2
 // domain (scale folded into Wq), softmax over the keys of a token, O^T = V^T P.  kv: this episode's K / V^T pairs in
 // LDS (+ lane * 16; V^T pairs [m][nkp] at kv_v); nv4 = (number of keys the lane's token sees) - 4 g.
-template <int NKP, int CAP>
+template <int NKT, int CAP>
 __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, const char *kv, int nv4, int g, f32x4 (&o)[2]) {
   constexpr int kv_v = CAP * 4096, nkp = CAP;     // LDS slot of an episode: K pairs [2 CAP] | V^T pairs [m][CAP]
-  constexpr int NKT = 2 * NKP;
+  constexpr int NKP = (NKT + 1) / 2;              // key tiles NKT (an odd count: the last V^T pair is half used), pairs NKP
   const u32x4 qhu = __builtin_bit_cast(u32x4, qh), qlu = __builtin_bit_cast(u32x4, ql);
   const bool glo = g < 2;
 #pragma unroll
@@ -319,9 +319,10 @@ __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, cons
 #pragma unroll
     for (int kb = 0; kb < NKP; ++kb) {
       f16x8 ph, pl;
-      split_frag(sa[2 * kb], sa[2 * kb + 1], ph, pl);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      split_frag(sa[2 * kb], 2 * kb + 1 < NKT ? sa[2 * kb + 1 < NKT ? 2 * kb + 1 : 0] : z4, ph, pl);
       mfma3(oa, vh[kb], vl[kb], ph, pl);
-      split_frag(sb[2 * kb], sb[2 * kb + 1], ph, pl);
+      split_frag(sb[2 * kb], 2 * kb + 1 < NKT ? sb[2 * kb + 1 < NKT ? 2 * kb + 1 : 0] : z4, ph, pl);
       mfma3(ob, vh[kb], vl[kb], ph, pl);
     }
     {
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       const int nck = n_ck[e], nak = n_ak[e];
       const bool isq = rc < G.P && !is_ctx(G, b, rc);
       const bool hasq = 16 * j < G.P;                 // (wave-uniform) some row of the tile may see the targets
-      const int nkp_t = max(1, ((hasq ? nak : nck) + 31) >> 5);
+      const int nkp_t = max(1, ((hasq ? nak : nck) + 31) >> 5), nkt_t = max(1, ((hasq ? nak : nck) + 15) >> 4);
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       // Q^T = Wq X^T (pre-scaled by log2(e) / sqrt(hd))
       f16x8 qh, ql;
@@ -558,12 +559,21 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       {
         const char *kv = lds + KV_OFF + e * kv_ep + lane * 16;
         const int nv4 = (isq ? nak : nck) - 4 * g;
-        bool done = false;     // (the host never asks for more key tiles than the variant holds)
-        if constexpr (MAXNKP >= 5) { if (nkp_t >= 5) { attention<5, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
-        if constexpr (MAXNKP >= 4) { if (!done && nkp_t == 4) { attention<4, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
-        if constexpr (MAXNKP >= 3) { if (!done && nkp_t == 3) { attention<3, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
-        if constexpr (MAXNKP >= 2) { if (!done && nkp_t >= 2) { attention<2, MAXNKP>(qh, ql, kv, nv4, g, o); done = true; } }
-        if (!done) attention<1, MAXNKP>(qh, ql, kv, nv4, g, o);
+        // (the host never asks for more key tiles than the variant holds.)  The 16-wave variant (<= 64 keys) has a body per
+        // key-tile count -- at the headline shape the first 14 steps need one tile --, the 8-wave variant per pair
+        if constexpr (MAXNKP == 2) {
+          if (nkt_t >= 4) attention<4, MAXNKP>(qh, ql, kv, nv4, g, o);
+          else if (nkt_t == 3) attention<3, MAXNKP>(qh, ql, kv, nv4, g, o);
+          else if (nkt_t == 2) attention<2, MAXNKP>(qh, ql, kv, nv4, g, o);
+          else attention<1, MAXNKP>(qh, ql, kv, nv4, g, o);
+        } else {
+          // (per PAIR of key tiles: bodies for the odd counts were measured at cfg3, 1 % for 40 % more code)
+          if (MAXNKP >= 5 && nkp_t >= 5) attention<10, MAXNKP>(qh, ql, kv, nv4, g, o);
+          else if (MAXNKP >= 4 && nkp_t == 4) attention<8, MAXNKP>(qh, ql, kv, nv4, g, o);
+          else if (MAXNKP >= 3 && nkp_t == 3) attention<6, MAXNKP>(qh, ql, kv, nv4, g, o);
+          else if (nkp_t == 2) attention<4, MAXNKP>(qh, ql, kv, nv4, g, o);
+          else attention<2, MAXNKP>(qh, ql, kv, nv4, g, o);
+        }
       }
 #ifdef S3_STAMPS
       asm volatile("" :: "v"(o[0]), "v"(o[1]));
