@@ -12,12 +12,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// fp32 -> bf16 round-to-nearest-even (finite inputs; NaN propagation is not needed here because
-// every consumer accumulates in fp32 and NaNs in activations already mean a failed step).
+// fp32 -> bf16 round-to-nearest-even through the hardware conversion (v_cvt_pk_bf16_f32): a NaN stays a NaN -- the integer
+// form (u + 0x7FFF + lsb) >> 16 turns some NaNs into 0 / inf (MI355X_MICROARCH.md, correctness boundaries), which would
+// hide a failed step in the bf16 modes.
 __device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
