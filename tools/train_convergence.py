@@ -1,5 +1,5 @@
 """Sanity run of the training driver (aline_amd.driver.train) on a small location-finding problem: the prediction loss
-must fall during burn-in and keep falling once the design loss is switched on.   python tools/train_convergence.py"""
+must fall during burn-in and keep falling once the design loss is switched on.   python tools/train_convergence.py [f32|f16x3]"""
 import json
 import os
 import random
@@ -20,6 +20,7 @@ class Cfg(dict):
 torch.manual_seed(0); random.seed(0)
 dev = torch.device("cuda")
 model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).to(dev)
+model.set_precision(sys.argv[1] if len(sys.argv) > 1 else "f32")       # "f16x3": rollouts on the s3 path, backward in exact fp32
 task = HiddenLocation(n_query_init=50, device=dev)
 cfg = Cfg(optimizer="AdamW", lr=1e-3, max_epoch=400, burning_epoch=200, checkpoint=0, output_dir="/tmp/aline_probe",
           file_name="probe.pth", T=10, min_T=10, alpha=1.0, gamma=1.0, clip_grads=True, batch_size=256, verbose=10 ** 9,
