@@ -1263,7 +1263,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     c.g.n_ctx = r->n_ctx0 + t;
     s3::StepArgs sa{};
     sa.g = c.g; sa.tpe = tpe; sa.L = m->L; sa.F = F; sa.order = t > 0 ? r->n_ctx0 + t : 0;
-    sa.epw = sh.epw; sa.nk2 = std::min(2 * sh.nkp, (r->n_ctx0 + t + n_t + 15) / 16);
+    sa.epw = sh.epw; sa.nk2 = 2 * std::min(sh.nkp, (r->n_ctx0 + t + n_t + 31) / 32);
     sa.img = img; sa.X0 = X0; sa.XW = XW; sa.emb = aa; sa.emb.g = c.g;
     sa.logits = logits; sa.NP = NP;
     sa.zimg = want_gmm ? Zimg : nullptr; sa.zrow0 = (long)t * r->B * n_t;

@@ -378,8 +378,7 @@ struct Stamps {
 struct StepArgs {
   Geo g; int tpe, L, F;
   int epw;                         // episodes per workgroup (the LDS slot of an episode holds the variant's MAXNKP key-tile pairs)
-  int nk2;                         // key tiles to compute this step: ceil(bound of the key count / 16) <= 2 nkp (the half of a V^T
-                                   // pair no key tile fills stays zero: the K / V slots are cleared at the start of the launch)
+  int nk2;                         // key tiles (even) to compute this step: 2 ceil(bound of the key count / 32) <= 2 nkp
   int order;                       // > 0: role value of the point chosen at the previous step (its X0 row becomes Ex + Ey)
   const unsigned *img;             // L layer images, then the head images
   u32x4 *X0, *XW;                  // input image (patched in place) / work image
@@ -416,7 +415,6 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   for (int piece = wave; piece < (lbytes >> 10); piece += NW) glds16(gimg + piece * 1024 + lane * 16, wl + piece * 1024);
   for (int piece = wave; piece < (head_bytes(F) >> 10); piece += NW) glds16(gimg + (long)a.L * lbytes + piece * 1024 + lane * 16, whd + piece * 1024);
   if (tid == 0) { queue[0] = 0; queue[1] = 0; }
-  for (int i = tid; i < epw * kv_ep / 16; i += NW * 64) reinterpret_cast<u32x4 *>(lds + KV_OFF)[i] = (u32x4){0u, 0u, 0u, 0u};
   // per episode: the patched row, then the key list (context rows in slot order, then the visible targets)
   for (int e0 = 0; e0 < epw; e0 += NGRP) {
     const int e = e0 + grp;
