@@ -41,10 +41,14 @@ constexpr int GEMM_BK = 32;
 
 template <int PREC> struct LdsTile;  // storage of a [ROWS x 32] operand tile in LDS
 template <> struct LdsTile<0> { static constexpr int LD = 34; using T = float; static constexpr int PLANES = 1; };
-template <> struct LdsTile<1> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 1; };
-template <> struct LdsTile<2> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 2; };
-template <> struct LdsTile<3> { static constexpr int LD = 40; using T = unsigned short; static constexpr int PLANES = 2; };
+template <> struct LdsTile<1> { static constexpr int LD = 32; using T = unsigned short; static constexpr int PLANES = 1; };
+template <> struct LdsTile<2> { static constexpr int LD = 32; using T = unsigned short; static constexpr int PLANES = 2; };
+template <> struct LdsTile<3> { static constexpr int LD = 32; using T = unsigned short; static constexpr int PLANES = 2; };
 constexpr float GEMM_F16_WSCALE = 256.f;
+// 16-bit operand tiles: rows of 32 k-values = 64 bytes, the four 16-byte chunks of a row XOR-swizzled by (row / 4) % 4:
+// the 8-byte stores of a half wave (4 rows x 8 slots) and the 16-byte fragment reads of 16 rows both touch every bank once
+// (a 40-element pitch made the reads conflict-free and the stores two-way conflicting: 47 % of the LDS-active cycles by PMC)
+__device__ __forceinline__ int gemm_swz(int row, int k) { return row * 32 + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7); }
 
 typedef __attribute__((ext_vector_type(8))) _Float16 gemm_f16x8;
 __device__ __forceinline__ void split_f16(float a, unsigned short &hi, unsigned short &lo) {
@@ -78,8 +82,8 @@ __device__ __forceinline__ void lds_store4(typename LdsTile<PREC>::T *base, int 
     split2_f16(v.x * scale, v.y * scale, h0, l0);
     split2_f16(v.z * scale, v.w * scale, h1, l1);
     typedef __attribute__((ext_vector_type(2))) unsigned gemm_u32x2;
-    *reinterpret_cast<gemm_u32x2 *>(base + row * LD + k) = (gemm_u32x2){h0, h1};
-    *reinterpret_cast<gemm_u32x2 *>(base + plane_elems + row * LD + k) = (gemm_u32x2){l0, l1};
+    *reinterpret_cast<gemm_u32x2 *>(base + gemm_swz(row, k)) = (gemm_u32x2){h0, h1};
+    *reinterpret_cast<gemm_u32x2 *>(base + plane_elems + gemm_swz(row, k)) = (gemm_u32x2){l0, l1};
     return;
   }
   if constexpr (PREC == 0) {
@@ -87,7 +91,7 @@ __device__ __forceinline__ void lds_store4(typename LdsTile<PREC>::T *base, int 
     p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
   } else if constexpr (PREC == 1) {
     u16x4 h = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
-    *reinterpret_cast<u16x4 *>(base + row * LD + k) = h;
+    *reinterpret_cast<u16x4 *>(base + gemm_swz(row, k)) = h;
   } else {
     u16x4 h, l;
     unsigned short a, b;
@@ -95,8 +99,8 @@ __device__ __forceinline__ void lds_store4(typename LdsTile<PREC>::T *base, int 
     split_bf16(v.y, a, b); h[1] = a; l[1] = b;
     split_bf16(v.z, a, b); h[2] = a; l[2] = b;
     split_bf16(v.w, a, b); h[3] = a; l[3] = b;
-    *reinterpret_cast<u16x4 *>(base + row * LD + k) = h;
-    *reinterpret_cast<u16x4 *>(base + plane_elems + row * LD + k) = l;
+    *reinterpret_cast<u16x4 *>(base + gemm_swz(row, k)) = h;
+    *reinterpret_cast<u16x4 *>(base + plane_elems + gemm_swz(row, k)) = l;
   }
 }
 
@@ -201,13 +205,13 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
       gemm_f16x8 ah[TM], bh[TN], al[TM], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const gemm_f16x8 *>(As + (wm * WM + i * 16 + fr) * LD + fg * 8);
-        al[i] = *reinterpret_cast<const gemm_f16x8 *>(As + A_ELEMS + (wm * WM + i * 16 + fr) * LD + fg * 8);
+        ah[i] = *reinterpret_cast<const gemm_f16x8 *>(As + gemm_swz(wm * WM + i * 16 + fr, fg * 8));
+        al[i] = *reinterpret_cast<const gemm_f16x8 *>(As + A_ELEMS + gemm_swz(wm * WM + i * 16 + fr, fg * 8));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const gemm_f16x8 *>(Bs + (wn * WN + j * 16 + fr) * LD + fg * 8);
-        bl[j] = *reinterpret_cast<const gemm_f16x8 *>(Bs + B_ELEMS + (wn * WN + j * 16 + fr) * LD + fg * 8);
+        bh[j] = *reinterpret_cast<const gemm_f16x8 *>(Bs + gemm_swz(wn * WN + j * 16 + fr, fg * 8));
+        bl[j] = *reinterpret_cast<const gemm_f16x8 *>(Bs + B_ELEMS + gemm_swz(wn * WN + j * 16 + fr, fg * 8));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -221,10 +225,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
       bf16x8 ah[TM], bh[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        ah[i] = *reinterpret_cast<const bf16x8 *>(As + (wm * WM + i * 16 + fr) * LD + fg * 8);
+        ah[i] = *reinterpret_cast<const bf16x8 *>(As + gemm_swz(wm * WM + i * 16 + fr, fg * 8));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bh[j] = *reinterpret_cast<const bf16x8 *>(Bs + (wn * WN + j * 16 + fr) * LD + fg * 8);
+        bh[j] = *reinterpret_cast<const bf16x8 *>(Bs + gemm_swz(wn * WN + j * 16 + fr, fg * 8));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -234,10 +238,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
         bf16x8 al[TM], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          al[i] = *reinterpret_cast<const bf16x8 *>(As + A_ELEMS + (wm * WM + i * 16 + fr) * LD + fg * 8);
+          al[i] = *reinterpret_cast<const bf16x8 *>(As + A_ELEMS + gemm_swz(wm * WM + i * 16 + fr, fg * 8));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bl[j] = *reinterpret_cast<const bf16x8 *>(Bs + B_ELEMS + (wn * WN + j * 16 + fr) * LD + fg * 8);
+          bl[j] = *reinterpret_cast<const bf16x8 *>(Bs + B_ELEMS + gemm_swz(wn * WN + j * 16 + fr, fg * 8));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
