@@ -573,7 +573,11 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
 
 template <int F, int NW, int MAXNKP>
 static int launch_s3_step_v(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {
-  constexpr bool PF = NW == 16;      // next tile's rows requested a tile ahead (the 8-wave variant has no registers for it)
+#ifdef S3_PREFETCH         // (timing experiment, tools/x3_variants.sh: the next tile's rows requested a tile ahead costs 8 registers,
+  constexpr bool PF = NW == 16;      //  i.e. spills in the 128-register variant: 2 % slower than without; 4 waves per SIMD hide the load)
+#else
+  constexpr bool PF = false;
+#endif
   static size_t attr = 0;
   if (sh.lds > attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F, NW, MAXNKP, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);

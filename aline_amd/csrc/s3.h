@@ -594,29 +594,37 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         layer_norm32(x1a, x1b, ln1w, ln1b, g);
         split_frag(x1a, x1b, x1h, x1l);
       }
-      // X2 = LN2(X1 + b2 + W2 relu(W1 X1 + b1)): all F hidden units of the tile in registers
+      // X2 = LN2(X1 + b2 + W2 relu(W1 X1 + b1)): the hidden units of the tile in registers, GH tiles of 16 at a time (all of them
+      // in the 256-register variant; four in the 128-register variant, which otherwise spills)
       f32x4 y0 = z4, y1 = z4;
       {
-        f32x4 hid[NH];
+        constexpr int GH = (NW == 16 && NH > 4) ? (NH % 4 == 0 ? 4 : 2) : NH;
 #pragma unroll
-        for (int i = 0; i < NH; ++i) {
-          const Frag u = lds_pair(wl, 8 + i, lane);
-          hid[i] = z4;
-          mfma3(hid[i], u.hi, u.lo, x1h, x1l);
-        }
-        f16x8 hh[NH / 2], hl[NH / 2];
+        for (int h0i = 0; h0i < NH; h0i += GH) {
+          f32x4 hid[GH];
 #pragma unroll
-        for (int c = 0; c < NH / 2; ++c) {
-          f32x4 h0 = hid[2 * c] * WINV + ld4(b1 + 32 * c + 4 * g), h1 = hid[2 * c + 1] * WINV + ld4(b1 + 32 * c + 16 + 4 * g);
+          for (int i = 0; i < GH; ++i) {
+            const Frag u = lds_pair(wl, 8 + h0i + i, lane);
+            hid[i] = z4;
+            mfma3(hid[i], u.hi, u.lo, x1h, x1l);
+          }
+          f16x8 hh[GH / 2], hl[GH / 2];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { h0[q] = relu_s(h0[q]); h1[q] = relu_s(h1[q]); }
-          split_frag(h0, h1, hh[c], hl[c]);
-        }
+          for (int c = 0; c < GH / 2; ++c) {
+            const int cc = h0i / 2 + c;
+            f32x4 h0 = hid[2 * c] * WINV + ld4(b1 + 32 * cc + 4 * g), h1 = hid[2 * c + 1] * WINV + ld4(b1 + 32 * cc + 16 + 4 * g);
 #pragma unroll
-        for (int c = 0; c < NH / 2; ++c) {
-          const Frag v0 = lds_pair(wl, 8 + NH + 2 * c, lane), v1 = lds_pair(wl, 8 + NH + 2 * c + 1, lane);
-          mfma3(y0, v0.hi, v0.lo, hh[c], hl[c]);
-          mfma3(y1, v1.hi, v1.lo, hh[c], hl[c]);
+            for (int q = 0; q < 4; ++q) { h0[q] = relu_s(h0[q]); h1[q] = relu_s(h1[q]); }
+            split_frag(h0, h1, hh[c], hl[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < GH / 2; ++c) {
+            const int cc = h0i / 2 + c;
+            const Frag v0 = lds_pair(wl, 8 + NH + 2 * cc, lane), v1 = lds_pair(wl, 8 + NH + 2 * cc + 1, lane);
+            mfma3(y0, v0.hi, v0.lo, hh[c], hl[c]);
+            mfma3(y1, v1.hi, v1.lo, hh[c], hl[c]);
+          }
+          if (GH < NH) __builtin_amdgcn_sched_barrier(0);     // keep the groups apart (the scheduler would merge their loads)
         }
       }
       f32x4 x2a = y0 * WINV + ld4(b2 + 4 * g) + x1a, x2b = y1 * WINV + ld4(b2 + 16 + 4 * g) + x1b;
@@ -640,18 +648,23 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         if (hasq) {   // acquisition logits of the candidate rows (model/head.py:27-33)
           const float *hp = reinterpret_cast<const float *>(whd + head_pairs(F) * PAIR_BYTES);   // b1 | w2 | .. | b2
           float plog = 0.f;
-          f32x4 hid[NH];
+          constexpr int GH = (NW == 16 && NH > 4) ? (NH % 4 == 0 ? 4 : 2) : NH;
 #pragma unroll
-          for (int i = 0; i < NH; ++i) {
-            const Frag u = lds_pair(whd, i, lane);
-            hid[i] = z4;
-            mfma3(hid[i], u.hi, u.lo, oh, ol);
-          }
+          for (int h0i = 0; h0i < NH; h0i += GH) {
+            f32x4 hid[GH];
 #pragma unroll
-          for (int i = 0; i < NH; ++i) {
-            const f32x4 hv = hid[i] * WINV + ld4(hp + 16 * i + 4 * g), wv = ld4(hp + F + 16 * i + 4 * g);
+            for (int i = 0; i < GH; ++i) {
+              const Frag u = lds_pair(whd, h0i + i, lane);
+              hid[i] = z4;
+              mfma3(hid[i], u.hi, u.lo, oh, ol);
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) plog = fmaf(relu_s(hv[q]), wv[q], plog);
+            for (int i = 0; i < GH; ++i) {
+              const f32x4 hv = hid[i] * WINV + ld4(hp + 16 * (h0i + i) + 4 * g), wv = ld4(hp + F + 16 * (h0i + i) + 4 * g);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) plog = fmaf(relu_s(hv[q]), wv[q], plog);
+            }
+            if (GH < NH) __builtin_amdgcn_sched_barrier(0);
           }
           const float v = group_sum4(plog) + hp[4 * F];
           if (g == 0 && r < G.P) a.logits[(long)b * a.NP + r] = v;
