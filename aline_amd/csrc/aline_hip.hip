@@ -542,8 +542,9 @@ static int device_cus() {
   return n;
 }
 
-// Launch shape of the s3 step kernel: 16 waves per workgroup (4 per SIMD, 128 registers) while an episode never holds
-// more than 64 keys, 8 waves (256 registers: all scores of a head pair over 160 keys) otherwise; as many episodes per
+// Launch shape of the s3 step kernel: 12 waves per workgroup (3 per SIMD, 170 registers: no spills; 16 waves at 128
+// registers measured 1.5 % slower, ALINE_S3_WAVES=16) while an episode never holds more than 64 keys, 8 waves (256
+// registers: all scores of a head pair over 160 keys) otherwise; as many episodes per
 // workgroup as keeps every CU busy and the token tiles spread evenly over the waves.
 struct S3Shape { int nw, nkp, epw; unsigned nwg; size_t lds; };     // nkp: key-tile pairs an episode's LDS slot holds
 static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
@@ -551,9 +552,9 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
   const int n_t = r.n_target_data + m.n_theta, N = r.P + n_t, tpe = (N + 15) / 16;
   const int nkeys = r.n_ctx0 + r.T - 1 + n_t;
   const int need = std::max(1, (nkeys + 31) / 32);
-  s.nw = need <= 2 ? 16 : 8;
-  if (const char *e = getenv("ALINE_S3_WAVES")) s.nw = atoi(e) == 16 && need <= 2 ? 16 : 8;
-  s.nkp = s.nw == 16 ? 2 : s3::NKP_MAX;
+  s.nw = need <= 2 ? 12 : 8;
+  if (const char *e = getenv("ALINE_S3_WAVES")) s.nw = (atoi(e) == 16 || atoi(e) == 12) && need <= 2 ? atoi(e) : 8;
+  s.nkp = s.nw >= 12 ? 2 : s3::NKP_MAX;
   const int per_ep = s3::kv_ep_bytes(s.nkp) + 32 * s.nkp * 4;
   const int epw_max = std::max(1, std::min(s3::EPW_MAX, (s3::LDS_LIMIT - s3::KV_OFF - s3::MISC_INTS * 4) / per_ep));
   const int cus = device_cus();
@@ -589,6 +590,7 @@ static int launch_s3_step_v(const Ctx &c, const S3Shape &sh, const s3::StepArgs 
 }
 template <int F>
 static int launch_s3_step_f(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {
+  if (sh.nw == 12) return launch_s3_step_v<F, 12, 2>(c, sh, a);
   return sh.nw == 16 ? launch_s3_step_v<F, 16, 2>(c, sh, a) : launch_s3_step_v<F, 8, s3::NKP_MAX>(c, sh, a);
 }
 static int launch_s3_step(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {

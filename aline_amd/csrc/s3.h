@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       {
         const char *kv = lds + KV_OFF + e * kv_ep + lane * 16;
         const int nv4 = (isq ? nak : nck) - 4 * g;
-        // (the host never asks for more key tiles than the variant holds.)  The 16-wave variant (<= 64 keys) has a body per
+        // (the host never asks for more key tiles than the variant holds.)  The 12- / 16-wave variant (<= 64 keys) has a body per
         // key-tile count -- at the headline shape the first 14 steps need one tile --, the 8-wave variant per pair
         if constexpr (MAXNKP == 2) {
           if (nkt_t >= 4) attention<4, MAXNKP>(qh, ql, kv, nv4, g, o);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       // in the 256-register variant; four in the 128-register variant, which otherwise spills)
       f32x4 y0 = z4, y1 = z4;
       {
-        constexpr int GH = (NW == 16 && NH > 4) ? (NH % 4 == 0 ? 4 : 2) : NH;
+        constexpr int GH = (NW > 8 && NH > 4) ? (NH % 4 == 0 ? 4 : 2) : NH;
 #pragma unroll
         for (int h0i = 0; h0i < NH; h0i += GH) {
           f32x4 hid[GH];
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         if (hasq) {   // acquisition logits of the candidate rows (model/head.py:27-33)
           const float *hp = reinterpret_cast<const float *>(whd + head_pairs(F) * PAIR_BYTES);   // b1 | w2 | .. | b2
           float plog = 0.f;
-          constexpr int GH = (NW == 16 && NH > 4) ? (NH % 4 == 0 ? 4 : 2) : NH;
+          constexpr int GH = (NW > 8 && NH > 4) ? (NH % 4 == 0 ? 4 : 2) : NH;
 #pragma unroll
           for (int h0i = 0; h0i < NH; h0i += GH) {
             f32x4 hid[GH];

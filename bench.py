@@ -504,7 +504,7 @@ def main():
                                                           args.T - 1)
         per_launch = fl_last * args.batch
         achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
-        kname, peak, traffic = "s3::step_kernel<128, 16, 2, true>", PEAK_BF16_DENSE_TFLOPS, None
+        kname, peak, traffic = "s3::step_kernel<128, 12, 2, false>", PEAK_BF16_DENSE_TFLOPS, None
         extra = {"launches_per_rollout": args.T, "mfma_passes_per_product": 3,
                  "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / 3,
                  "frac_vs_instruction_mix_peak": achieved_tflops * 3 / PEAK_BF16_DENSE_TFLOPS,

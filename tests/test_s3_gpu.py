@@ -113,10 +113,11 @@ def test_s3_matches_fp32_pipeline(emb, B, n_query, T, kw):
     close(a, b)
 
 
-@pytest.mark.parametrize("env", [{"ALINE_S3_WAVES": "8"}, {"ALINE_S3_EPW": "1"}, {"ALINE_S3_EPW": "3"},
+@pytest.mark.parametrize("env", [{"ALINE_S3_WAVES": "8"}, {"ALINE_S3_WAVES": "16"}, {"ALINE_S3_WAVES": "16", "ALINE_S3_EPW": "4"},
+                                 {"ALINE_S3_EPW": "1"}, {"ALINE_S3_EPW": "3"},
                                  {"ALINE_S3_WAVES": "8", "ALINE_S3_EPW": "5"}])
 def test_s3_launch_shapes_agree(env):
-    """8 or 16 waves per workgroup, any number of episodes per workgroup: the same results to fp32 rounding (only the
+    """8, 12 (default) or 16 waves per workgroup, any number of episodes per workgroup: the same results to fp32 rounding (only the
     work split changes, not the arithmetic of a token)."""
     a = run("f16x3", {}, "theta", 7, 100, 6)
     b = run("f16x3", env, "theta", 7, 100, 6)
