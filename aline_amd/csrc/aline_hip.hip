@@ -574,8 +574,8 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
 
 template <int F, int NW, int MAXNKP>
 static int launch_s3_step_v(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {
-#ifdef S3_PREFETCH         // (timing experiment, tools/x3_variants.sh: the next tile's rows requested a tile ahead costs 8 registers,
-  constexpr bool PF = NW == 16;      //  i.e. spills in the 128-register variant: 2 % slower than without; 4 waves per SIMD hide the load)
+#ifdef S3_PREFETCH         // (timing experiment, tools/x3_variants.sh: the next tile's rows requested a tile ahead: 2 % SLOWER
+  constexpr bool PF = NW >= 12;      //  at 12 and at 16 waves per workgroup -- three or four waves per SIMD hide the load already)
 #else
   constexpr bool PF = false;
 #endif
