@@ -605,7 +605,8 @@ static int launch_s3_step(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a
 template <int F>
 static int launch_s3_embed_f(const Ctx &c, const s3::EmbArgs &a) {
   const long ntiles = ((long)a.B * a.rows_per_ep + 15) / 16;
-  hipLaunchKernelGGL(s3::embed_kernel<F>, dim3((unsigned)std::min<long>((ntiles + 3) / 4, 2048)), dim3(256), 0, c.st, a);
+  // (every workgroup first packs the W2 fragment pairs into LDS: a few workgroups per CU that walk the tiles, not one per 4 tiles)
+  hipLaunchKernelGGL(s3::embed_kernel<F>, dim3((unsigned)std::min<long>((ntiles + 3) / 4, 4L * device_cus())), dim3(256), 0, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;
 }

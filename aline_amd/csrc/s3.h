@@ -223,7 +223,9 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int u = 16 * i + 4 * g + r;
         float acc = b1[u];
-        for (int k = 0; k < K; ++k) acc = fmaf(xin[k], w1[u * K + k], acc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)      // (compile-time indices: a runtime-indexed xin[] would live in scratch memory)
+          if (k < K) acc = fmaf(xin[k], w1[u * K + k], acc);
         hid[i][r] = relu_s(acc);
       }
     f32x4 y0 = z4, y1 = z4;
