@@ -14,6 +14,7 @@
 #include "s3.h"
 #include "attn3.h"
 #include "backward.h"
+#include "tail_bwd.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1459,8 +1460,17 @@ struct BwdPlan {
       total;
 };
 
+// Fused token-local tail (tail_bwd.h) for the small-width model: U1 / X1 / Hid / U2 are never stored.  ALINE_BWD_TAIL=0
+// switches back to the per-op pipeline (A/B measurements).
+static bool bwd_fused_tail(const aline_model &m) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("ALINE_BWD_TAIL"); on = e ? atoi(e) != 0 : 1; }
+  return on && m.d == tailbwd::D && m.F == tailbwd::F;
+}
+
 BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   BwdPlan p{};
+  const bool ft = bwd_fused_tail(m);
   const size_t N = (size_t)P + n_td + m.n_theta, I = (size_t)B * tc, M = I * N, d = m.d, F = m.F, L = m.L;
   const size_t n_t = (size_t)n_td + m.n_theta, rows_x = (size_t)B * (P + n_td), rows_y = (size_t)B * P;
   size_t off = 0;
@@ -1468,16 +1478,16 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   p.Xs = take((L + 1) * M * d);
   p.QKV = take(L * M * 3 * d);
   p.A = take(L * M * d);
-  p.U1 = take(L * M * d);
-  p.X1 = take(L * M * d);
-  p.Hid = take(L * M * F);
-  p.U2 = take(L * M * d);
+  p.U1 = take(ft ? 0 : L * M * d);
+  p.X1 = take(ft ? 0 : L * M * d);
+  p.Hid = take(ft ? 0 : L * M * F);
+  p.U2 = take(ft ? 0 : L * M * d);
   p.HidA = take(I * P * F);
   p.HidG = take(I * n_t * m.C * F);
   p.dXa = take(M * d);
   p.dXb = take(M * d);
   p.dQKV = take(M * 3 * d);
-  p.dHid = take(std::max(M * F, rows_x * F));
+  p.dHid = take(std::max(ft ? (size_t)0 : M * F, rows_x * F));
   p.dTmp = take(M * d);
   p.Ex = take(rows_x * d);
   p.Ey = take(rows_y * d);
@@ -1575,6 +1585,34 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
   return ALINE_OK;
 }
 
+// token-local tail of layer l (tail_bwd.h): forward recompute (dY == nullptr: Y = layer output) or forward + backward
+int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, const float *dY, float *dA, float *dU,
+                const aline_grads *gr, long M) {
+  const aline_model &m = *c.m;
+  tailbwd::Args a{};
+  a.X = X; a.A = A; a.dY = dY; a.Y = Y; a.dA = dA; a.dU = dU; a.M = M;
+  a.wo = m.out_proj_w[l]; a.bo = m.out_proj_b[l]; a.w1 = m.lin1_w[l]; a.b1 = m.lin1_b[l]; a.w2 = m.lin2_w[l]; a.b2 = m.lin2_b[l];
+  a.g1 = m.norm1_w[l]; a.e1 = m.norm1_b[l]; a.g2 = m.norm2_w[l]; a.e2 = m.norm2_b[l];
+  const size_t smem = tailbwd::LDS_FLOATS * sizeof(float);
+  const long groups = ((M + 15) / 16 + tailbwd::WAVES - 1) / tailbwd::WAVES;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  if (!dY) {
+    hipLaunchKernelGGL(tailbwd::tail_kernel<false>, dim3((unsigned)std::min<long>(groups, 256 * 3)), dim3(tailbwd::THREADS), smem, c.st, a);
+  } else {
+    a.dwo = gr->out_proj_w[l]; a.dbo = gr->out_proj_b[l]; a.dw1 = gr->lin1_w[l]; a.db1 = gr->lin1_b[l];
+    a.dw2 = gr->lin2_w[l]; a.db2 = gr->lin2_b[l]; a.dg1 = gr->norm1_w[l]; a.de1 = gr->norm1_b[l];
+    a.dg2 = gr->norm2_w[l]; a.de2 = gr->norm2_b[l];
+    hipLaunchKernelGGL(tailbwd::tail_kernel<true>, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);   // 394 registers: one wave per SIMD
+  }
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
 }  // namespace
 
 extern "C" size_t aline_rollout_backward_workspace_bytes(const aline_model *m, const aline_rollout *r,
@@ -1618,6 +1656,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
   if (ws_bytes < c.pl.total * sizeof(float)) return ALINE_EWORKSPACE;
   c.ws = static_cast<float *>(ws);
   c.st = static_cast<hipStream_t>(stream);
+  const bool ft = bwd_fused_tail(*m);
   const int B = r->B, P = r->P, n_td = r->n_target_data, n_th = m->n_theta, n_t = n_td + n_th;
   const int N = P + n_t, d = m->d, F = m->F, L = m->L, C = m->C, hd = m->H > 0 ? d / m->H : 0;
   const int rows_x = B * (P + n_td), rows_y = B * P;
@@ -1676,6 +1715,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         case 64: TRY(launch_attention<64>(fc, QKVl(l), Al(l), max_keys)); break;
         default: return ALINE_EUNSUPPORTED;
       }
+      if (ft) { TRY(launch_tail(c, l, Xs(l), Al(l), Xs(l + 1), nullptr, nullptr, nullptr, nullptr, M)); continue; }
       TRY(launch_gemm(bwd_prec(), gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));
       TRY(launch_add_layernorm(c.st, Xs(l), dTmp, m->norm1_w[l], m->norm1_b[l], X1l(l), M, d, U1l(l)));
       TRY(launch_gemm(bwd_prec(), gemm_args(X1l(l), d, m->lin1_w[l], m->lin1_b[l], d, Hidl(l), F, (int)M, F, d, true), 1, c.st));
@@ -1749,6 +1789,9 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     }
     // ---- encoder layers backward ---------------------------------------------------------------------------
     for (int l = L - 1; l >= 0 && do_enc; --l) {
+      if (ft) {                      // dTmp = dA, dXn = dU1 (the residual branch), parameter gradients of the tail
+        TRY(launch_tail(c, l, Xs(l), Al(l), nullptr, dX, dTmp, dXn, gr, M));
+      } else {
       // LN2
       TRY(ln_bwd(c, dX, U2l(l), m->norm2_w[l], dTmp, gr->norm2_w[l], gr->norm2_b[l], M));   // dTmp = dU2
       // FFN
@@ -1761,6 +1804,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       // out-proj
       TRY(gemm_dw(c, dXn, d, Al(l), d, gr->out_proj_w[l], gr->out_proj_b[l], M, d, d));
       TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false));                  // dTmp = dA
+      }
       // attention
       switch (hd) {
         case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys)); break;

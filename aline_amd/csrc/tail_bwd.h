@@ -1,0 +1,319 @@
+// Token-local tail of one encoder layer for the small-width model (d = 32, F = 128) in the TRAINING backward:
+//   u1 = x + Wo a + bo;  x1 = LN1(u1);  h = relu(W1 x1 + b1);  u2 = x1 + W2 h + b2;  y = LN2(u2)
+// (model/encoder.py:128-141, post-norm; `loss.backward()` of train_aline.py:124-132 through it).
+//
+// tail_kernel<false>: forward recompute, y from (x, a) -- exact fp32, [M, 128] hidden activations never exist.
+// tail_kernel<true>:  forward recompute AND backward of the same 16-row tile in the registers of one wave:
+//   in  x, a, dy = dLoss/dy                       (384 B per token row)
+//   out da = dLoss/da, du1 = dLoss/du1            (256 B per token row; du1 is also the residual branch into x)
+//   and the parameter gradients dWo, dbo, dW1, db1, dW2, db2, LN1 / LN2 weight and bias.
+// It replaces, per layer, 5 forward launches (out-projection GEMM, add + LN, two FFN GEMMs, add + LN) that saved
+// U1 / X1 / Hid / U2 (3.4 KB per token row) and 8 backward launches (two LN backward, three dW and three dX GEMMs)
+// that re-read them: ~7 KB of HBM traffic per token row and layer become 640 B.
+//
+// Register scheme.  Two layouts of a 16-row x 16-feature block in the 4 registers of a lane (tok = lane & 15, g = lane >> 4):
+//   T layout (token on lane): reg r of lane (tok, g) = V[row tok][feature 4 g + r]  -- the MFMA accumulator of Y^T = W X^T and,
+//     register for register, the B operand of the next product (fused_rollout.h): all forward products and all dX products
+//     (dX^T = W^T dY^T) chain in it; the A operand is a weight fragment read from a padded row-major LDS image.
+//   N layout (feature on lane): reg r of lane (f, g) = V[row 4 g + r][feature f]  -- what a weight gradient needs:
+//     dW[i][j] = sum_rows dY[row][i] X[row][j] is four 16x16x4 MFMAs with A = dY_N[r], B = X_N[r] (k = row).
+//   T -> N is a 16 x 32 transpose through a private LDS scratch of the wave (one ds_write_b128 pair, eight ds_read_b32).
+// The 36 dW accumulator tiles (144 registers) of a wave stay resident over all its tiles and are added to global memory once.
+// All products are exact fp32 (v_mfma_f32_16x16x4_f32): the acquisition-head gradients are a small difference of large
+// REINFORCE terms and do not survive a split-bf16 forward.
+#pragma once
+#include "fused_rollout.h"
+
+namespace tailbwd {
+
+constexpr int D = 32, F = 128;
+constexpr int PW = 36, PW2 = 132;                      // LDS row pitches (floats): conflict-free b128 row reads and column reads
+constexpr int L_WO = 0, L_W1 = L_WO + D * PW, L_W2 = L_W1 + F * PW, L_PRM = L_W2 + D * PW2;
+constexpr int P_BO = 0, P_B1 = 32, P_B2 = 160, P_G1 = 192, P_E1 = 224, P_G2 = 256, P_E2 = 288, NPRM = 320;
+constexpr int L_SCR = L_PRM + NPRM;
+constexpr int SCR = 16 * PW;
+constexpr int WAVES = 4, THREADS = 64 * WAVES;
+constexpr int LDS_FLOATS = L_SCR + WAVES * SCR;       // 12608 floats = 50.4 KB
+// gradient staging, reusing the image region after the tile loop
+constexpr int G_WO = 0, G_W1 = G_WO + D * D, G_W2 = G_W1 + F * D, G_PRM = G_W2 + D * F, G_TOT = G_PRM + NPRM;
+static_assert(G_TOT <= L_SCR, "gradient staging must fit below the scratch");
+
+struct Args {
+  const float *X, *A;        // [M, 32] layer input, attention output
+  const float *dY;           // [M, 32] gradient wrt the layer output                (backward)
+  float *Y;                  // [M, 32] layer output                                 (forward)
+  float *dA, *dU;            // [M, 32] gradient wrt a, gradient wrt u1              (backward)
+  long M;
+  const float *wo, *bo, *w1, *b1, *w2, *b2, *g1, *e1, *g2, *e2;
+  float *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dg1, *de1, *dg2, *de2;     // accumulated into (+=)
+};
+
+using fused::ld4;
+using fused::group_sum;
+
+// acc[ob] += W[16 ob + tok][16 kb + 4 g + r] * in[kb][r]   (Y^T = W X^T; W row-major [out][in] in LDS)
+template <int NOB, int NKB>
+__device__ __forceinline__ void mm_fwd(f32x4 (&acc)[NOB], const float *W, int pitch, const f32x4 (&in)[NKB], int tok, int g) {
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    f32x4 w[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) w[ob] = ld4(W + (16 * ob + tok) * pitch + 16 * kb + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) MFMA4(acc[ob], w[ob][r], in[kb][r]);
+  }
+}
+// acc[ib] += W[16 kb + 4 g + r][16 ib + tok] * dy[kb][r]    (dX^T = W^T dY^T; same image, column reads)
+template <int NIB, int NKB>
+__device__ __forceinline__ void mm_bwd(f32x4 (&acc)[NIB], const float *W, int pitch, const f32x4 (&dy)[NKB], int tok, int g) {
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float w[NIB];
+#pragma unroll
+      for (int ib = 0; ib < NIB; ++ib) w[ib] = W[(16 * kb + 4 * g + r) * pitch + 16 * ib + tok];
+#pragma unroll
+      for (int ib = 0; ib < NIB; ++ib) MFMA4(acc[ib], w[ib], dy[kb][r]);
+    }
+}
+// dW tile += sum over the 16 rows of the tile  a_N[.][i] * b_N[.][j]
+__device__ __forceinline__ void mm_dw(f32x4 &acc, const f32x4 &aN, const f32x4 &bN) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) MFMA4(acc, aN[r], bN[r]);
+}
+// T layout -> N layout of a 16 x 32 block through the wave's scratch (DS operations of a wave execute in order)
+__device__ __forceinline__ void to_n(f32x4 (&out)[2], const f32x4 &in0, const f32x4 &in1, float *scr, int tok, int g) {
+  *reinterpret_cast<f32x4 *>(scr + tok * PW + 4 * g) = in0;
+  *reinterpret_cast<f32x4 *>(scr + tok * PW + 16 + 4 * g) = in1;
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[mt][r] = scr[(4 * g + r) * PW + 16 * mt + tok];
+  asm volatile("" ::: "memory");
+}
+// u <- (u - mean) * rstd over the 32 features of each row (eps 1e-5, biased variance); returns rstd
+__device__ __forceinline__ float normalise(f32x4 (&u)[2]) {
+  float s = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += u[mt][r];
+  const float mean = group_sum(s) * (1.f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { u[mt][r] -= mean; ss = fmaf(u[mt][r], u[mt][r], ss); }
+  const float rstd = rsqrtf(group_sum(ss) * (1.f / D) + 1e-5f);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[mt][r] *= rstd;
+  return rstd;
+}
+// LayerNorm backward: dy (gradient wrt gamma n + beta) -> du; the parameter gradients accumulate per lane (T layout)
+__device__ __forceinline__ void ln_backward(f32x4 (&du)[2], const f32x4 (&dy)[2], const f32x4 (&n)[2], float rstd,
+                                            const float *gamma, f32x4 (&dgam)[2], f32x4 (&dbet)[2], int g) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const f32x4 gv = ld4(gamma + 16 * mt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dgam[mt][r] = fmaf(dy[mt][r], n[mt][r], dgam[mt][r]);
+      dbet[mt][r] += dy[mt][r];
+      const float dn = dy[mt][r] * gv[r];
+      du[mt][r] = dn;
+      s1 += dn;
+      s2 = fmaf(dn, n[mt][r], s2);
+    }
+  }
+  const float m1 = group_sum(s1) * (1.f / D), m2 = group_sum(s2) * (1.f / D);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) du[mt][r] = (du[mt][r] - m1 - n[mt][r] * m2) * rstd;
+}
+__device__ __forceinline__ float sum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+template <bool BWD>
+__global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  for (int i = tid; i < D * D; i += THREADS) lds[L_WO + (i >> 5) * PW + (i & 31)] = a.wo[i];
+  for (int i = tid; i < F * D; i += THREADS) lds[L_W1 + (i >> 5) * PW + (i & 31)] = a.w1[i];
+  for (int i = tid; i < D * F; i += THREADS) lds[L_W2 + (i >> 7) * PW2 + (i & 127)] = a.w2[i];
+  if (tid < F) lds[L_PRM + P_B1 + tid] = a.b1[tid];
+  if (tid < D) {
+    lds[L_PRM + P_BO + tid] = a.bo[tid]; lds[L_PRM + P_B2 + tid] = a.b2[tid];
+    lds[L_PRM + P_G1 + tid] = a.g1[tid]; lds[L_PRM + P_E1 + tid] = a.e1[tid];
+    lds[L_PRM + P_G2 + tid] = a.g2[tid]; lds[L_PRM + P_E2 + tid] = a.e2[tid];
+  }
+  __syncthreads();
+
+  // weight-gradient accumulators of this wave (MFMA accumulator layout: [16 ib + 4 g + r][16 jb + tok])
+  f32x4 gWo[2][2], gW1[8][2], gW2[2][8];
+  f32x4 gG1[2], gE1[2], gG2[2], gE2[2];      // LayerNorm parameters, T layout (feature 16 mt + 4 g + r, partial over rows)
+  float gBo[2], gB1[8], gB2[2];              // biases, N layout (feature 16 blk + tok, partial over lane groups)
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) gWo[i][j] = fused::zero4();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { gW1[j][i] = fused::zero4(); gW2[i][j] = fused::zero4(); }
+      gG1[i] = gE1[i] = gG2[i] = gE2[i] = fused::zero4();
+      gBo[i] = gB2[i] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gB1[j] = 0.f;
+  }
+
+  const long ntiles = (a.M + 15) / 16;
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long)gridDim.x * WAVES) {
+    // opaque base: the images are loop-invariant, and hoisted weight fragments would take every register
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const float *W = lds + zoff, *prm = W + L_PRM;
+    float *scr = lds + zoff + L_SCR + wave * SCR;
+    const long row = tile * 16 + tok;
+    const bool ok = row < a.M;
+    const long rc = ok ? row : a.M - 1;
+    f32x4 x[2], at[2], dy[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      x[mt] = ld4(a.X + rc * D + 16 * mt + 4 * g);
+      at[mt] = ld4(a.A + rc * D + 16 * mt + 4 * g);
+      if (BWD) dy[mt] = ok ? ld4(a.dY + rc * D + 16 * mt + 4 * g) : fused::zero4();
+    }
+    // ---- forward ---------------------------------------------------------------------------------------------
+    f32x4 n1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) n1[mt] = ld4(prm + P_BO + 16 * mt + 4 * g) + x[mt];
+    mm_fwd<2, 2>(n1, W + L_WO, PW, at, tok, g);
+    const float rstd1 = normalise(n1);
+    f32x4 x1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) x1[mt] = n1[mt] * ld4(prm + P_G1 + 16 * mt + 4 * g) + ld4(prm + P_E1 + 16 * mt + 4 * g);
+    f32x4 h[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(prm + P_B1 + 16 * ob + 4 * g);
+    mm_fwd<8, 2>(h, W + L_W1, PW, x1, tok, g);
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[ob][r] = relu_nn(h[ob][r]);
+    f32x4 n2[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) n2[mt] = ld4(prm + P_B2 + 16 * mt + 4 * g) + x1[mt];
+    mm_fwd<2, 8>(n2, W + L_W2, PW2, h, tok, g);
+    const float rstd2 = normalise(n2);
+    if (!BWD) {
+      if (ok) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          *reinterpret_cast<f32x4 *>(a.Y + row * D + 16 * mt + 4 * g) =
+              n2[mt] * ld4(prm + P_G2 + 16 * mt + 4 * g) + ld4(prm + P_E2 + 16 * mt + 4 * g);
+      }
+      continue;
+    }
+    // ---- backward --------------------------------------------------------------------------------------------
+    f32x4 du2[2];
+    ln_backward(du2, dy, n2, rstd2, prm + P_G2, gG2, gE2, g);
+    f32x4 du2N[2], x1N[2];
+    to_n(du2N, du2[0], du2[1], scr, tok, g);
+    to_n(x1N, x1[0], x1[1], scr, tok, g);
+    gB2[0] += sum4(du2N[0]); gB2[1] += sum4(du2N[1]);
+    f32x4 dx1[2] = {du2[0], du2[1]};
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {          // 32 hidden units at a time
+      f32x4 dh[2] = {fused::zero4(), fused::zero4()};
+      mm_bwd<2, 2>(dh, W + L_W2 + 32 * kc, PW2, du2, tok, g);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[j][r] = h[2 * kc + j][r] > 0.f ? dh[j][r] : 0.f;
+      mm_bwd<2, 2>(dx1, W + L_W1 + 32 * kc * PW, PW, dh, tok, g);
+      f32x4 hN[2], dhN[2];
+      to_n(hN, h[2 * kc], h[2 * kc + 1], scr, tok, g);
+      to_n(dhN, dh[0], dh[1], scr, tok, g);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        mm_dw(gW2[0][2 * kc + j], du2N[0], hN[j]);
+        mm_dw(gW2[1][2 * kc + j], du2N[1], hN[j]);
+        mm_dw(gW1[2 * kc + j][0], dhN[j], x1N[0]);
+        mm_dw(gW1[2 * kc + j][1], dhN[j], x1N[1]);
+        gB1[2 * kc + j] += sum4(dhN[j]);
+      }
+    }
+    f32x4 du1[2];
+    ln_backward(du1, dx1, n1, rstd1, prm + P_G1, gG1, gE1, g);
+    f32x4 da[2] = {fused::zero4(), fused::zero4()};
+    mm_bwd<2, 2>(da, W + L_WO, PW, du1, tok, g);
+    if (ok) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        *reinterpret_cast<f32x4 *>(a.dA + row * D + 16 * mt + 4 * g) = da[mt];
+        *reinterpret_cast<f32x4 *>(a.dU + row * D + 16 * mt + 4 * g) = du1[mt];
+      }
+    }
+    f32x4 du1N[2], aN[2];
+    to_n(du1N, du1[0], du1[1], scr, tok, g);
+    to_n(aN, at[0], at[1], scr, tok, g);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      mm_dw(gWo[i][0], du1N[i], aN[0]);
+      mm_dw(gWo[i][1], du1N[i], aN[1]);
+      gBo[i] += sum4(du1N[i]);
+    }
+  }
+  if (!BWD) return;
+
+  // ---- the workgroup's gradients: LDS staging, then one atomic per element ------------------------------------
+  __syncthreads();
+  for (int i = tid; i < G_TOT; i += THREADS) lds[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) atomicAdd(&lds[G_WO + (16 * i + 4 * g + r) * D + 16 * j + tok], gWo[i][j][r]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&lds[G_W1 + (16 * j + 4 * g + r) * D + 16 * i + tok], gW1[j][i][r]);
+        atomicAdd(&lds[G_W2 + (16 * i + 4 * g + r) * F + 16 * j + tok], gW2[i][j][r]);
+      }
+      atomicAdd(&lds[G_PRM + P_G1 + 16 * i + 4 * g + r], gG1[i][r]);
+      atomicAdd(&lds[G_PRM + P_E1 + 16 * i + 4 * g + r], gE1[i][r]);
+      atomicAdd(&lds[G_PRM + P_G2 + 16 * i + 4 * g + r], gG2[i][r]);
+      atomicAdd(&lds[G_PRM + P_E2 + 16 * i + 4 * g + r], gE2[i][r]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    atomicAdd(&lds[G_PRM + P_BO + 16 * i + tok], gBo[i]);
+    atomicAdd(&lds[G_PRM + P_B2 + 16 * i + tok], gB2[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(&lds[G_PRM + P_B1 + 16 * j + tok], gB1[j]);
+  __syncthreads();
+  for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwo + i, lds[G_WO + i]);
+  for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1 + i, lds[G_W1 + i]);
+  for (int i = tid; i < D * F; i += THREADS) unsafeAtomicAdd(a.dw2 + i, lds[G_W2 + i]);
+  if (tid < F) unsafeAtomicAdd(a.db1 + tid, lds[G_PRM + P_B1 + tid]);
+  if (tid < D) {
+    unsafeAtomicAdd(a.dbo + tid, lds[G_PRM + P_BO + tid]);
+    unsafeAtomicAdd(a.db2 + tid, lds[G_PRM + P_B2 + tid]);
+    unsafeAtomicAdd(a.dg1 + tid, lds[G_PRM + P_G1 + tid]);
+    unsafeAtomicAdd(a.de1 + tid, lds[G_PRM + P_E1 + tid]);
+    unsafeAtomicAdd(a.dg2 + tid, lds[G_PRM + P_G2 + tid]);
+    unsafeAtomicAdd(a.de2 + tid, lds[G_PRM + P_E2 + tid]);
+  }
+}
+
+}  // namespace tailbwd
