@@ -15,6 +15,7 @@
 #include "attn3.h"
 #include "backward.h"
 #include "tail_bwd.h"
+#include "attn_bwd_mfma.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1573,6 +1574,13 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 
 template <int HD>
 int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys) {
+  static int mfma_on = -1;      // ALINE_BWD_ATTN_MFMA=0: the VALU kernel (A/B measurements)
+  if (mfma_on < 0) { const char *e = getenv("ALINE_BWD_ATTN_MFMA"); mfma_on = e ? atoi(e) != 0 : 1; }
+  if (mfma_on && HD == abwd::HD && c.m->d == abwd::D && max_keys <= abwd::MAXK) {
+    hipLaunchKernelGGL(abwd::attention_bwd_mfma_kernel, dim3((unsigned)c.g.B), dim3(abwd::THREADS), 0, c.st, c.g, qkv, dA, dqkv);
+    CHECK_LAUNCH();
+    return ALINE_OK;
+  }
   size_t smem = (size_t)max_keys * (4 * HD * sizeof(float) + sizeof(int)) +
                 (size_t)c.g.N * (2 * HD + 4) * sizeof(float);
   if (smem > 160 * 1024 - 1024) return ALINE_EUNSUPPORTED;

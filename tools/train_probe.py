@@ -3,10 +3,13 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.pa
 from conftest import Fixture
 from helpers import native_model, to_dev
 from aline_amd.train import train_step
+# usage: train_probe.py [t_chunk ...]   (with arguments: timing only, at those chunk sizes)
+TCS = [int(v) for v in sys.argv[1:]]
 fx = Fixture("cfg2_location_d32")
 model, _ = native_model(fx.meta["dims"], fx.meta["wseed"])
-terms, ro = train_step(model, to_dev(fx.batch()), 30, forced_idx=fx.forced_idx("train"), clip_grads=False)
-for k, p in model.named_parameters():
+if not TCS:
+    terms, ro = train_step(model, to_dev(fx.batch()), 30, forced_idx=fx.forced_idx("train"), clip_grads=False)
+for k, p in (model.named_parameters() if not TCS else ()):
     ref = fx.t("train.grad." + k); got = p.grad.cpu()
     print(f"{k:55s} max|ref|={float(ref.abs().max()):.3e} relerr={float((got-ref).abs().max())/(float(ref.abs().max())+1e-9):.2e}")
 # timing at B=1000
@@ -16,7 +19,7 @@ m = Aline(Embedder(2,1,32,128,2,"theta"), Encoder(32,128,4,0.0,3), OutputHead(2,
 opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
 task = HiddenLocation()
 batch = task.sample_batch(1000)
-for tc in (10, 30):
+for tc in (TCS or (10, 30)):
     train_step(m, batch, 30, optimizer=opt, t_chunk=tc); torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(3): train_step(m, batch, 30, optimizer=opt, t_chunk=tc)
