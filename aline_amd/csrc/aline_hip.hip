@@ -1469,6 +1469,13 @@ static bool bwd_fused_tail(const aline_model &m) {
   return on && m.d == tailbwd::D && m.F == tailbwd::F;
 }
 
+// In-projection + attention backward as one kernel (attn_bwd_mfma.h).  ALINE_BWD_ATTN_BLOCK=0: the per-op kernels.
+static bool fused_attn_block(const aline_model &m, int max_keys) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("ALINE_BWD_ATTN_BLOCK"); on = e ? atoi(e) != 0 : 1; }
+  return on && m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK;
+}
+
 BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   BwdPlan p{};
   const bool ft = bwd_fused_tail(m);
@@ -1812,6 +1819,24 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       // out-proj
       TRY(gemm_dw(c, dXn, d, Al(l), d, gr->out_proj_w[l], gr->out_proj_b[l], M, d, d));
       TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false));                  // dTmp = dA
+      }
+      // attention block: in-projection + attention in one kernel (attn_bwd_mfma.h), dXn = dU1 -> dX_l
+      if (fused_attn_block(*m, max_keys)) {
+        abwd::BlockArgs ba{};
+        ba.g = g; ba.X = Xs(l); ba.dA = dTmp; ba.dX = dXn; ba.win = m->in_proj_w[l]; ba.bin = m->in_proj_b[l];
+        ba.dwin = gr->in_proj_w[l]; ba.dbin = gr->in_proj_b[l];
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(2) * (int)sizeof(float));
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(3) * (int)sizeof(float));
+          attr = true;
+        }
+        // persistent workgroups: two per CU at <= 32 keys (221 registers), one otherwise
+        if (max_keys <= 32) hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<2>, dim3((unsigned)std::min(I, 512)), dim3(abwd::THREADS), abwd::block_lds_floats(2) * sizeof(float), c.st, ba);
+        else hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<3>, dim3((unsigned)std::min(I, 256)), dim3(abwd::THREADS), abwd::block_lds_floats(3) * sizeof(float), c.st, ba);
+        CHECK_LAUNCH();
+        std::swap(dX, dXn);
+        continue;
       }
       // attention
       switch (hd) {

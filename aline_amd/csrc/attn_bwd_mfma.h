@@ -194,4 +194,301 @@ __global__ __launch_bounds__(THREADS) void attention_bwd_mfma_kernel(Geo g, cons
   }
 }
 
+
+// ---- the whole attention block: in-projection + attention, backward, in one kernel --------------------------------------
+//   q = Wq x + bq,  K / V = Wk / Wv x_key + b  (key rows only),  a = attention(q, K, V)
+//   in   x = layer input [M, 32], dA = dLoss/da, dX = dLoss/du1 (the residual branch, written by the tail kernel)
+//   out  dX += Wq^T dq  (every row)  + Wk^T dK + Wv^T dV  (key rows);  dWin, dbin accumulated into (+=)
+// Neither QKV nor dQKV ([M, 96] each) exist: the per-op pipeline wrote / read them five times per layer (in-projection GEMM,
+// attention backward, its dW and dX GEMMs).  Persistent workgroups walk the instances; per instance the key list, the key
+// rows of x and their K / V (MFMA prologue) live in LDS, dK / dV are summed over the waves in LDS and an MFMA epilogue
+// turns them into the key rows' dX and the Wk / Wv gradients.  The 12 dWin accumulator tiles stay in registers.
+struct BlockArgs {
+  Geo g;
+  const float *X, *dA;
+  float *dX;
+  const float *win, *bin;      // in_proj_weight [96, 32], in_proj_bias [96]
+  float *dwin, *dbin;
+};
+
+__device__ __forceinline__ int load_role(const Geo &g, int b, int p) {
+  if (g.inst_B > 0) return g.role[(long)(b % g.inst_B) * g.P + p];
+  return g.role ? g.role[(long)b * g.P + p] : (p < g.n_ctx ? 1 : 0);
+}
+__device__ __forceinline__ bool role_is_ctx(const Geo &g, int b, int r) {
+  if (g.inst_B > 0) return r > 0 && r <= g.n_ctx0 + g.inst_t0 + b / g.inst_B;
+  return r > 0;
+}
+
+constexpr int block_lds_floats(int KT) { return 3 * D * PK + 3 * D + 5 * 16 * KT * PK + WAVES * 16 * PK + 2 * D * D + 2 * D; }
+
+template <int KT>
+__global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kernel(BlockArgs a) {
+  constexpr int MK = 16 * KT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // block_lds_floats(KT): in-projection image, bias,
+  float *const Wi = lds, *const bi = Wi + 3 * D * PK;               // key rows of x / K / V / dK / dV, wave scratch,
+  float *const kvs = bi + 3 * D, *const scrs = kvs + 5 * MK * PK;   // Wk / Wv (+ bias) gradients of this workgroup
+  float *const gkv = scrs + WAVES * 16 * PK;
+  __shared__ int keyrow[MK];
+  __shared__ int wave_cnt[WAVES];
+  float *const Xk = kvs, *const Ks = kvs + MK * PK, *const Vs = kvs + 2 * MK * PK, *const dKs = kvs + 3 * MK * PK,
+               *const dVs = kvs + 4 * MK * PK;
+  static_assert(5 * MK * PK >= D * D + D, "gradient staging reuses the key-row arrays");
+  const Geo &g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gq = lane >> 4;
+  const int n_t = g.n_td + g.n_th;
+  for (int i = tid; i < 3 * D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
+  if (tid < 3 * D) bi[tid] = a.bin[tid];
+  for (int i = tid; i < 2 * D * D + 2 * D; i += THREADS) gkv[i] = 0.f;
+  const float scale = rsqrtf((float)HD);
+  float *scr = scrs + wave * 16 * PK;
+  f32x4 gWq[2][2];
+  float gBq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gWq[i][j] = zero4();
+  const int ntile = (g.N + 15) >> 4;
+
+  for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
+    const long ep = (long)b * g.N;
+    // first tile of this wave: its loads fly while the key list and K / V are built
+    f32x4 nx[2], ngo[2];
+    int nrole = 0;
+    {
+      const int row = min(wave * 16 + tok, g.N - 1);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        nx[mt] = ld4(a.X + (ep + row) * D + 16 * mt + 4 * gq);
+        ngo[mt] = ld4(a.dA + (ep + row) * D + 16 * mt + 4 * gq);
+      }
+      if (row < g.P) nrole = load_role(g, b, row);
+    }
+    __syncthreads();      // the previous instance is done with the arrays
+    // ---- key list: context points in slot order, then the visible targets ---------------------------------------
+    int n_ck = 0;
+    for (int c0 = 0; c0 < g.P; c0 += THREADS) {
+      const int row = c0 + tid;
+      const bool key = row < g.P && role_is_ctx(g, b, load_role(g, b, min(row, g.P - 1)));
+      const unsigned long long bal = __ballot(key);
+      if (lane == 0) wave_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int off = n_ck;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+      const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (key && k < MK) keyrow[k] = row;
+      n_ck += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+    n_ck = min(n_ck, MK);
+    int n_ak = n_ck;
+    for (int j = 0; j < n_t; ++j)
+      if ((!g.tmask || g.tmask[j]) && n_ak < MK) { if (tid == 0) keyrow[n_ak] = g.P + j; ++n_ak; }
+    __syncthreads();
+    const int nkt = (n_ak + 15) >> 4;
+    for (int i = tid; i < 16 * nkt * 8; i += THREADS) {
+      const int j = i >> 3, c4 = (i & 7) * 4;
+      *reinterpret_cast<f32x4 *>(Xk + j * PK + c4) = j < n_ak ? ld4(a.X + (ep + keyrow[j]) * D + c4) : zero4();
+      *reinterpret_cast<f32x4 *>(dKs + j * PK + c4) = zero4();
+      *reinterpret_cast<f32x4 *>(dVs + j * PK + c4) = zero4();
+    }
+    __syncthreads();
+    // ---- K, V of the key rows (T layout: key on lane) -------------------------------------------------------------
+    for (int u = wave; u < 2 * nkt; u += WAVES) {
+      const int kt = u >> 1, which = u & 1;
+      const f32x4 xin[2] = {ld4(Xk + (16 * kt + tok) * PK + 4 * gq), ld4(Xk + (16 * kt + tok) * PK + 16 + 4 * gq)};
+      f32x4 acc[2] = {ld4(bi + D * (1 + which) + 4 * gq), ld4(bi + D * (1 + which) + 16 + 4 * gq)};
+      tailbwd::mm_fwd<2, 2>(acc, Wi + D * (1 + which) * PK, PK, xin, tok, gq);
+      float *dst = (which ? Vs : Ks) + (16 * kt + tok) * PK + 4 * gq;
+      *reinterpret_cast<f32x4 *>(dst) = acc[0];
+      *reinterpret_cast<f32x4 *>(dst + 16) = acc[1];
+    }
+    __syncthreads();
+
+    f32x4 dKt[2][KT], dVt[2][KT];      // [chan 16 mt + 4 g + r][key 16 kt + tok], summed over this wave's tiles
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) { dKt[mt][kt] = zero4(); dVt[mt][kt] = zero4(); }
+    for (int tile = wave; tile < ntile; tile += WAVES) {
+      const int row = tile * 16 + tok;
+      const bool ok = row < g.N;
+      const int rc = ok ? row : g.N - 1;
+      const bool isq = ok && row < g.P && !role_is_ctx(g, b, nrole);
+      const int nk = !ok ? 0 : (isq ? n_ak : n_ck);
+      f32x4 x[2], q[2], go[2], dq[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        x[mt] = nx[mt];
+        go[mt] = ok ? ngo[mt] : zero4();
+        q[mt] = ld4(bi + 16 * mt + 4 * gq);
+        dq[mt] = zero4();
+      }
+      if (tile + WAVES < ntile) {      // the next tile's rows
+        const int nr = min(row + 16 * WAVES, g.N - 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          nx[mt] = ld4(a.X + (ep + nr) * D + 16 * mt + 4 * gq);
+          ngo[mt] = ld4(a.dA + (ep + nr) * D + 16 * mt + 4 * gq);
+        }
+        nrole = nr < g.P ? load_role(g, b, nr) : 0;
+      }
+      tailbwd::mm_fwd<2, 2>(q, Wi, PK, x, tok, gq);
+      q[0] *= scale; q[1] *= scale;
+      f32x4 qN[2], goN[2];
+      tailbwd::to_n(qN, q[0], q[1], scr, tok, gq);
+      tailbwd::to_n(goN, go[0], go[1], scr, tok, gq);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int mt = h >> 1, hg = h & 1;
+        const bool mine_g = (gq >> 1) == hg;      // this lane group's channels 16 mt + 4 g + r belong to head h (k axis)
+        const bool mine_c = (tok >> 3) == hg;     // channel 16 mt + tok belongs to head h (i axis)
+        f32x4 s[KT], dp[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          s[kt] = zero4(); dp[kt] = zero4();
+          if (kt < nkt) {
+            const f32x4 kf = mine_g ? ld4(Ks + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
+            const f32x4 vf = mine_g ? ld4(Vs + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { MFMA4(s[kt], kf[r], q[mt][r]); MFMA4(dp[kt], vf[r], go[mt][r]); }
+          }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (16 * kt + 4 * gq + r < nk) mx = fmaxf(mx, s[kt][r]);
+        mx = group_max(mx);
+        float l = 0.f, delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = 16 * kt + 4 * gq + r < nk ? __expf(s[kt][r] - mx) : 0.f;
+            s[kt][r] = e;
+            l += e;
+            delta = fmaf(e, dp[kt][r], delta);
+          }
+        l = group_sum(l);
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        delta = group_sum(delta) * inv;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = s[kt][r] * inv;
+            s[kt][r] = p;
+            dp[kt][r] = p * (dp[kt][r] - delta);      // dS^T
+          }
+        const f32x4 goA = mine_c ? goN[mt] : zero4(), qA = mine_c ? qN[mt] : zero4();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float ka = mine_c ? Ks[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok] : 0.f;
+              MFMA4(dq[mt], ka, dp[kt][r]);
+            }
+            f32x4 pn[2];
+            tailbwd::to_n(pn, s[kt], dp[kt], scr, tok, gq);      // pn[0] = P_N, pn[1] = dS_N  (key on lane, row on (g, r))
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { MFMA4(dVt[mt][kt], goA[r], pn[0][r]); MFMA4(dKt[mt][kt], qA[r], pn[1][r]); }
+          }
+        }
+      }
+      dq[0] *= scale; dq[1] *= scale;
+      f32x4 dxo[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) dxo[mt] = ok ? ld4(a.dX + (ep + rc) * D + 16 * mt + 4 * gq) : zero4();
+      tailbwd::mm_bwd<2, 2>(dxo, Wi, PK, dq, tok, gq);          // dx = du1 + Wq^T dq
+      if (ok) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4 *>(a.dX + (ep + row) * D + 16 * mt + 4 * gq) = dxo[mt];
+      }
+      f32x4 dqN[2], xN[2];
+      tailbwd::to_n(dqN, dq[0], dq[1], scr, tok, gq);
+      tailbwd::to_n(xN, x[0], x[1], scr, tok, gq);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        tailbwd::mm_dw(gWq[i][0], dqN[i], xN[0]);
+        tailbwd::mm_dw(gWq[i][1], dqN[i], xN[1]);
+        gBq[i] += tailbwd::sum4(dqN[i]);
+      }
+    }
+    // ---- dK / dV of the key rows: sum over the waves through LDS ---------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+        if (kt < nkt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(&dKs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dKt[mt][kt][r]);
+            atomicAdd(&dVs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dVt[mt][kt][r]);
+          }
+        }
+    __syncthreads();      // (also: every wave's dX rows are stored before the key rows are updated)
+    // ---- key rows: dx += Wk^T dK + Wv^T dV; one (key tile, 16 input features) unit per wave at a time ---------------
+    for (int u = wave; u < 2 * nkt; u += WAVES) {
+      const int kt = u >> 1, ib = u & 1;
+      const int key = 16 * kt + tok;
+      float *dst = a.dX + (ep + keyrow[min(key, n_ak - 1)]) * D + 16 * ib + 4 * gq;
+      const f32x4 old = ld4(dst);
+      const f32x4 dk[2] = {ld4(dKs + key * PK + 4 * gq), ld4(dKs + key * PK + 16 + 4 * gq)};
+      const f32x4 dv[2] = {ld4(dVs + key * PK + 4 * gq), ld4(dVs + key * PK + 16 + 4 * gq)};
+      f32x4 acc[1] = {zero4()};
+      tailbwd::mm_bwd<1, 2>(acc, Wi + D * PK + 16 * ib, PK, dk, tok, gq);
+      tailbwd::mm_bwd<1, 2>(acc, Wi + 2 * D * PK + 16 * ib, PK, dv, tok, gq);
+      if (key < n_ak) *reinterpret_cast<f32x4 *>(dst) = old + acc[0];
+    }
+    // ---- Wk / Wv gradients: contraction over the keys of a tile (N-layout operands read column-wise from LDS), added
+    // to the workgroup's LDS accumulators (32 registers per wave that would otherwise stay resident for this alone)
+    for (int kt = wave; kt < nkt; kt += WAVES) {
+      f32x4 kN[2], vN[2], xkN[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (16 * kt + 4 * gq + r) * PK + 16 * i + tok;
+          kN[i][r] = dKs[o]; vN[i][r] = dVs[o]; xkN[i][r] = Xk[o];
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 wk = zero4(), wv = zero4();
+          tailbwd::mm_dw(wk, kN[i], xkN[j]);
+          tailbwd::mm_dw(wv, vN[i], xkN[j]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(&gkv[(16 * i + 4 * gq + r) * D + 16 * j + tok], wk[r]);
+            atomicAdd(&gkv[D * D + (16 * i + 4 * gq + r) * D + 16 * j + tok], wv[r]);
+          }
+        }
+        atomicAdd(&gkv[2 * D * D + 16 * i + tok], tailbwd::sum4(kN[i]));
+        atomicAdd(&gkv[2 * D * D + D + 16 * i + tok], tailbwd::sum4(vN[i]));
+      }
+    }
+  }
+  // ---- the workgroup's in-projection gradients: LDS staging, then one atomic per element ----------------------------
+  __syncthreads();
+  float *stg = kvs;      // Wq [32][32], then bq [32]
+  for (int i = tid; i < D * D + D; i += THREADS) stg[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&stg[(16 * i + 4 * gq + r) * D + 16 * j + tok], gWq[i][j][r]);
+    atomicAdd(&stg[D * D + 16 * i + tok], gBq[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwin + i, stg[i]);
+  for (int i = tid; i < 2 * D * D; i += THREADS) unsafeAtomicAdd(a.dwin + D * D + i, gkv[i]);
+  if (tid < D) unsafeAtomicAdd(a.dbin + tid, stg[D * D + tid]);
+  if (tid < 2 * D) unsafeAtomicAdd(a.dbin + D + tid, gkv[2 * D * D + tid]);
+}
+
 }  // namespace abwd
