@@ -1457,7 +1457,7 @@ static int bwd_prec() {
 namespace {
 
 struct BwdPlan {
-  size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt,
+  size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt, KeyIdx, Kcnt,
       total;
 };
 
@@ -1504,6 +1504,8 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   p.dEx = take(rows_x * d);
   p.dEy = take(rows_y * d);
   p.Wt = take(std::max({(size_t)3 * d * d, F * d, (size_t)m.C * F * d}));
+  p.KeyIdx = take(M);      // (ints) key rows of every instance: K / V of the forward recompute on these rows only
+  p.Kcnt = take(I * 2);
   p.total = off;
   return p;
 }
@@ -1545,6 +1547,12 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
   a.X = X; a.ldx = ldx; a.Rx = Rx; a.Gx = Gx; a.offx = offx;
   a.dW = dW; a.ldw = K; a.db = db; a.M = M; a.N = N; a.K = K;
   a.mchunk = 4096;
+  // short products (the GMM heads see n_t target rows per instance: 60 000 rows at the headline shape) would run on M / 4096
+  // = 15 workgroups (0.21 ms each, ten of them per step): shrink the chunk until ~512 workgroups exist
+  {
+    const long blocks_nk = (long)std::max(1, std::max(N, K) / 128) * (std::min(N, K) / 32);
+    while (a.mchunk > 256 && ((M + a.mchunk - 1) / a.mchunk) * blocks_nk < 512) a.mchunk /= 2;
+  }
   // the block kernel reads its wide operand once per 32 columns of the other one: let the wider matrix be the wide one
   if (K > N && K % 64 == 0) {
     std::swap(a.dY, a.X); std::swap(a.ldy, a.ldx); std::swap(a.Ry, a.Rx); std::swap(a.Gy, a.Gx); std::swap(a.offy, a.offx);
@@ -1608,12 +1616,12 @@ int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, 
   a.X = X; a.A = A; a.dY = dY; a.Y = Y; a.dA = dA; a.dU = dU; a.M = M;
   a.wo = m.out_proj_w[l]; a.bo = m.out_proj_b[l]; a.w1 = m.lin1_w[l]; a.b1 = m.lin1_b[l]; a.w2 = m.lin2_w[l]; a.b2 = m.lin2_b[l];
   a.g1 = m.norm1_w[l]; a.e1 = m.norm1_b[l]; a.g2 = m.norm2_w[l]; a.e2 = m.norm2_b[l];
-  const size_t smem = tailbwd::LDS_FLOATS * sizeof(float);
+  const size_t smem = (dY ? tailbwd::LDS_FLOATS : tailbwd::LDS_FLOATS_FWD) * sizeof(float);
   const long groups = ((M + 15) / 16 + tailbwd::WAVES - 1) / tailbwd::WAVES;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS * (int)sizeof(float));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_FWD * (int)sizeof(float));
     attr = true;
   }
   if (!dY) {
@@ -1719,9 +1727,25 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     } else if (do_enc) {
       (void)hipMemcpyAsync(Xs(0), io.x_in, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, c.st);
     }
+    // With the fused attention-block backward nothing downstream reads QKV: Q for every row, K / V for the key rows only
+    // (key_list_kernel + row-gather GEMM, as the generic rollout pipeline does), one buffer for all layers.
+    const bool ckv = do_enc && fused_attn_block(*m, max_keys) && hd == abwd::HD && max_keys < N;
+    int *keyidx = reinterpret_cast<int *>(c.at(c.pl.KeyIdx)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.Kcnt));
+    if (ckv) {
+      hipLaunchKernelGGL(key_list_kernel, dim3(I), dim3(256), 0, c.st, g, max_keys, keyidx, kcnt);
+      CHECK_LAUNCH();
+    }
     for (int l = 0; l < L && do_enc; ++l) {
-      TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
       Ctx fc; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
+      if (ckv) {
+        float *Q = QKVl(0), *KVc = Q + (size_t)M * d;
+        TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, Q, d, (int)M, d, d, false), 1, c.st));
+        GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, KVc, 2 * d, I * max_keys, 2 * d, d, false);
+        ka.row_index = keyidx;
+        TRY(launch_gemm(bwd_prec(), ka, 1, c.st));
+        TRY(launch_attention<8>(fc, Q, Al(l), max_keys, KVc, kcnt));
+      } else {
+      TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
       switch (hd) {
         case 4: TRY(launch_attention<4>(fc, QKVl(l), Al(l), max_keys)); break;
         case 8: TRY(launch_attention<8>(fc, QKVl(l), Al(l), max_keys)); break;
@@ -1729,6 +1753,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         case 32: TRY(launch_attention<32>(fc, QKVl(l), Al(l), max_keys)); break;
         case 64: TRY(launch_attention<64>(fc, QKVl(l), Al(l), max_keys)); break;
         default: return ALINE_EUNSUPPORTED;
+      }
       }
       if (ft) { TRY(launch_tail(c, l, Xs(l), Al(l), Xs(l + 1), nullptr, nullptr, nullptr, nullptr, M)); continue; }
       TRY(launch_gemm(bwd_prec(), gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void attention_bwd_mfma_kernel(Geo g, cons
           const f32x4 kf = mine_g ? ld4(Ks + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
           const f32x4 vf = mine_g ? ld4(Vs + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { MFMA4(s[kt], kf[r], q[mt][r]); MFMA4(dp[kt], vf[r], go[mt][r]); }
+          for (int r = 0; r < 4; ++r) { MFMAO(s[kt], kf[r], q[mt][r]); MFMAO(dp[kt], vf[r], go[mt][r]); }
         }
       }
       // softmax over the keys (register axis x lane groups), delta, score gradient
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(THREADS) void attention_bwd_mfma_kernel(Geo g, cons
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float ka = mine_c ? Ks[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok] : 0.f;
-            MFMA4(dq[mt], ka, dp[kt][r]);
+            MFMAO(dq[mt], ka, dp[kt][r]);
           }
           f32x4 pn[2];
           tailbwd::to_n(pn, s[kt], dp[kt], scr, tok, gq);      // pn[0] = P_N, pn[1] = dS_N  (key on lane, row on (g, r))
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { MFMA4(dVt[mt][kt], goA[r], pn[0][r]); MFMA4(dKt[mt][kt], qA[r], pn[1][r]); }
+          for (int r = 0; r < 4; ++r) { MFMAO(dVt[mt][kt], goA[r], pn[0][r]); MFMAO(dKt[mt][kt], qA[r], pn[1][r]); }
         }
       }
     }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
             const f32x4 kf = mine_g ? ld4(Ks + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
             const f32x4 vf = mine_g ? ld4(Vs + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { MFMA4(s[kt], kf[r], q[mt][r]); MFMA4(dp[kt], vf[r], go[mt][r]); }
+            for (int r = 0; r < 4; ++r) { MFMAO(s[kt], kf[r], q[mt][r]); MFMAO(dp[kt], vf[r], go[mt][r]); }
           }
         }
         float mx = -INFINITY;
@@ -388,12 +388,12 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float ka = mine_c ? Ks[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok] : 0.f;
-              MFMA4(dq[mt], ka, dp[kt][r]);
+              MFMAO(dq[mt], ka, dp[kt][r]);
             }
             f32x4 pn[2];
             tailbwd::to_n(pn, s[kt], dp[kt], scr, tok, gq);      // pn[0] = P_N, pn[1] = dS_N  (key on lane, row on (g, r))
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { MFMA4(dVt[mt][kt], goA[r], pn[0][r]); MFMA4(dKt[mt][kt], qA[r], pn[1][r]); }
+            for (int r = 0; r < 4; ++r) { MFMAO(dVt[mt][kt], goA[r], pn[0][r]); MFMAO(dKt[mt][kt], qA[r], pn[1][r]); }
           }
         }
       }

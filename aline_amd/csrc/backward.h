@@ -442,7 +442,9 @@ struct GmmBwdArgs {
   const float *g_ll;                           // [rows] dLoss/d ll, or null
   const float *g_mean, *g_std, *g_wgt;         // [rows, C] dLoss/d mixture_{means,stds,weights}, or null
 };
-constexpr int GMM_BWD_ROWS = 64;   // rows per workgroup (16 per wave): weight-gradient partials stay in registers
+constexpr int GMM_BWD_ROWS = 256;  // rows per workgroup (64 per wave): weight-gradient partials stay in registers, are summed over the
+                                   // waves in LDS and leave as one atomic per element and workgroup (with 64 rows and one atomic per wave the
+                                   // 3 C F addresses took 3 752 contended adds each at the headline shape: 1.7 ms)
 __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long r_lo = (long)blockIdx.x * GMM_BWD_ROWS, r_hi = min(a.rows, r_lo + GMM_BWD_ROWS);
@@ -531,6 +533,9 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
       }
     }
   }
+  __shared__ float red[16 * 3 * 128 + 16 * 3];
+  for (int e = threadIdx.x; e < 16 * 3 * 128 + 16 * 3; e += 256) red[e] = 0.f;
+  __syncthreads();
   if (!wide_f) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -539,12 +544,22 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
         const int f = lane + 64 * n;
         if (c < a.C && f < a.F) {
 #pragma unroll
-          for (int o = 0; o < 3; ++o) atomicAdd(a.dw2[c] + o * a.F + f, pw[c][o][n]);
+          for (int o = 0; o < 3; ++o) atomicAdd(&red[(c * 3 + o) * 128 + f], pw[c][o][n]);
         }
       }
     }
   }
-  if (lane < a.C) { atomicAdd(a.db2[lane] + 0, pb0); atomicAdd(a.db2[lane] + 1, pb1); atomicAdd(a.db2[lane] + 2, pb2); }
+  if (lane < a.C) {
+    atomicAdd(&red[16 * 3 * 128 + lane * 3 + 0], pb0); atomicAdd(&red[16 * 3 * 128 + lane * 3 + 1], pb1);
+    atomicAdd(&red[16 * 3 * 128 + lane * 3 + 2], pb2);
+  }
+  __syncthreads();
+  if (!wide_f)
+    for (int e = threadIdx.x; e < a.C * 3 * 128; e += 256) {
+      const int c = e / 384, o = (e / 128) % 3, f = e & 127;
+      if (f < a.F) atomicAdd(a.dw2[c] + o * a.F + f, red[e]);
+    }
+  if (threadIdx.x < a.C * 3) atomicAdd(a.db2[threadIdx.x / 3] + threadIdx.x % 3, red[16 * 3 * 128 + threadIdx.x]);
 }
 
 // Gradient of the step-invariant embeddings: X0[(t,b), row] = Ex[b, row] (+ Ey[b, p] while p is context),

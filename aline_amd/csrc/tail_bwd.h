@@ -31,9 +31,9 @@ constexpr int PW = 36, PW2 = 132;                      // LDS row pitches (float
 constexpr int L_WO = 0, L_W1 = L_WO + D * PW, L_W2 = L_W1 + F * PW, L_PRM = L_W2 + D * PW2;
 constexpr int P_BO = 0, P_B1 = 32, P_B2 = 160, P_G1 = 192, P_E1 = 224, P_G2 = 256, P_E2 = 288, NPRM = 320;
 constexpr int L_SCR = L_PRM + NPRM;
-constexpr int SCR = 16 * PW;
+constexpr int SCR = 2 * 16 * PW;       // two 16 x 32 blocks per wave (backward only)
 constexpr int WAVES = 4, THREADS = 64 * WAVES;
-constexpr int LDS_FLOATS = L_SCR + WAVES * SCR;       // 12608 floats = 50.4 KB
+constexpr int LDS_FLOATS_FWD = L_SCR, LDS_FLOATS = L_SCR + WAVES * SCR;       // 41.2 KB forward, 59.6 KB backward
 // gradient staging, reusing the image region after the tile loop
 constexpr int G_WO = 0, G_W1 = G_WO + D * D, G_W2 = G_W1 + F * D, G_PRM = G_W2 + D * F, G_TOT = G_PRM + NPRM;
 static_assert(G_TOT <= L_SCR, "gradient staging must fit below the scratch");
@@ -51,6 +51,15 @@ struct Args {
 using fused::ld4;
 using fused::group_sum;
 
+// An MFMA whose place among the other MFMAs is the one written here: hipcc's scheduler otherwise groups the MFMAs of one
+// accumulator back to back (a dependent v_mfma_f32_16x16x4_f32 issues every ~50 cycles instead of 32; measured 52 cycles
+// per MFMA in tail_kernel<false>).  Everything that is not an MFMA may still move across (mask 0x7F6).
+#define MFMAO(acc, a, b)                                              \
+  do {                                                                \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);   \
+    __builtin_amdgcn_sched_barrier(0x7F6);                            \
+  } while (0)
+
 // acc[ob] += W[16 ob + tok][16 kb + 4 g + r] * in[kb][r]   (Y^T = W X^T; W row-major [out][in] in LDS)
 template <int NOB, int NKB>
 __device__ __forceinline__ void mm_fwd(f32x4 (&acc)[NOB], const float *W, int pitch, const f32x4 (&in)[NKB], int tok, int g) {
@@ -62,7 +71,7 @@ __device__ __forceinline__ void mm_fwd(f32x4 (&acc)[NOB], const float *W, int pi
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int ob = 0; ob < NOB; ++ob) MFMA4(acc[ob], w[ob][r], in[kb][r]);
+      for (int ob = 0; ob < NOB; ++ob) MFMAO(acc[ob], w[ob][r], in[kb][r]);
   }
 }
 // acc[ib] += W[16 kb + 4 g + r][16 ib + tok] * dy[kb][r]    (dX^T = W^T dY^T; same image, column reads)
@@ -76,13 +85,13 @@ __device__ __forceinline__ void mm_bwd(f32x4 (&acc)[NIB], const float *W, int pi
 #pragma unroll
       for (int ib = 0; ib < NIB; ++ib) w[ib] = W[(16 * kb + 4 * g + r) * pitch + 16 * ib + tok];
 #pragma unroll
-      for (int ib = 0; ib < NIB; ++ib) MFMA4(acc[ib], w[ib], dy[kb][r]);
+      for (int ib = 0; ib < NIB; ++ib) MFMAO(acc[ib], w[ib], dy[kb][r]);
     }
 }
 // dW tile += sum over the 16 rows of the tile  a_N[.][i] * b_N[.][j]
 __device__ __forceinline__ void mm_dw(f32x4 &acc, const f32x4 &aN, const f32x4 &bN) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) MFMA4(acc, aN[r], bN[r]);
+  for (int r = 0; r < 4; ++r) MFMAO(acc, aN[r], bN[r]);
 }
 // T layout -> N layout of a 16 x 32 block through the wave's scratch (DS operations of a wave execute in order)
 __device__ __forceinline__ void to_n(f32x4 (&out)[2], const f32x4 &in0, const f32x4 &in1, float *scr, int tok, int g) {
@@ -94,6 +103,30 @@ __device__ __forceinline__ void to_n(f32x4 (&out)[2], const f32x4 &in0, const f3
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[mt][r] = scr[(4 * g + r) * PW + 16 * mt + tok];
   asm volatile("" ::: "memory");
+}
+// two blocks in one LDS round trip (the wave's scratch holds two 16 x 32 blocks)
+__device__ __forceinline__ void to_n2(f32x4 (&o0)[2], f32x4 (&o1)[2], const f32x4 &a0, const f32x4 &a1, const f32x4 &b0,
+                                      const f32x4 &b1, float *scr, int tok, int g) {
+  *reinterpret_cast<f32x4 *>(scr + tok * PW + 4 * g) = a0;
+  *reinterpret_cast<f32x4 *>(scr + tok * PW + 16 + 4 * g) = a1;
+  *reinterpret_cast<f32x4 *>(scr + 16 * PW + tok * PW + 4 * g) = b0;
+  *reinterpret_cast<f32x4 *>(scr + 16 * PW + tok * PW + 16 + 4 * g) = b1;
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o0[mt][r] = scr[(4 * g + r) * PW + 16 * mt + tok];
+      o1[mt][r] = scr[16 * PW + (4 * g + r) * PW + 16 * mt + tok];
+    }
+  asm volatile("" ::: "memory");
+}
+// four weight-gradient tiles at once, MFMA by MFMA over independent accumulators (a dependent 16x16x4 MFMA waits 40 cycles)
+__device__ __forceinline__ void mm_dw4(f32x4 &c0, f32x4 &c1, f32x4 &c2, f32x4 &c3, const f32x4 &a0, const f32x4 &b0,
+                                       const f32x4 &a1, const f32x4 &b1, const f32x4 &a2, const f32x4 &b2, const f32x4 &a3,
+                                       const f32x4 &b3) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { MFMAO(c0, a0[r], b0[r]); MFMAO(c1, a1[r], b1[r]); MFMAO(c2, a2[r], b2[r]); MFMAO(c3, a3[r], b3[r]); }
 }
 // u <- (u - mean) * rstd over the 32 features of each row (eps 1e-5, biased variance); returns rstd
 __device__ __forceinline__ float normalise(f32x4 (&u)[2]) {
@@ -174,7 +207,20 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
   }
 
   const long ntiles = (a.M + 15) / 16;
-  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long)gridDim.x * WAVES) {
+  const long tstep = (long)gridDim.x * WAVES;
+  // the tile after this one is loaded while this one is computed (one wave per SIMD: nobody else hides the latency)
+  f32x4 nx[2], na[2], ndy[2];
+  auto load_tile = [&](long tile) {
+    const long r = min(tile * 16 + tok, a.M - 1);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      nx[mt] = ld4(a.X + r * D + 16 * mt + 4 * g);
+      na[mt] = ld4(a.A + r * D + 16 * mt + 4 * g);
+      if (BWD) ndy[mt] = ld4(a.dY + r * D + 16 * mt + 4 * g);
+    }
+  };
+  if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
     // opaque base: the images are loop-invariant, and hoisted weight fragments would take every register
     int zoff = 0;
     asm volatile("" : "+v"(zoff));
@@ -182,14 +228,14 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
     float *scr = lds + zoff + L_SCR + wave * SCR;
     const long row = tile * 16 + tok;
     const bool ok = row < a.M;
-    const long rc = ok ? row : a.M - 1;
     f32x4 x[2], at[2], dy[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      x[mt] = ld4(a.X + rc * D + 16 * mt + 4 * g);
-      at[mt] = ld4(a.A + rc * D + 16 * mt + 4 * g);
-      if (BWD) dy[mt] = ok ? ld4(a.dY + rc * D + 16 * mt + 4 * g) : fused::zero4();
+      x[mt] = nx[mt];
+      at[mt] = na[mt];
+      if (BWD) dy[mt] = ok ? ndy[mt] : fused::zero4();
     }
+    if (tile + tstep < ntiles) load_tile(tile + tstep);
     // ---- forward ---------------------------------------------------------------------------------------------
     f32x4 n1[2];
 #pragma unroll
@@ -225,8 +271,7 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
     f32x4 du2[2];
     ln_backward(du2, dy, n2, rstd2, prm + P_G2, gG2, gE2, g);
     f32x4 du2N[2], x1N[2];
-    to_n(du2N, du2[0], du2[1], scr, tok, g);
-    to_n(x1N, x1[0], x1[1], scr, tok, g);
+    to_n2(du2N, x1N, du2[0], du2[1], x1[0], x1[1], scr, tok, g);
     gB2[0] += sum4(du2N[0]); gB2[1] += sum4(du2N[1]);
     f32x4 dx1[2] = {du2[0], du2[1]};
 #pragma unroll
@@ -239,14 +284,11 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
         for (int r = 0; r < 4; ++r) dh[j][r] = h[2 * kc + j][r] > 0.f ? dh[j][r] : 0.f;
       mm_bwd<2, 2>(dx1, W + L_W1 + 32 * kc * PW, PW, dh, tok, g);
       f32x4 hN[2], dhN[2];
-      to_n(hN, h[2 * kc], h[2 * kc + 1], scr, tok, g);
-      to_n(dhN, dh[0], dh[1], scr, tok, g);
+      to_n2(hN, dhN, h[2 * kc], h[2 * kc + 1], dh[0], dh[1], scr, tok, g);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        mm_dw(gW2[0][2 * kc + j], du2N[0], hN[j]);
-        mm_dw(gW2[1][2 * kc + j], du2N[1], hN[j]);
-        mm_dw(gW1[2 * kc + j][0], dhN[j], x1N[0]);
-        mm_dw(gW1[2 * kc + j][1], dhN[j], x1N[1]);
+        mm_dw4(gW2[0][2 * kc + j], gW2[1][2 * kc + j], gW1[2 * kc + j][0], gW1[2 * kc + j][1], du2N[0], hN[j], du2N[1], hN[j],
+               dhN[j], x1N[0], dhN[j], x1N[1]);
         gB1[2 * kc + j] += sum4(dhN[j]);
       }
     }
@@ -262,14 +304,9 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
       }
     }
     f32x4 du1N[2], aN[2];
-    to_n(du1N, du1[0], du1[1], scr, tok, g);
-    to_n(aN, at[0], at[1], scr, tok, g);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      mm_dw(gWo[i][0], du1N[i], aN[0]);
-      mm_dw(gWo[i][1], du1N[i], aN[1]);
-      gBo[i] += sum4(du1N[i]);
-    }
+    to_n2(du1N, aN, du1[0], du1[1], at[0], at[1], scr, tok, g);
+    mm_dw4(gWo[0][0], gWo[0][1], gWo[1][0], gWo[1][1], du1N[0], aN[0], du1N[0], aN[1], du1N[1], aN[0], du1N[1], aN[1]);
+    gBo[0] += sum4(du1N[0]); gBo[1] += sum4(du1N[1]);
   }
   if (!BWD) return;
 
