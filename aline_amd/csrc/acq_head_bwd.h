@@ -1,0 +1,177 @@
+// Acquisition head of the small-width model (d = 32, F = 128) in the TRAINING backward:
+//   logit_p = w2 . relu(W1 z_p + b1) + b2  for the candidate rows,  log_prob = log_softmax over the remaining candidates
+// (model/head.py:27-44; REINFORCE term of train_aline.py:113-125 through it).  Three kernels instead of five, and the
+// [I P, 128] hidden activations (3 GB per chunk at the headline shape, written once and read / rewritten four times by the
+// per-op pipeline: 15 GB, 5.4 ms) never exist:
+//   logit_kernel    z -> logit of every token row (16-row tile per wave, hidden units in registers)
+//   dlogit_kernel   one wave per (step, episode) instance: softmax over the remaining candidates, logit <- dLoss/dlogit
+//   bwd_kernel      recomputes the hidden units of a tile, dz = W1^T dh for every row (target rows get zeros: this is also
+//                   the initialisation of dLoss/dz), and keeps the dW1 / dw2 / db1 accumulators of the wave in registers.
+// Register layouts and helpers: tail_bwd.h (T / N layouts, exact fp32 16x16x4 MFMAs).
+#pragma once
+#include "tail_bwd.h"
+
+namespace acqb {
+
+constexpr int D = 32, F = 128, PW = tailbwd::PW;
+constexpr int L_W1 = 0, L_B1 = L_W1 + F * PW, L_W2 = L_B1 + F, L_SCR = L_W2 + F;
+constexpr int WAVES = 4, THREADS = 64 * WAVES, SCR = 2 * 16 * PW;
+constexpr int LDS_FLOATS_LOGIT = L_SCR, LDS_FLOATS = L_SCR + WAVES * SCR;
+// gradient staging of bwd_kernel, reusing the image region: dW1 [128][32] | db1 [128] | dw2 [128]
+static_assert(F * D + 2 * F <= L_SCR, "gradient staging must fit below the scratch");
+
+struct Args {
+  const float *Z;          // [M, 32] encoder output, every token row
+  float *logit;            // [M] logits (logit_kernel) / dLoss/dlogit (after dlogit_kernel; 0 on non-candidate rows)
+  float *dZ;               // [M, 32] (bwd_kernel) written for every row
+  long M;
+  const float *w1, *b1, *w2, *b2;
+  float *dw1, *db1, *dw2;
+};
+
+using fused::ld4;
+using fused::group_sum;
+using fused::zero4;
+
+__device__ __forceinline__ void load_image(float *lds, const Args &a, int tid) {
+  for (int i = tid; i < F * D; i += THREADS) lds[L_W1 + (i >> 5) * PW + (i & 31)] = a.w1[i];
+  if (tid < F) { lds[L_B1 + tid] = a.b1[tid]; lds[L_W2 + tid] = a.w2[tid]; }
+}
+
+__global__ __launch_bounds__(THREADS) void logit_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  load_image(lds, a, tid);
+  __syncthreads();
+  const float b2 = a.b2[0];
+  const long ntiles = (a.M + 15) / 16;
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long)gridDim.x * WAVES) {
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const float *W = lds + zoff;
+    const long row = tile * 16 + tok, rc = min(row, a.M - 1);
+    const f32x4 z[2] = {ld4(a.Z + rc * D + 4 * g), ld4(a.Z + rc * D + 16 + 4 * g)};
+    f32x4 h[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
+    tailbwd::mm_fwd<8, 2>(h, W + L_W1, PW, z, tok, g);
+    float s = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+      const f32x4 w2 = ld4(W + L_W2 + 16 * ob + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s = fmaf(relu_nn(h[ob][r]), w2[r], s);
+    }
+    s = group_sum(s) + b2;
+    if (g == 0 && row < a.M) a.logit[row] = s;
+  }
+}
+
+struct DlArgs {
+  Geo g;                   // instance mode
+  float *logit;            // [I N] in: logits, out: dLoss/dlogit
+  const float *g_logp;     // [B, T] dLoss/dlog_prob
+  const int32_t *slot;     // [B, T] chosen slot
+  int T;
+  float *db2;
+};
+// one wave per instance
+__global__ __launch_bounds__(256) void dlogit_kernel(DlArgs a) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= a.g.B) return;
+  const int P = a.g.P, N = a.g.N;
+  const int b = i % a.g.inst_B, t = a.g.inst_t0 + i / a.g.inst_B;
+  float *lg = a.logit + (long)i * N;
+  float mx = -INFINITY;
+  for (int p = lane; p < P; p += 64) if (!is_ctx(a.g, i, p)) mx = fmaxf(mx, lg[p]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int p = lane; p < P; p += 64) if (!is_ctx(a.g, i, p)) sum += __expf(lg[p] - mx);
+  const float inv = 1.f / wave_sum(sum);
+  const float gl = a.g_logp[(long)b * a.T + t];
+  const int chosen = a.slot[(long)b * a.T + t];
+  float dbl = 0.f;
+  for (int p = lane; p < N; p += 64) {
+    float dl = 0.f;
+    if (p < P && !is_ctx(a.g, i, p)) dl = gl * ((p == chosen ? 1.f : 0.f) - __expf(lg[p] - mx) * inv);
+    lg[p] = dl;
+    dbl += dl;
+  }
+  dbl = wave_sum(dbl);
+  if (lane == 0) atomicAdd(a.db2, dbl);
+}
+
+__global__ __launch_bounds__(THREADS) void bwd_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  load_image(lds, a, tid);
+  __syncthreads();
+  f32x4 gW1[8][2], gw2[8];      // dW1 tiles [16 ob + 4 g + r][16 jb + tok]; dw2 in the T layout (partial over the rows)
+  float gB1[8];                 // db1 in the N layout (feature 16 ob + tok, partial over the lane groups)
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) { gW1[ob][0] = gW1[ob][1] = gw2[ob] = zero4(); gB1[ob] = 0.f; }
+  const long ntiles = (a.M + 15) / 16;
+  const long tstep = (long)gridDim.x * WAVES;
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const float *W = lds + zoff;
+    float *scr = lds + zoff + L_SCR + wave * SCR;
+    const long row = tile * 16 + tok, rc = min(row, a.M - 1);
+    const bool ok = row < a.M;
+    const f32x4 z[2] = {ld4(a.Z + rc * D + 4 * g), ld4(a.Z + rc * D + 16 + 4 * g)};
+    const float dl = ok ? a.logit[rc] : 0.f;
+    f32x4 h[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
+    tailbwd::mm_fwd<8, 2>(h, W + L_W1, PW, z, tok, g);
+    // dw2 += dl h;  dh = dl w2 on the active units (h is overwritten by dh)
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+      const f32x4 w2 = ld4(W + L_W2 + 16 * ob + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = relu_nn(h[ob][r]);
+        gw2[ob][r] = fmaf(dl, hv, gw2[ob][r]);
+        h[ob][r] = hv > 0.f ? dl * w2[r] : 0.f;
+      }
+    }
+    f32x4 dz[2] = {zero4(), zero4()};
+    tailbwd::mm_bwd<2, 8>(dz, W + L_W1, PW, h, tok, g);
+    if (ok) {
+      *reinterpret_cast<f32x4 *>(a.dZ + row * D + 4 * g) = dz[0];
+      *reinterpret_cast<f32x4 *>(a.dZ + row * D + 16 + 4 * g) = dz[1];
+    }
+    f32x4 zN[2], dhN[2];
+    tailbwd::to_n2(zN, dhN, z[0], z[1], h[0], h[1], scr, tok, g);
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      f32x4 nxt[2];
+      if (kc < 3) tailbwd::to_n(nxt, h[2 * kc + 2], h[2 * kc + 3], scr, tok, g);
+      tailbwd::mm_dw4(gW1[2 * kc][0], gW1[2 * kc][1], gW1[2 * kc + 1][0], gW1[2 * kc + 1][1], dhN[0], zN[0], dhN[0], zN[1],
+                      dhN[1], zN[0], dhN[1], zN[1]);
+      gB1[2 * kc] += tailbwd::sum4(dhN[0]);
+      gB1[2 * kc + 1] += tailbwd::sum4(dhN[1]);
+      if (kc < 3) { dhN[0] = nxt[0]; dhN[1] = nxt[1]; }
+    }
+  }
+  // ---- the workgroup's gradients: LDS staging, then one atomic per element ---------------------------------------
+  __syncthreads();
+  for (int i = tid; i < F * D + 2 * F; i += THREADS) lds[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(&lds[(16 * ob + 4 * g + r) * D + tok], gW1[ob][0][r]);
+      atomicAdd(&lds[(16 * ob + 4 * g + r) * D + 16 + tok], gW1[ob][1][r]);
+      atomicAdd(&lds[F * D + F + 16 * ob + 4 * g + r], gw2[ob][r]);
+    }
+    atomicAdd(&lds[F * D + 16 * ob + tok], gB1[ob]);
+  }
+  __syncthreads();
+  for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1 + i, lds[i]);
+  if (tid < F) { unsafeAtomicAdd(a.db1 + tid, lds[F * D + tid]); unsafeAtomicAdd(a.dw2 + tid, lds[F * D + F + tid]); }
+}
+
+}  // namespace acqb

@@ -16,6 +16,7 @@
 #include "backward.h"
 #include "tail_bwd.h"
 #include "attn_bwd_mfma.h"
+#include "acq_head_bwd.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1469,6 +1470,13 @@ static bool bwd_fused_tail(const aline_model &m) {
   return on && m.d == tailbwd::D && m.F == tailbwd::F;
 }
 
+// Acquisition head backward without the [I P, F] hidden activations (acq_head_bwd.h).  ALINE_BWD_ACQ=0: the per-op kernels.
+static bool fused_acq_head(const aline_model &m) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("ALINE_BWD_ACQ"); on = e ? atoi(e) != 0 : 1; }
+  return on && m.d == acqb::D && m.F == acqb::F;
+}
+
 // In-projection + attention backward as one kernel (attn_bwd_mfma.h).  ALINE_BWD_ATTN_BLOCK=0: the per-op kernels.
 static bool fused_attn_block(const aline_model &m, int max_keys) {
   static int on = -1;
@@ -1490,7 +1498,7 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   p.X1 = take(ft ? 0 : L * M * d);
   p.Hid = take(ft ? 0 : L * M * F);
   p.U2 = take(ft ? 0 : L * M * d);
-  p.HidA = take(I * P * F);
+  p.HidA = take(fused_acq_head(m) ? 0 : I * P * F);
   p.HidG = take(I * n_t * m.C * F);
   p.dXa = take(M * d);
   p.dXb = take(M * d);
@@ -1764,10 +1772,13 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     }
     const float *Z = do_enc ? Xs(L) : io.z_in;
     float *HidA = c.at(c.pl.HidA), *HidG = c.at(c.pl.HidG);
+    const bool facq = do_head && fused_acq_head(*m);
     if (do_head) {
+      if (!facq) {
       GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, d, HidA, F, I * P, F, d, true);
       a.R_in = P; a.G_in = N; a.off_in = 0;
       TRY(launch_gemm(bwd_prec(), a, 1, c.st));
+      }
       GemmArgs ag = gemm_args(Z, d, nullptr, nullptr, d, HidG, C * F, I * n_t, F, d, true);
       ag.R_in = n_t; ag.G_in = N; ag.off_in = P; ag.col_per_group = F;
       for (int k = 0; k < C; ++k) { ag.W[k] = m->gmm_w1[k]; ag.bias[k] = m->gmm_b1[k]; }
@@ -1777,9 +1788,28 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
 
     // ---- heads backward -> dZ --------------------------------------------------------------------------
     float *dX = c.at(c.pl.dXa), *dXn = c.at(c.pl.dXb);
-    if (do_head) (void)hipMemsetAsync(dX, 0, (size_t)M * d * sizeof(float), c.st);
-    else (void)hipMemcpyAsync(dX, io.d_in, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, c.st);
-    if (do_head) {
+    if (do_head && !facq) (void)hipMemsetAsync(dX, 0, (size_t)M * d * sizeof(float), c.st);
+    else if (!do_head) (void)hipMemcpyAsync(dX, io.d_in, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+    if (facq) {            // logits -> dLoss/dlogit -> dz of every row (zeros on the target rows) + parameter gradients
+      acqb::Args a{};
+      a.Z = Z; a.logit = dTmp; a.dZ = dX; a.M = M;
+      a.w1 = m->acq_w1; a.b1 = m->acq_b1; a.w2 = m->acq_w2; a.b2 = m->acq_b2;
+      a.dw1 = gr->acq_w1; a.db1 = gr->acq_b1; a.dw2 = gr->acq_w2;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&acqb::bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, acqb::LDS_FLOATS * (int)sizeof(float));
+        attr = true;
+      }
+      const long groups = ((M + 15) / 16 + acqb::WAVES - 1) / acqb::WAVES;
+      hipLaunchKernelGGL(acqb::logit_kernel, dim3((unsigned)std::min<long>(groups, 256 * 4)), dim3(acqb::THREADS), acqb::LDS_FLOATS_LOGIT * sizeof(float), c.st, a);
+      CHECK_LAUNCH();
+      acqb::DlArgs dl{};
+      dl.g = g; dl.logit = dTmp; dl.g_logp = g_logp; dl.slot = r->slot; dl.T = r->T; dl.db2 = gr->acq_b2;
+      hipLaunchKernelGGL(acqb::dlogit_kernel, dim3((unsigned)((I + 3) / 4)), dim3(256), 0, c.st, dl);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(acqb::bwd_kernel, dim3((unsigned)std::min<long>(groups, 512)), dim3(acqb::THREADS), acqb::LDS_FLOATS * sizeof(float), c.st, a);
+      CHECK_LAUNCH();
+    } else if (do_head) {
       AcqBwdArgs a{};
       a.g = g; a.F = F; a.hid = HidA; a.w2 = m->acq_w2; a.b2 = m->acq_b2; a.g_logp = g_logp; a.slot = r->slot;
       a.T = r->T; a.dw2 = gr->acq_w2; a.db2 = gr->acq_b2;
