@@ -27,16 +27,23 @@
 namespace tailbwd {
 
 constexpr int D = 32, F = 128;
-constexpr int PW = 36, PW2 = 132;                      // LDS row pitches (floats): conflict-free b128 row reads and column reads
+#if !defined(TAIL_PW)
+#define TAIL_PW 36
+#define TAIL_PW2 132
+#endif
+constexpr int PW = TAIL_PW, PW2 = TAIL_PW2;                      // LDS row pitches (floats): conflict-free b128 row reads and column reads
 constexpr int L_WO = 0, L_W1 = L_WO + D * PW, L_W2 = L_W1 + F * PW, L_PRM = L_W2 + D * PW2;
 constexpr int P_BO = 0, P_B1 = 32, P_B2 = 160, P_G1 = 192, P_E1 = 224, P_G2 = 256, P_E2 = 288, NPRM = 320;
 constexpr int L_SCR = L_PRM + NPRM;
 constexpr int SCR = 2 * 16 * PW;       // two 16 x 32 blocks per wave (backward only)
 constexpr int WAVES = 4, THREADS = 64 * WAVES;
 constexpr int LDS_FLOATS_FWD = L_SCR, LDS_FLOATS = L_SCR + WAVES * SCR;       // 41.2 KB forward, 59.6 KB backward
+// backward with the weight-gradient accumulators in LDS (8 waves of <= 256 registers, two per SIMD): image | 8 scratches | sums
+constexpr int WAVES_ACC = 8, L_ACC = L_SCR + WAVES_ACC * SCR;
 // gradient staging, reusing the image region after the tile loop
 constexpr int G_WO = 0, G_W1 = G_WO + D * D, G_W2 = G_W1 + F * D, G_PRM = G_W2 + D * F, G_TOT = G_PRM + NPRM;
 static_assert(G_TOT <= L_SCR, "gradient staging must fit below the scratch");
+constexpr int LDS_FLOATS_ACC = L_ACC + G_TOT;      // 116 KB
 
 struct Args {
   const float *X, *A;        // [M, 32] layer input, attention output
@@ -54,11 +61,15 @@ using fused::group_sum;
 // An MFMA whose place among the other MFMAs is the one written here: hipcc's scheduler otherwise groups the MFMAs of one
 // accumulator back to back (a dependent v_mfma_f32_16x16x4_f32 issues every ~50 cycles instead of 32; measured 52 cycles
 // per MFMA in tail_kernel<false>).  Everything that is not an MFMA may still move across (mask 0x7F6).
+#if defined(TAIL_NO_MFMA)      // (tools/probes/tail_probe.hip: the kernel without its matrix instructions)
+#define MFMAO(acc, a, b) do { acc[0] += (a) * (b); } while (0)
+#else
 #define MFMAO(acc, a, b)                                              \
   do {                                                                \
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);   \
     __builtin_amdgcn_sched_barrier(0x7F6);                            \
   } while (0)
+#endif
 
 // acc[ob] += W[16 ob + tok][16 kb + 4 g + r] * in[kb][r]   (Y^T = W X^T; W row-major [out][in] in LDS)
 template <int NOB, int NKB>
@@ -172,11 +183,23 @@ __device__ __forceinline__ void ln_backward(f32x4 (&du)[2], const f32x4 (&dy)[2]
     for (int r = 0; r < 4; ++r) du[mt][r] = (du[mt][r] - m1 - n[mt][r] * m2) * rstd;
 }
 __device__ __forceinline__ float sum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+// tile (rb, cb) of a row-major [.., ld] LDS matrix += an MFMA accumulator tile ([16 rb + 4 g + r][16 cb + tok])
+__device__ __forceinline__ void lds_add_tile(float *base, int ld, int rb, int cb, const f32x4 &t, int tok, int g) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) atomicAdd(&base[(16 * rb + 4 * g + r) * ld + 16 * cb + tok], t[r]);
+}
 
-template <bool BWD>
-__global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
+// LDSACC (backward only; an experiment kept for tools/probes/tail_probe.hip, NOT used by the library): the 36 weight-gradient
+// tiles are not kept in registers (144 of them: 434 registers, one wave per SIMD, ~470 VGPR <-> AGPR moves per tile) but added
+// to a workgroup-wide LDS accumulator after every group of products, so that a wave fits 256 registers and two waves share a
+// SIMD.  Measured: 18.6 ms instead of 3.7 -- ds_add_f32 retires a few lanes per cycle, 9 216 lane-adds per tile swamp the LDS.
+template <bool BWD, bool LDSACC = false>
+__global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel(Args a) {
+  static_assert(BWD || !LDSACC, "LDS accumulation is a backward option");
+  constexpr int WAVES = LDSACC ? WAVES_ACC : tailbwd::WAVES, THREADS = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  if (LDSACC) for (int i = tid; i < G_TOT; i += THREADS) lds[L_ACC + i] = 0.f;
   for (int i = tid; i < D * D; i += THREADS) lds[L_WO + (i >> 5) * PW + (i & 31)] = a.wo[i];
   for (int i = tid; i < F * D; i += THREADS) lds[L_W1 + (i >> 5) * PW + (i & 31)] = a.w1[i];
   for (int i = tid; i < D * F; i += THREADS) lds[L_W2 + (i >> 7) * PW2 + (i & 127)] = a.w2[i];
@@ -219,7 +242,8 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
       if (BWD) ndy[mt] = ld4(a.dY + r * D + 16 * mt + 4 * g);
     }
   };
-  if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
+  constexpr bool PREF = !LDSACC;      // two waves per SIMD hide the load latency themselves, and the 24 registers are spills there
+  if (PREF && (long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
   for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
     // opaque base: the images are loop-invariant, and hoisted weight fragments would take every register
     int zoff = 0;
@@ -229,13 +253,14 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
     const long row = tile * 16 + tok;
     const bool ok = row < a.M;
     f32x4 x[2], at[2], dy[2];
+    if (!PREF) load_tile(tile);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       x[mt] = nx[mt];
       at[mt] = na[mt];
       if (BWD) dy[mt] = ok ? ndy[mt] : fused::zero4();
     }
-    if (tile + tstep < ntiles) load_tile(tile + tstep);
+    if (PREF && tile + tstep < ntiles) load_tile(tile + tstep);
     // ---- forward ---------------------------------------------------------------------------------------------
     f32x4 n1[2];
 #pragma unroll
@@ -287,8 +312,18 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
       to_n2(hN, dhN, h[2 * kc], h[2 * kc + 1], dh[0], dh[1], scr, tok, g);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        mm_dw4(gW2[0][2 * kc + j], gW2[1][2 * kc + j], gW1[2 * kc + j][0], gW1[2 * kc + j][1], du2N[0], hN[j], du2N[1], hN[j],
-               dhN[j], x1N[0], dhN[j], x1N[1]);
+        if (LDSACC) {
+          f32x4 t0 = fused::zero4(), t1 = fused::zero4(), t2 = fused::zero4(), t3 = fused::zero4();
+          mm_dw4(t0, t1, t2, t3, du2N[0], hN[j], du2N[1], hN[j], dhN[j], x1N[0], dhN[j], x1N[1]);
+          float *acc = lds + zoff + L_ACC;
+          lds_add_tile(acc + G_W2, F, 0, 2 * kc + j, t0, tok, g);
+          lds_add_tile(acc + G_W2, F, 1, 2 * kc + j, t1, tok, g);
+          lds_add_tile(acc + G_W1, D, 2 * kc + j, 0, t2, tok, g);
+          lds_add_tile(acc + G_W1, D, 2 * kc + j, 1, t3, tok, g);
+        } else {
+          mm_dw4(gW2[0][2 * kc + j], gW2[1][2 * kc + j], gW1[2 * kc + j][0], gW1[2 * kc + j][1], du2N[0], hN[j], du2N[1], hN[j],
+                 dhN[j], x1N[0], dhN[j], x1N[1]);
+        }
         gB1[2 * kc + j] += sum4(dhN[j]);
       }
     }
@@ -305,51 +340,66 @@ __global__ __launch_bounds__(THREADS) void tail_kernel(Args a) {
     }
     f32x4 du1N[2], aN[2];
     to_n2(du1N, aN, du1[0], du1[1], at[0], at[1], scr, tok, g);
-    mm_dw4(gWo[0][0], gWo[0][1], gWo[1][0], gWo[1][1], du1N[0], aN[0], du1N[0], aN[1], du1N[1], aN[0], du1N[1], aN[1]);
+    if (LDSACC) {
+      f32x4 t0 = fused::zero4(), t1 = fused::zero4(), t2 = fused::zero4(), t3 = fused::zero4();
+      mm_dw4(t0, t1, t2, t3, du1N[0], aN[0], du1N[0], aN[1], du1N[1], aN[0], du1N[1], aN[1]);
+      float *acc = lds + zoff + L_ACC;
+      lds_add_tile(acc + G_WO, D, 0, 0, t0, tok, g);
+      lds_add_tile(acc + G_WO, D, 0, 1, t1, tok, g);
+      lds_add_tile(acc + G_WO, D, 1, 0, t2, tok, g);
+      lds_add_tile(acc + G_WO, D, 1, 1, t3, tok, g);
+    } else {
+      mm_dw4(gWo[0][0], gWo[0][1], gWo[1][0], gWo[1][1], du1N[0], aN[0], du1N[0], aN[1], du1N[1], aN[0], du1N[1], aN[1]);
+    }
     gBo[0] += sum4(du1N[0]); gBo[1] += sum4(du1N[1]);
   }
   if (!BWD) return;
 
   // ---- the workgroup's gradients: LDS staging, then one atomic per element ------------------------------------
+  float *const stg = lds + (LDSACC ? L_ACC : 0);
   __syncthreads();
-  for (int i = tid; i < G_TOT; i += THREADS) lds[i] = 0.f;
-  __syncthreads();
+  if (!LDSACC) {
+    for (int i = tid; i < G_TOT; i += THREADS) stg[i] = 0.f;
+    __syncthreads();
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (!LDSACC) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) atomicAdd(&lds[G_WO + (16 * i + 4 * g + r) * D + 16 * j + tok], gWo[i][j][r]);
+        for (int j = 0; j < 2; ++j) atomicAdd(&stg[G_WO + (16 * i + 4 * g + r) * D + 16 * j + tok], gWo[i][j][r]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        atomicAdd(&lds[G_W1 + (16 * j + 4 * g + r) * D + 16 * i + tok], gW1[j][i][r]);
-        atomicAdd(&lds[G_W2 + (16 * i + 4 * g + r) * F + 16 * j + tok], gW2[i][j][r]);
+        for (int j = 0; j < 8; ++j) {
+          atomicAdd(&stg[G_W1 + (16 * j + 4 * g + r) * D + 16 * i + tok], gW1[j][i][r]);
+          atomicAdd(&stg[G_W2 + (16 * i + 4 * g + r) * F + 16 * j + tok], gW2[i][j][r]);
+        }
       }
-      atomicAdd(&lds[G_PRM + P_G1 + 16 * i + 4 * g + r], gG1[i][r]);
-      atomicAdd(&lds[G_PRM + P_E1 + 16 * i + 4 * g + r], gE1[i][r]);
-      atomicAdd(&lds[G_PRM + P_G2 + 16 * i + 4 * g + r], gG2[i][r]);
-      atomicAdd(&lds[G_PRM + P_E2 + 16 * i + 4 * g + r], gE2[i][r]);
+      atomicAdd(&stg[G_PRM + P_G1 + 16 * i + 4 * g + r], gG1[i][r]);
+      atomicAdd(&stg[G_PRM + P_E1 + 16 * i + 4 * g + r], gE1[i][r]);
+      atomicAdd(&stg[G_PRM + P_G2 + 16 * i + 4 * g + r], gG2[i][r]);
+      atomicAdd(&stg[G_PRM + P_E2 + 16 * i + 4 * g + r], gE2[i][r]);
     }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    atomicAdd(&lds[G_PRM + P_BO + 16 * i + tok], gBo[i]);
-    atomicAdd(&lds[G_PRM + P_B2 + 16 * i + tok], gB2[i]);
+    atomicAdd(&stg[G_PRM + P_BO + 16 * i + tok], gBo[i]);
+    atomicAdd(&stg[G_PRM + P_B2 + 16 * i + tok], gB2[i]);
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(&lds[G_PRM + P_B1 + 16 * j + tok], gB1[j]);
+  for (int j = 0; j < 8; ++j) atomicAdd(&stg[G_PRM + P_B1 + 16 * j + tok], gB1[j]);
   __syncthreads();
-  for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwo + i, lds[G_WO + i]);
-  for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1 + i, lds[G_W1 + i]);
-  for (int i = tid; i < D * F; i += THREADS) unsafeAtomicAdd(a.dw2 + i, lds[G_W2 + i]);
-  if (tid < F) unsafeAtomicAdd(a.db1 + tid, lds[G_PRM + P_B1 + tid]);
+  for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwo + i, stg[G_WO + i]);
+  for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1 + i, stg[G_W1 + i]);
+  for (int i = tid; i < D * F; i += THREADS) unsafeAtomicAdd(a.dw2 + i, stg[G_W2 + i]);
+  if (tid < F) unsafeAtomicAdd(a.db1 + tid, stg[G_PRM + P_B1 + tid]);
   if (tid < D) {
-    unsafeAtomicAdd(a.dbo + tid, lds[G_PRM + P_BO + tid]);
-    unsafeAtomicAdd(a.db2 + tid, lds[G_PRM + P_B2 + tid]);
-    unsafeAtomicAdd(a.dg1 + tid, lds[G_PRM + P_G1 + tid]);
-    unsafeAtomicAdd(a.de1 + tid, lds[G_PRM + P_E1 + tid]);
-    unsafeAtomicAdd(a.dg2 + tid, lds[G_PRM + P_G2 + tid]);
-    unsafeAtomicAdd(a.de2 + tid, lds[G_PRM + P_E2 + tid]);
+    unsafeAtomicAdd(a.dbo + tid, stg[G_PRM + P_BO + tid]);
+    unsafeAtomicAdd(a.db2 + tid, stg[G_PRM + P_B2 + tid]);
+    unsafeAtomicAdd(a.dg1 + tid, stg[G_PRM + P_G1 + tid]);
+    unsafeAtomicAdd(a.de1 + tid, stg[G_PRM + P_E1 + tid]);
+    unsafeAtomicAdd(a.dg2 + tid, stg[G_PRM + P_G2 + tid]);
+    unsafeAtomicAdd(a.de2 + tid, stg[G_PRM + P_E2 + tid]);
   }
 }
 
