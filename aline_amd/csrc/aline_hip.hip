@@ -1464,24 +1464,16 @@ struct BwdPlan {
 
 // Fused token-local tail (tail_bwd.h) for the small-width model: U1 / X1 / Hid / U2 are never stored.  ALINE_BWD_TAIL=0
 // switches back to the per-op pipeline (A/B measurements).
-static bool bwd_fused_tail(const aline_model &m) {
-  static int on = -1;
-  if (on < 0) { const char *e = getenv("ALINE_BWD_TAIL"); on = e ? atoi(e) != 0 : 1; }
-  return on && m.d == tailbwd::D && m.F == tailbwd::F;
-}
+// (the switches are read at every call: tests compare both pipelines in one process)
+static bool env_on(const char *name) { const char *e = getenv(name); return e ? atoi(e) != 0 : true; }
+static bool bwd_fused_tail(const aline_model &m) { return m.d == tailbwd::D && m.F == tailbwd::F && env_on("ALINE_BWD_TAIL"); }
 
 // Acquisition head backward without the [I P, F] hidden activations (acq_head_bwd.h).  ALINE_BWD_ACQ=0: the per-op kernels.
-static bool fused_acq_head(const aline_model &m) {
-  static int on = -1;
-  if (on < 0) { const char *e = getenv("ALINE_BWD_ACQ"); on = e ? atoi(e) != 0 : 1; }
-  return on && m.d == acqb::D && m.F == acqb::F;
-}
+static bool fused_acq_head(const aline_model &m) { return m.d == acqb::D && m.F == acqb::F && env_on("ALINE_BWD_ACQ"); }
 
 // In-projection + attention backward as one kernel (attn_bwd_mfma.h).  ALINE_BWD_ATTN_BLOCK=0: the per-op kernels.
 static bool fused_attn_block(const aline_model &m, int max_keys) {
-  static int on = -1;
-  if (on < 0) { const char *e = getenv("ALINE_BWD_ATTN_BLOCK"); on = e ? atoi(e) != 0 : 1; }
-  return on && m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK;
+  return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK && env_on("ALINE_BWD_ATTN_BLOCK");
 }
 
 BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
@@ -1597,8 +1589,7 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 
 template <int HD>
 int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys) {
-  static int mfma_on = -1;      // ALINE_BWD_ATTN_MFMA=0: the VALU kernel (A/B measurements)
-  if (mfma_on < 0) { const char *e = getenv("ALINE_BWD_ATTN_MFMA"); mfma_on = e ? atoi(e) != 0 : 1; }
+  const bool mfma_on = env_on("ALINE_BWD_ATTN_MFMA");      // 0: the VALU kernel (A/B measurements)
   if (mfma_on && HD == abwd::HD && c.m->d == abwd::D && max_keys <= abwd::MAXK) {
     hipLaunchKernelGGL(abwd::attention_bwd_mfma_kernel, dim3((unsigned)c.g.B), dim3(abwd::THREADS), 0, c.st, c.g, qkv, dA, dqkv);
     CHECK_LAUNCH();

@@ -220,15 +220,16 @@ __device__ __forceinline__ bool role_is_ctx(const Geo &g, int b, int r) {
   return r > 0;
 }
 
-constexpr int block_lds_floats(int KT) { return 3 * D * PK + 3 * D + 5 * 16 * KT * PK + WAVES * 16 * PK + 2 * D * D + 2 * D; }
+constexpr int block_lds_floats(int KT) { return 3 * D * PK + 3 * D + 5 * 16 * KT * PK + WAVES * 16 * PK + 2 * D * D + 2 * D + 16 * KT * PK; }
 
 template <int KT>
 __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kernel(BlockArgs a) {
   constexpr int MK = 16 * KT;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // block_lds_floats(KT): in-projection image, bias,
   float *const Wi = lds, *const bi = Wi + 3 * D * PK;               // key rows of x / K / V / dK / dV, wave scratch,
-  float *const kvs = bi + 3 * D, *const scrs = kvs + 5 * MK * PK;   // Wk / Wv (+ bias) gradients of this workgroup
-  float *const gkv = scrs + WAVES * 16 * PK;
+  float *const kvs = bi + 3 * D, *const scrs = kvs + 5 * MK * PK;   // Wk / Wv (+ bias) gradients of this workgroup,
+  float *const gkv = scrs + WAVES * 16 * PK;                        // a K-sized block of zeros (operands of the other heads)
+  float *const Zs = gkv + 2 * D * D + 2 * D;
   __shared__ int keyrow[MK];
   __shared__ int wave_cnt[WAVES];
   float *const Xk = kvs, *const Ks = kvs + MK * PK, *const Vs = kvs + 2 * MK * PK, *const dKs = kvs + 3 * MK * PK,
@@ -239,8 +240,10 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
   const int n_t = g.n_td + g.n_th;
   for (int i = tid; i < 3 * D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
   if (tid < 3 * D) bi[tid] = a.bin[tid];
-  for (int i = tid; i < 2 * D * D + 2 * D; i += THREADS) gkv[i] = 0.f;
-  const float scale = rsqrtf((float)HD);
+  for (int i = tid; i < 2 * D * D + 2 * D + MK * PK; i += THREADS) gkv[i] = 0.f;      // (gkv and Zs are adjacent)
+  // scores in base-2 units: q carries 1 / sqrt(hd) and log2(e), the softmax is exp2(s - max); dQ gets the plain
+  // 1 / sqrt(hd) at the end and the dK sums (products with this q) are multiplied by ln 2 when they leave the registers
+  const float scale = rsqrtf((float)HD), scale2 = scale * 1.44269504088896340736f, ln2 = 0.69314718055994530942f;
   float *scr = scrs + wave * 16 * PK;
   f32x4 gWq[2][2];
   float gBq[2] = {0.f, 0.f};
@@ -315,7 +318,12 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
       const bool ok = row < g.N;
       const int rc = ok ? row : g.N - 1;
       const bool isq = ok && row < g.P && !role_is_ctx(g, b, nrole);
-      const int nk = !ok ? 0 : (isq ? n_ak : n_ck);
+      const int nk = isq ? n_ak : n_ck;      // (padding rows: dO = 0, they contribute nothing)
+      f32x4 kmask[KT];                       // 0 on the visible keys of this row, -inf elsewhere: initial value of the scores
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kmask[kt][r] = 16 * kt + 4 * gq + r < nk ? 0.f : -INFINITY;
       f32x4 x[2], q[2], go[2], dq[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
         nrole = nr < g.P ? load_role(g, b, nr) : 0;
       }
       tailbwd::mm_fwd<2, 2>(q, Wi, PK, x, tok, gq);
-      q[0] *= scale; q[1] *= scale;
+      q[0] *= scale2; q[1] *= scale2;
       f32x4 qN[2], goN[2];
       tailbwd::to_n(qN, q[0], q[1], scr, tok, gq);
       tailbwd::to_n(goN, go[0], go[1], scr, tok, gq);
@@ -343,35 +351,41 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
         const int mt = h >> 1, hg = h & 1;
         const bool mine_g = (gq >> 1) == hg;      // this lane group's channels 16 mt + 4 g + r belong to head h (k axis)
         const bool mine_c = (tok >> 3) == hg;     // channel 16 mt + tok belongs to head h (i axis)
+        // operands of the other heads come from the block of zeros: an address select instead of a branch around the loads
+        const float *Kg = mine_g ? Ks : Zs, *Vg = mine_g ? Vs : Zs, *Kc = mine_c ? Ks : Zs;
         f32x4 s[KT], dp[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          s[kt] = zero4(); dp[kt] = zero4();
+          s[kt] = kmask[kt]; dp[kt] = zero4();
           if (kt < nkt) {
-            const f32x4 kf = mine_g ? ld4(Ks + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
-            const f32x4 vf = mine_g ? ld4(Vs + (16 * kt + tok) * PK + 16 * mt + 4 * gq) : zero4();
+            const f32x4 kf = ld4(Kg + (16 * kt + tok) * PK + 16 * mt + 4 * gq);
+            const f32x4 vf = ld4(Vg + (16 * kt + tok) * PK + 16 * mt + 4 * gq);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0], q[mt][0], kmask[kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x7F6);
+            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[0], go[mt][0], zero4(), 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x7F6);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { MFMAO(s[kt], kf[r], q[mt][r]); MFMAO(dp[kt], vf[r], go[mt][r]); }
+            for (int r = 1; r < 4; ++r) { MFMAO(s[kt], kf[r], q[mt][r]); MFMAO(dp[kt], vf[r], go[mt][r]); }
           }
         }
-        float mx = -INFINITY;
+        float mx = -3.0e38f;      // (a row without a visible key: every exp2 below is 0, inv = 0)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (16 * kt + 4 * gq + r < nk) mx = fmaxf(mx, s[kt][r]);
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = group_max(mx);
         float l = 0.f, delta = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = 16 * kt + 4 * gq + r < nk ? __expf(s[kt][r] - mx) : 0.f;
+            const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
             s[kt][r] = e;
             l += e;
             delta = fmaf(e, dp[kt][r], delta);
           }
         l = group_sum(l);
-        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
         delta = group_sum(delta) * inv;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -387,8 +401,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
           if (kt < nkt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float ka = mine_c ? Ks[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok] : 0.f;
-              MFMAO(dq[mt], ka, dp[kt][r]);
+              MFMAO(dq[mt], Kc[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok], dp[kt][r]);
             }
             f32x4 pn[2];
             tailbwd::to_n(pn, s[kt], dp[kt], scr, tok, gq);      // pn[0] = P_N, pn[1] = dS_N  (key on lane, row on (g, r))
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
         if (kt < nkt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            atomicAdd(&dKs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dKt[mt][kt][r]);
+            atomicAdd(&dKs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dKt[mt][kt][r] * ln2);
             atomicAdd(&dVs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dVt[mt][kt][r]);
           }
         }

@@ -168,3 +168,40 @@ def test_target_only_swap_trains_under_reference_composition(golden, name):
     with torch.no_grad():
         out = model(to_dev(fx.batch()))
     assert out.design_out.zt.shape[0] == fx.meta["B"]
+
+
+@pytest.mark.parametrize("T,B", [(30, 24), (44, 6), (60, 4)])
+def test_fused_backward_kernels_match_per_op_pipeline(T, B, monkeypatch):
+    """The fused training-backward kernels of the small-width model (tail_bwd.h: token-local tail; attn_bwd_mfma.h:
+    in-projection + attention, <= 32 keys at T = 30, <= 48 at T = 44, beyond that the per-op attention kernels;
+    acq_head_bwd.h: acquisition head) against the per-op pipeline (GEMM / LayerNorm / attention kernels with saved
+    activations), same rollout, same upstream gradients."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd.train import backward, reinforce_terms
+    torch.manual_seed(5)
+    model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda()
+    batch = HiddenLocation().sample_batch(B)
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        terms = reinforce_terms(ro, "theta")
+        grads = []
+        for fused in ("1", "0"):
+            for k in ("ALINE_BWD_TAIL", "ALINE_BWD_ATTN_BLOCK", "ALINE_BWD_ACQ"):
+                monkeypatch.setenv(k, fused)
+            for p in model.parameters():
+                p.grad = None
+            backward(model, ro, terms["g_logp"], terms["g_ll"])
+            torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    worst = ("", 0.0)
+    # (the acquisition output bias has a mathematically zero gradient -- softmax shift invariance: rounding noise on both sides)
+    floor = 1e-2 * max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[0]:
+        ref = grads[1][k]
+        err = float((grads[0][k] - ref).abs().max()) / max(float(ref.abs().max()), floor)
+        if err > worst[1]:
+            worst = (k, err)
+    # both sides are exact-fp32 products in different summation orders
+    assert worst[1] < 2e-4, worst
