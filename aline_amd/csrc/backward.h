@@ -443,8 +443,9 @@ struct GmmBwdArgs {
   const float *g_mean, *g_std, *g_wgt;         // [rows, C] dLoss/d mixture_{means,stds,weights}, or null
 };
 constexpr int GMM_BWD_ROWS = 256;  // rows per workgroup (64 per wave): weight-gradient partials stay in registers, are summed over the
-                                   // waves in LDS and leave as one atomic per element and workgroup (with 64 rows and one atomic per wave the
-                                   // 3 C F addresses took 3 752 contended adds each at the headline shape: 1.7 ms)
+                                   // waves in LDS and leave as one atomic per element and workgroup.  (1.65 ms per call at the headline shape,
+                                   // 60 000 rows: neither the atomics nor the cross-lane reductions -- batching the 3 C reductions of a row made
+                                   // it 2.0 ms; the kernel holds 424 registers and spills 236 SGPRs on its 4 x 16 pointer arguments.)
 __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long r_lo = (long)blockIdx.x * GMM_BWD_ROWS, r_hi = min(a.rows, r_lo + GMM_BWD_ROWS);
