@@ -17,6 +17,7 @@
 #include "tail_bwd.h"
 #include "attn_bwd_mfma.h"
 #include "acq_head_bwd.h"
+#include "layer_fwd.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1730,12 +1731,30 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     // (key_list_kernel + row-gather GEMM, as the generic rollout pipeline does), one buffer for all layers.
     const bool ckv = do_enc && fused_attn_block(*m, max_keys) && hd == abwd::HD && max_keys < N;
     int *keyidx = reinterpret_cast<int *>(c.at(c.pl.KeyIdx)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.Kcnt));
-    if (ckv) {
+    if (ckv && !(ft && env_on("ALINE_BWD_LAYER_FWD"))) {
       hipLaunchKernelGGL(key_list_kernel, dim3(I), dim3(256), 0, c.st, g, max_keys, keyidx, kcnt);
       CHECK_LAUNCH();
     }
     for (int l = 0; l < L && do_enc; ++l) {
       Ctx fc; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
+      if (ckv && ft && env_on("ALINE_BWD_LAYER_FWD")) {      // the whole layer in one kernel (layer_fwd.h): Xs(l) -> Al(l), Xs(l + 1)
+        lfwd::Args fa{};
+        fa.g = g; fa.X = Xs(l); fa.A = Al(l); fa.Y = Xs(l + 1); fa.win = m->in_proj_w[l]; fa.bin = m->in_proj_b[l];
+        fa.wo = m->out_proj_w[l]; fa.bo = m->out_proj_b[l]; fa.w1 = m->lin1_w[l]; fa.b1 = m->lin1_b[l];
+        fa.w2 = m->lin2_w[l]; fa.b2 = m->lin2_b[l]; fa.g1 = m->norm1_w[l]; fa.e1 = m->norm1_b[l];
+        fa.g2 = m->norm2_w[l]; fa.e2 = m->norm2_b[l];
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(2) * (int)sizeof(float));
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(3) * (int)sizeof(float));
+          attr = true;
+        }
+        const unsigned grid = (unsigned)std::min(I, 512);      // two persistent workgroups per CU
+        if (max_keys <= 32) hipLaunchKernelGGL(lfwd::layer_fwd_kernel<2>, dim3(grid), dim3(lfwd::THREADS), lfwd::lds_floats(2) * sizeof(float), c.st, fa);
+        else hipLaunchKernelGGL(lfwd::layer_fwd_kernel<3>, dim3(grid), dim3(lfwd::THREADS), lfwd::lds_floats(3) * sizeof(float), c.st, fa);
+        CHECK_LAUNCH();
+        continue;
+      }
       if (ckv) {
         float *Q = QKVl(0), *KVc = Q + (size_t)M * d;
         TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, Q, d, (int)M, d, d, false), 1, c.st));

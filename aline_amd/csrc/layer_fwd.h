@@ -1,0 +1,206 @@
+// One encoder layer of the small-width model (d = 32, F = 128, 4 heads of 8, <= 48 keys per instance), forward recompute of
+// the TRAINING backward, as ONE kernel:  x -> q = Wq x + bq -> a = masked set-attention(q, K, V) -> y = tail(x, a)
+// (model/encoder.py:8-46, 83-126, 128-141).  It replaces the Q-projection GEMM, the K / V gather GEMM, the attention
+// kernel and the tail kernel of the per-op recompute (2.25 ms per layer at the headline shape): x is read once, a (the
+// tail backward needs it) and y are written once, q / K / V never leave the CU.
+// Persistent workgroups walk the (step, episode) instances; per instance the key list, the key rows of x and their K / V
+// (MFMA prologue, attn_bwd_mfma.h) live in LDS; a wave owns a 16-row token tile from x to y in the T layout of tail_bwd.h:
+//   S^T [keys x rows] = Kblk q^T (key mask = initial accumulator), softmax over registers + lane groups,
+//   a^T [chan x rows] = Vblk^T P^T with P^T, register for register, as the B operand; then the tail in the same registers.
+#pragma once
+#include "attn_bwd_mfma.h"
+
+namespace lfwd {
+
+constexpr int D = 32, F = 128, HD = 8, H = 4, PK = abwd::PK, WAVES = 4, THREADS = 64 * WAVES;
+using fused::ld4;
+using fused::group_sum;
+using fused::group_max;
+using fused::zero4;
+using namespace tailbwd;      // image offsets L_*, P_*, PW, PW2, mm_fwd, normalise
+
+struct Args {
+  Geo g;
+  const float *X;            // [M, 32] layer input
+  float *A, *Y;              // [M, 32] attention output (kept for the tail backward), layer output
+  const float *win, *bin;    // in_proj_weight [96, 32], in_proj_bias [96]
+  const float *wo, *bo, *w1, *b1, *w2, *b2, *g1, *e1, *g2, *e2;
+};
+
+// LDS (floats): tail image [L_SCR] | in-projection image [96][36] | bias [96] | Xk, Ks, Vs, zeros [4][16 KT][36]
+constexpr int lds_floats(int KT) { return L_SCR + 3 * D * PK + 3 * D + 4 * 16 * KT * PK; }
+
+template <int KT>
+__global__ __launch_bounds__(THREADS, 2) void layer_fwd_kernel(Args a) {
+  constexpr int MK = 16 * KT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *const Wi = lds + L_SCR, *const bi = Wi + 3 * D * PK, *const Xk = bi + 3 * D, *const Ks = Xk + MK * PK,
+               *const Vs = Ks + MK * PK, *const Zs = Vs + MK * PK;
+  __shared__ int keyrow[MK];
+  __shared__ int wave_cnt[WAVES];
+  const Geo &g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gq = lane >> 4;
+  const int n_t = g.n_td + g.n_th;
+  for (int i = tid; i < D * D; i += THREADS) lds[L_WO + (i >> 5) * PW + (i & 31)] = a.wo[i];
+  for (int i = tid; i < F * D; i += THREADS) lds[L_W1 + (i >> 5) * PW + (i & 31)] = a.w1[i];
+  for (int i = tid; i < D * F; i += THREADS) lds[L_W2 + (i >> 7) * PW2 + (i & 127)] = a.w2[i];
+  if (tid < F) lds[L_PRM + P_B1 + tid] = a.b1[tid];
+  if (tid < D) {
+    lds[L_PRM + P_BO + tid] = a.bo[tid]; lds[L_PRM + P_B2 + tid] = a.b2[tid];
+    lds[L_PRM + P_G1 + tid] = a.g1[tid]; lds[L_PRM + P_E1 + tid] = a.e1[tid];
+    lds[L_PRM + P_G2 + tid] = a.g2[tid]; lds[L_PRM + P_E2 + tid] = a.e2[tid];
+  }
+  for (int i = tid; i < 3 * D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
+  if (tid < 3 * D) bi[tid] = a.bin[tid];
+  for (int i = tid; i < MK * PK; i += THREADS) Zs[i] = 0.f;
+  // scores in base-2 units: q carries 1 / sqrt(hd) and log2(e)
+  const float scale2 = rsqrtf((float)HD) * 1.44269504088896340736f;
+  const int ntile = (g.N + 15) >> 4;
+
+  for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
+    const long ep = (long)b * g.N;
+    f32x4 nx[2];
+    int nrole = 0;
+    {
+      const int row = min(wave * 16 + tok, g.N - 1);
+      nx[0] = ld4(a.X + (ep + row) * D + 4 * gq);
+      nx[1] = ld4(a.X + (ep + row) * D + 16 + 4 * gq);
+      if (row < g.P) nrole = abwd::load_role(g, b, row);
+    }
+    __syncthreads();      // the previous instance is done with the arrays (and the images are in place)
+    // ---- key list: context points in slot order, then the visible targets ---------------------------------------
+    int n_ck = 0;
+    for (int c0 = 0; c0 < g.P; c0 += THREADS) {
+      const int row = c0 + tid;
+      const bool key = row < g.P && abwd::role_is_ctx(g, b, abwd::load_role(g, b, min(row, g.P - 1)));
+      const unsigned long long bal = __ballot(key);
+      if (lane == 0) wave_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int off = n_ck;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+      const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (key && k < MK) keyrow[k] = row;
+      n_ck += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+    n_ck = min(n_ck, MK);
+    int n_ak = n_ck;
+    for (int j = 0; j < n_t; ++j)
+      if ((!g.tmask || g.tmask[j]) && n_ak < MK) { if (tid == 0) keyrow[n_ak] = g.P + j; ++n_ak; }
+    __syncthreads();
+    const int nkt = (n_ak + 15) >> 4;
+    for (int i = tid; i < 16 * nkt * 8; i += THREADS) {
+      const int j = i >> 3, c4 = (i & 7) * 4;
+      *reinterpret_cast<f32x4 *>(Xk + j * PK + c4) = j < n_ak ? ld4(a.X + (ep + keyrow[j]) * D + c4) : zero4();
+    }
+    __syncthreads();
+    for (int u = wave; u < 2 * nkt; u += WAVES) {      // K, V of the key rows (T layout: key on lane)
+      const int kt = u >> 1, which = u & 1;
+      const f32x4 xin[2] = {ld4(Xk + (16 * kt + tok) * PK + 4 * gq), ld4(Xk + (16 * kt + tok) * PK + 16 + 4 * gq)};
+      f32x4 acc[2] = {ld4(bi + D * (1 + which) + 4 * gq), ld4(bi + D * (1 + which) + 16 + 4 * gq)};
+      mm_fwd<2, 2>(acc, Wi + D * (1 + which) * PK, PK, xin, tok, gq);
+      float *dst = (which ? Vs : Ks) + (16 * kt + tok) * PK + 4 * gq;
+      *reinterpret_cast<f32x4 *>(dst) = acc[0];
+      *reinterpret_cast<f32x4 *>(dst + 16) = acc[1];
+    }
+    __syncthreads();
+
+    for (int tile = wave; tile < ntile; tile += WAVES) {
+      int zoff = 0;
+      asm volatile("" : "+v"(zoff));
+      const float *W = lds + zoff, *prm = W + L_PRM;
+      const int row = tile * 16 + tok;
+      const bool ok = row < g.N;
+      const bool isq = ok && row < g.P && !abwd::role_is_ctx(g, b, nrole);
+      const int nk = isq ? n_ak : n_ck;
+      f32x4 kmask[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kmask[kt][r] = 16 * kt + 4 * gq + r < nk ? 0.f : -INFINITY;
+      const f32x4 x[2] = {nx[0], nx[1]};
+      if (tile + WAVES < ntile) {
+        const int nr = min(row + 16 * WAVES, g.N - 1);
+        nx[0] = ld4(a.X + (ep + nr) * D + 4 * gq);
+        nx[1] = ld4(a.X + (ep + nr) * D + 16 + 4 * gq);
+        nrole = nr < g.P ? abwd::load_role(g, b, nr) : 0;
+      }
+      f32x4 q[2] = {ld4(bi + 4 * gq), ld4(bi + 16 + 4 * gq)};
+      mm_fwd<2, 2>(q, Wi, PK, x, tok, gq);
+      q[0] *= scale2; q[1] *= scale2;
+      f32x4 at[2] = {zero4(), zero4()};
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int mt = h >> 1, hg = h & 1;
+        const bool mine_g = (gq >> 1) == hg, mine_c = (tok >> 3) == hg;
+        const float *Kg = mine_g ? Ks : Zs, *Vc = mine_c ? Vs : Zs;
+        f32x4 s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          s[kt] = kmask[kt];
+          if (kt < nkt) {
+            const f32x4 kf = ld4(Kg + (16 * kt + tok) * PK + 16 * mt + 4 * gq);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0], q[mt][0], kmask[kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x7F6);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) MFMAO(s[kt], kf[r], q[mt][r]);
+          }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = group_max(mx);
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); l += s[kt][r]; }
+        l = group_sum(l);
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) MFMAO(at[mt], Vc[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok], s[kt][r] * inv);
+          }
+        }
+      }
+      if (ok) {
+        *reinterpret_cast<f32x4 *>(a.A + (ep + row) * D + 4 * gq) = at[0];
+        *reinterpret_cast<f32x4 *>(a.A + (ep + row) * D + 16 + 4 * gq) = at[1];
+      }
+      // ---- token-local tail (tail_bwd.h, forward) -------------------------------------------------------------------
+      f32x4 n1[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) n1[mt] = ld4(prm + P_BO + 16 * mt + 4 * gq) + x[mt];
+      mm_fwd<2, 2>(n1, W + L_WO, PW, at, tok, gq);
+      normalise(n1);
+      f32x4 x1[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) x1[mt] = n1[mt] * ld4(prm + P_G1 + 16 * mt + 4 * gq) + ld4(prm + P_E1 + 16 * mt + 4 * gq);
+      f32x4 hid[8];
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) hid[ob] = ld4(prm + P_B1 + 16 * ob + 4 * gq);
+      mm_fwd<8, 2>(hid, W + L_W1, PW, x1, tok, gq);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[ob][r] = relu_nn(hid[ob][r]);
+      f32x4 n2[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) n2[mt] = ld4(prm + P_B2 + 16 * mt + 4 * gq) + x1[mt];
+      mm_fwd<2, 8>(n2, W + L_W2, PW2, hid, tok, gq);
+      normalise(n2);
+      if (ok) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          *reinterpret_cast<f32x4 *>(a.Y + (ep + row) * D + 16 * mt + 4 * gq) =
+              n2[mt] * ld4(prm + P_G2 + 16 * mt + 4 * gq) + ld4(prm + P_E2 + 16 * mt + 4 * gq);
+      }
+    }
+  }
+}
+
+}  // namespace lfwd

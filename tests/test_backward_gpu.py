@@ -174,7 +174,7 @@ def test_target_only_swap_trains_under_reference_composition(golden, name):
 def test_fused_backward_kernels_match_per_op_pipeline(T, B, monkeypatch):
     """The fused training-backward kernels of the small-width model (tail_bwd.h: token-local tail; attn_bwd_mfma.h:
     in-projection + attention, <= 32 keys at T = 30, <= 48 at T = 44, beyond that the per-op attention kernels;
-    acq_head_bwd.h: acquisition head) against the per-op pipeline (GEMM / LayerNorm / attention kernels with saved
+    acq_head_bwd.h: acquisition head; layer_fwd.h: the forward recompute of a layer) against the per-op pipeline (GEMM / LayerNorm / attention kernels with saved
     activations), same rollout, same upstream gradients."""
     from aline_amd import Aline, Embedder, Encoder, OutputHead
     from aline_amd.rollout import Rollout
@@ -188,7 +188,7 @@ def test_fused_backward_kernels_match_per_op_pipeline(T, B, monkeypatch):
         terms = reinforce_terms(ro, "theta")
         grads = []
         for fused in ("1", "0"):
-            for k in ("ALINE_BWD_TAIL", "ALINE_BWD_ATTN_BLOCK", "ALINE_BWD_ACQ"):
+            for k in ("ALINE_BWD_TAIL", "ALINE_BWD_ATTN_BLOCK", "ALINE_BWD_ACQ", "ALINE_BWD_LAYER_FWD"):
                 monkeypatch.setenv(k, fused)
             for p in model.parameters():
                 p.grad = None
