@@ -575,7 +575,7 @@ def main():
             tdt = float(tt.item())
         out["train_step"] = {"value": world * designs_per_rollout * args.train_steps / tdt, "unit": "designs/s",
                              "ms_per_step": tdt / args.train_steps * 1e3, "steps": args.train_steps,
-                             "includes": f"forward rollout ({path}) + generic fp32 backward of all T steps + "
+                             "includes": f"forward rollout ({path}) + fused exact-fp32 backward of all T steps (layer_fwd / tail / attention-block / acquisition-head kernels) + "
                                          "flat-bucket gradient all-reduce (N>1) + inf-norm clip + AdamW",
                              "collective": "1 all-reduce / optimiser step" if world > 1 else "none (N=1)",
                              "rccl_allreduce_calls": train_mod.ALLREDUCE_CALLS - ar0,
