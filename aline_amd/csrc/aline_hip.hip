@@ -1630,7 +1630,16 @@ int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, 
     a.dwo = gr->out_proj_w[l]; a.dbo = gr->out_proj_b[l]; a.dw1 = gr->lin1_w[l]; a.db1 = gr->lin1_b[l];
     a.dw2 = gr->lin2_w[l]; a.db2 = gr->lin2_b[l]; a.dg1 = gr->norm1_w[l]; a.de1 = gr->norm1_b[l];
     a.dg2 = gr->norm2_w[l]; a.de2 = gr->norm2_b[l];
-    hipLaunchKernelGGL(tailbwd::tail_kernel<true>, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);   // 394 registers: one wave per SIMD
+    const char *pc = getenv("ALINE_BWD_TAIL_PC");      // opt-in: measured 3.56 ms per call against 3.65
+    if (pc && atoi(pc) != 0) {      // producer / consumer wave pairs, 8 waves of 224 registers (tail_bwd_pc_kernel)
+      static bool attr_pc = false;
+      if (!attr_pc) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_bwd_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_PC * (int)sizeof(float));
+        attr_pc = true;
+      }
+      hipLaunchKernelGGL(tailbwd::tail_bwd_pc_kernel, dim3((unsigned)std::min<long>(groups, 256)), dim3(512), tailbwd::LDS_FLOATS_PC * sizeof(float), c.st, a);
+    } else
+    hipLaunchKernelGGL(tailbwd::tail_kernel<true>, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);   // 434 registers: one wave per SIMD
   }
   CHECK_LAUNCH();
   return ALINE_OK;

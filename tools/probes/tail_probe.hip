@@ -27,6 +27,7 @@ int main(int argc, char **argv) {
   hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS * 4);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_FWD * 4);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_ACC * 4);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_bwd_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_PC * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int pass = 0; pass < 2; ++pass) {
     float ms;
@@ -42,6 +43,10 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 3; ++i) tailbwd::tail_kernel<true, true><<<gb, 64 * tailbwd::WAVES_ACC, tailbwd::LDS_FLOATS_ACC * 4>>>(a);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     if (pass) printf("backward, LDS accumulators, grid %4d x 8 waves: %.3f ms\n", gb, ms / 3);
+    hipEventRecord(e0);
+    for (int i = 0; i < 3; ++i) tailbwd::tail_bwd_pc_kernel<<<gb, 512, tailbwd::LDS_FLOATS_PC * 4>>>(a);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    if (pass) printf("backward, producer / consumer wave pairs, grid %4d x 8 waves: %.3f ms\n", gb, ms / 3);
   }
   printf("%s\n", hipGetErrorString(hipGetLastError()));
   return 0;
