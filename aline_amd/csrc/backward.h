@@ -563,6 +563,112 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
   if (threadIdx.x < a.C * 3) atomicAdd(a.db2[threadIdx.x / 3] + threadIdx.x % 3, red[16 * 3 * 128 + threadIdx.x]);
 }
 
+// The same for F = 128 (lane owns hidden units lane, lane + 64), written around the latency of a row: gmm_bwd_kernel walks the
+// components of a row one after the other, every one with its own global loads (twice) and its own cross-lane reductions:
+// ~25 us per row on the one wave per SIMD its 424 registers allow (1.65 ms per call at the headline shape, VALU busy 9 %).
+// Here the second-layer weights sit in LDS, the 2 C hidden values of a row are loaded in one batch (the next row's while this
+// one is computed) and stay in registers for both passes, and the 3 C reductions of a row run side by side.
+__global__ __launch_bounds__(256) void gmm_bwd128_kernel(GmmBwdArgs a) {
+  constexpr int F = 128;
+  __shared__ float sw[16 * 3 * F + 16 * 4];       // w2 [C][3][F], b2 [C][4]; reused for the gradient sums at the end
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r_lo = (long)blockIdx.x * GMM_BWD_ROWS, r_hi = min(a.rows, r_lo + GMM_BWD_ROWS);
+  for (int e = threadIdx.x; e < a.C * 3 * F; e += 256) sw[e] = a.w2[e / (3 * F)][e % (3 * F)];
+  if (threadIdx.x < a.C * 3) sw[16 * 3 * F + (threadIdx.x / 3) * 4 + threadIdx.x % 3] = a.b2[threadIdx.x / 3][threadIdx.x % 3];
+  __syncthreads();
+  float pw[16][3][2];
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int o = 0; o < 3; ++o) pw[c][o][0] = pw[c][o][1] = 0.f;
+  float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;      // lane c: bias gradients of component c
+  float nh[16][2];
+  auto load_row = [&](long row) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < a.C) { const float *hp = a.hid + (row * a.C + c) * F; nh[c][0] = hp[lane]; nh[c][1] = hp[lane + 64]; }
+  };
+  if (r_lo + wave < r_hi) load_row(r_lo + wave);
+  for (long row = r_lo + wave; row < r_hi; row += 4) {
+    float hv[16][2], ps[16][3];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { hv[c][0] = nh[c][0]; hv[c][1] = nh[c][1]; }
+    if (row + 4 < r_hi) load_row(row + 4);
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < a.C) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) ps[c][o] = fmaf(hv[c][0], sw[(c * 3 + o) * F + lane], hv[c][1] * sw[(c * 3 + o) * F + lane + 64]);
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < a.C) {
+#pragma unroll
+          for (int o = 0; o < 3; ++o) ps[c][o] += __shfl_xor(ps[c][o], off, WAVE);
+        }
+    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < a.C && lane == c) {
+        raw0 = ps[c][0] + sw[16 * 3 * F + c * 4]; raw1 = ps[c][1] + sw[16 * 3 * F + c * 4 + 1]; raw2 = ps[c][2] + sw[16 * 3 * F + c * 4 + 2];
+      }
+    const bool act = lane < a.C;
+    const float mean = raw0, sd = softplus_f(raw1) + a.std_min;
+    const float mxw = wave_max(act ? raw2 : -INFINITY);
+    const float ew = act ? __expf(raw2 - mxw) : 0.f;
+    const float wgt = ew / wave_sum(ew);
+    const float v = a.value[row % a.value_mod];
+    const float z = (v - mean) / sd;
+    const float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
+    const float m2 = wave_max(lp);
+    const float er = act ? __expf(lp - m2) : 0.f;
+    const float resp = er / wave_sum(er);          // responsibilities
+    const float gl = a.g_ll ? a.g_ll[row] : 0.f;
+    float d0 = act ? gl * resp * z / sd : 0.f;                                        // mean
+    float dsd = act ? gl * resp * (z * z - 1.f) / sd : 0.f;                           // sigma
+    float d2 = act ? gl * (resp - wgt) : 0.f;                                         // mixture logits
+    if (a.g_mean && act) d0 += a.g_mean[row * a.C + lane];
+    if (a.g_std && act) dsd += a.g_std[row * a.C + lane];
+    if (a.g_wgt) {
+      const float gw = act ? a.g_wgt[row * a.C + lane] : 0.f;
+      const float dot = wave_sum(gw * wgt);
+      if (act) d2 += wgt * (gw - dot);                                                // softmax backward
+    }
+    const float d1 = dsd * (1.f / (1.f + __expf(-raw1)));                             // softplus'
+    pb0 += d0; pb1 += d1; pb2 += d2;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < a.C) {
+        const float g0 = __shfl(d0, c, WAVE), g1 = __shfl(d1, c, WAVE), g2 = __shfl(d2, c, WAVE);
+        float *hp = a.hid + (row * a.C + c) * F;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int f = lane + 64 * n;
+          const float h = hv[c][n];
+          pw[c][0][n] = fmaf(g0, h, pw[c][0][n]);      // (h = relu output: 0 on the inactive units)
+          pw[c][1][n] = fmaf(g1, h, pw[c][1][n]);
+          pw[c][2][n] = fmaf(g2, h, pw[c][2][n]);
+          hp[f] = h > 0.f ? g0 * sw[(c * 3) * F + f] + g1 * sw[(c * 3 + 1) * F + f] + g2 * sw[(c * 3 + 2) * F + f] : 0.f;
+        }
+      }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * 3 * F + 16 * 4; e += 256) sw[e] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < a.C) {
+#pragma unroll
+      for (int o = 0; o < 3; ++o) { atomicAdd(&sw[(c * 3 + o) * F + lane], pw[c][o][0]); atomicAdd(&sw[(c * 3 + o) * F + lane + 64], pw[c][o][1]); }
+    }
+  if (lane < a.C) { atomicAdd(&sw[16 * 3 * F + lane * 4], pb0); atomicAdd(&sw[16 * 3 * F + lane * 4 + 1], pb1); atomicAdd(&sw[16 * 3 * F + lane * 4 + 2], pb2); }
+  __syncthreads();
+  for (int e = threadIdx.x; e < a.C * 3 * F; e += 256) atomicAdd(a.dw2[e / (3 * F)] + e % (3 * F), sw[e]);
+  if (threadIdx.x < a.C * 3) atomicAdd(a.db2[threadIdx.x / 3] + threadIdx.x % 3, sw[16 * 3 * F + (threadIdx.x / 3) * 4 + threadIdx.x % 3]);
+}
+
 // Gradient of the step-invariant embeddings: X0[(t,b), row] = Ex[b, row] (+ Ey[b, p] while p is context),
 // theta rows = tokens.   dEx[b,row] += sum_t dX0;  dEy[b,p] += sum_{t: ctx} dX0;  dtheta += sum_{t,b} dX0.
 __global__ void assemble_bwd_kernel(Geo g, int d, int n_inst_t, const float *__restrict__ dX0,
