@@ -1485,7 +1485,7 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
   p.Xs = take((L + 1) * M * d);
-  p.QKV = take(L * M * 3 * d);
+  p.QKV = take(std::max(L * M * 3 * d, (2 * L + 3) * M * d));      // or: L + 1 compact K / V buffers (<= 2 M d each) + Q
   p.A = take(L * M * d);
   p.U1 = take(ft ? 0 : L * M * d);
   p.X1 = take(ft ? 0 : L * M * d);
@@ -1740,15 +1740,25 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     // (key_list_kernel + row-gather GEMM, as the generic rollout pipeline does), one buffer for all layers.
     const bool ckv = do_enc && fused_attn_block(*m, max_keys) && hd == abwd::HD && max_keys < N;
     int *keyidx = reinterpret_cast<int *>(c.at(c.pl.KeyIdx)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.Kcnt));
-    if (ckv && !(ft && env_on("ALINE_BWD_LAYER_FWD"))) {
+    // compact K / V of layer l [I * max_keys, 2 d] (kept for the backward), then dK | dV of the layer in flight, then Q
+    const size_t kv_floats = (size_t)I * max_keys * 2 * d;
+    auto KVl = [&](int l) { return QKVl(0) + (size_t)l * kv_floats; };
+    float *dKVc = QKVl(0) + (size_t)L * kv_floats, *Qbuf = dKVc + kv_floats;
+    if (ckv) {
       hipLaunchKernelGGL(key_list_kernel, dim3(I), dim3(256), 0, c.st, g, max_keys, keyidx, kcnt);
       CHECK_LAUNCH();
     }
     for (int l = 0; l < L && do_enc; ++l) {
       Ctx fc; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
-      if (ckv && ft && env_on("ALINE_BWD_LAYER_FWD")) {      // the whole layer in one kernel (layer_fwd.h): Xs(l) -> Al(l), Xs(l + 1)
+      if (ckv) {      // K / V of the key rows: row-gather GEMM on the key list
+        GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, KVl(l), 2 * d, I * max_keys, 2 * d, d, false);
+        ka.row_index = keyidx;
+        TRY(launch_gemm(bwd_prec(), ka, 1, c.st));
+      }
+      if (ckv && ft && env_on("ALINE_BWD_LAYER_FWD")) {      // the rest of the layer in one kernel (layer_fwd.h): Xs(l) -> Al(l), Xs(l + 1)
         lfwd::Args fa{};
         fa.g = g; fa.X = Xs(l); fa.A = Al(l); fa.Y = Xs(l + 1); fa.win = m->in_proj_w[l]; fa.bin = m->in_proj_b[l];
+        fa.kvc = KVl(l); fa.kcnt = kcnt; fa.max_keys = max_keys;
         fa.wo = m->out_proj_w[l]; fa.bo = m->out_proj_b[l]; fa.w1 = m->lin1_w[l]; fa.b1 = m->lin1_b[l];
         fa.w2 = m->lin2_w[l]; fa.b2 = m->lin2_b[l]; fa.g1 = m->norm1_w[l]; fa.e1 = m->norm1_b[l];
         fa.g2 = m->norm2_w[l]; fa.e2 = m->norm2_b[l];
@@ -1765,12 +1775,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         continue;
       }
       if (ckv) {
-        float *Q = QKVl(0), *KVc = Q + (size_t)M * d;
-        TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, Q, d, (int)M, d, d, false), 1, c.st));
-        GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, KVc, 2 * d, I * max_keys, 2 * d, d, false);
-        ka.row_index = keyidx;
-        TRY(launch_gemm(bwd_prec(), ka, 1, c.st));
-        TRY(launch_attention<8>(fc, Q, Al(l), max_keys, KVc, kcnt));
+        TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, Qbuf, d, (int)M, d, d, false), 1, c.st));
+        TRY(launch_attention<8>(fc, Qbuf, Al(l), max_keys, KVl(l), kcnt));
       } else {
       TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
       switch (hd) {
@@ -1898,19 +1904,24 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false));                  // dTmp = dA
       }
       // attention block: in-projection + attention in one kernel (attn_bwd_mfma.h), dXn = dU1 -> dX_l
-      if (fused_attn_block(*m, max_keys)) {
+      if (ckv) {
         abwd::BlockArgs ba{};
         ba.g = g; ba.X = Xs(l); ba.dA = dTmp; ba.dX = dXn; ba.win = m->in_proj_w[l]; ba.bin = m->in_proj_b[l];
         ba.dwin = gr->in_proj_w[l]; ba.dbin = gr->in_proj_b[l];
+        ba.kvc = KVl(l); ba.dkvc = dKVc; ba.keyidx = keyidx; ba.kcnt = kcnt; ba.max_keys = max_keys;
         static bool attr = false;
         if (!attr) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(2) * (int)sizeof(float));
           (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(3) * (int)sizeof(float));
           attr = true;
         }
-        // persistent workgroups: two per CU at <= 32 keys (221 registers), one otherwise
+        // persistent workgroups: two per CU at <= 32 keys (242 registers), one otherwise
         if (max_keys <= 32) hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<2>, dim3((unsigned)std::min(I, 512)), dim3(abwd::THREADS), abwd::block_lds_floats(2) * sizeof(float), c.st, ba);
         else hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<3>, dim3((unsigned)std::min(I, 256)), dim3(abwd::THREADS), abwd::block_lds_floats(3) * sizeof(float), c.st, ba);
+        CHECK_LAUNCH();
+        // key rows: dx += Wk^T dK + Wv^T dV, Wk / Wv gradients (one wave per (instance, key tile))
+        const long units = (long)I * ((max_keys + 15) / 16);
+        hipLaunchKernelGGL(abwd::kv_bwd_kernel, dim3((unsigned)std::min<long>((units + abwd::WAVES - 1) / abwd::WAVES, 1024)), dim3(abwd::THREADS), 0, c.st, ba);
         CHECK_LAUNCH();
         std::swap(dX, dXn);
         continue;

@@ -195,20 +195,29 @@ __global__ __launch_bounds__(THREADS) void attention_bwd_mfma_kernel(Geo g, cons
 }
 
 
-// ---- the whole attention block: in-projection + attention, backward, in one kernel --------------------------------------
+// ---- the whole attention block: in-projection + attention, backward ----------------------------------------------------------
 //   q = Wq x + bq,  K / V = Wk / Wv x_key + b  (key rows only),  a = attention(q, K, V)
 //   in   x = layer input [M, 32], dA = dLoss/da, dX = dLoss/du1 (the residual branch, written by the tail kernel)
 //   out  dX += Wq^T dq  (every row)  + Wk^T dK + Wv^T dV  (key rows);  dWin, dbin accumulated into (+=)
 // Neither QKV nor dQKV ([M, 96] each) exist: the per-op pipeline wrote / read them five times per layer (in-projection GEMM,
-// attention backward, its dW and dX GEMMs).  Persistent workgroups walk the instances; per instance the key list, the key
-// rows of x and their K / V (MFMA prologue) live in LDS, dK / dV are summed over the waves in LDS and an MFMA epilogue
-// turns them into the key rows' dX and the Wk / Wv gradients.  The 12 dWin accumulator tiles stay in registers.
+// attention backward, its dW and dX GEMMs).  Two kernels:
+//   attn_block_bwd_kernel  persistent workgroups walk the instances; K / V of the instance's key rows come from the compact
+//                          buffer of the forward recompute (one coalesced copy into LDS, one barrier), the token tiles run as
+//                          described above with q recomputed and dX = dU1 + Wq^T dq, dWq in registers; dK / dV are summed over
+//                          the waves in LDS and stored to a compact buffer [I * max_keys, 64].
+//   kv_bwd_kernel          one wave per (instance, key tile): key rows' dX += Wk^T dK + Wv^T dV, dWk / dWv / biases.
+// (The first version did the key list, the K / V projection and the key-row epilogue per instance inside the kernel: four
+// dependent global round trips and seven barriers per instance, 1.69 of its 3.23 ms per call with the token tiles switched off.)
 struct BlockArgs {
   Geo g;
   const float *X, *dA;
   float *dX;
   const float *win, *bin;      // in_proj_weight [96, 32], in_proj_bias [96]
   float *dwin, *dbin;
+  const float *kvc;            // [I * max_keys, 64] K | V of the key rows, key-list order (forward recompute)
+  float *dkvc;                 // [I * max_keys, 64] dK | dV sums of the key rows (attn_block_bwd_kernel -> kv_bwd_kernel)
+  const int *keyidx, *kcnt;    // key_list_kernel: global token row of key j of instance b (-1 beyond), [I, 2] counts
+  int max_keys;
 };
 
 __device__ __forceinline__ int load_role(const Geo &g, int b, int p) {
@@ -220,27 +229,21 @@ __device__ __forceinline__ bool role_is_ctx(const Geo &g, int b, int r) {
   return r > 0;
 }
 
-constexpr int block_lds_floats(int KT) { return 3 * D * PK + 3 * D + 5 * 16 * KT * PK + WAVES * 16 * PK + 2 * D * D + 2 * D + 16 * KT * PK; }
+// LDS (floats): Wq image [32][36] | bq [32] | Ks, Vs, dKs, dVs, zeros [5][16 KT][36] | wave scratch [4][16][36]
+constexpr int block_lds_floats(int KT) { return D * PK + D + 5 * 16 * KT * PK + WAVES * 16 * PK; }
 
 template <int KT>
 __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kernel(BlockArgs a) {
   constexpr int MK = 16 * KT;
-  extern __shared__ __attribute__((aligned(16))) float lds[];      // block_lds_floats(KT): in-projection image, bias,
-  float *const Wi = lds, *const bi = Wi + 3 * D * PK;               // key rows of x / K / V / dK / dV, wave scratch,
-  float *const kvs = bi + 3 * D, *const scrs = kvs + 5 * MK * PK;   // Wk / Wv (+ bias) gradients of this workgroup,
-  float *const gkv = scrs + WAVES * 16 * PK;                        // a K-sized block of zeros (operands of the other heads)
-  float *const Zs = gkv + 2 * D * D + 2 * D;
-  __shared__ int keyrow[MK];
-  __shared__ int wave_cnt[WAVES];
-  float *const Xk = kvs, *const Ks = kvs + MK * PK, *const Vs = kvs + 2 * MK * PK, *const dKs = kvs + 3 * MK * PK,
-               *const dVs = kvs + 4 * MK * PK;
-  static_assert(5 * MK * PK >= D * D + D, "gradient staging reuses the key-row arrays");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *const Wi = lds, *const bi = Wi + D * PK, *const Ks = bi + D, *const Vs = Ks + MK * PK, *const dKs = Vs + MK * PK,
+               *const dVs = dKs + MK * PK, *const Zs = dVs + MK * PK, *const scrs = Zs + MK * PK;
+  static_assert(4 * MK * PK >= D * D + D, "gradient staging reuses the key-row arrays");
   const Geo &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gq = lane >> 4;
-  const int n_t = g.n_td + g.n_th;
-  for (int i = tid; i < 3 * D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
-  if (tid < 3 * D) bi[tid] = a.bin[tid];
-  for (int i = tid; i < 2 * D * D + 2 * D + MK * PK; i += THREADS) gkv[i] = 0.f;      // (gkv and Zs are adjacent)
+  for (int i = tid; i < D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
+  if (tid < D) bi[tid] = a.bin[tid];
+  for (int i = tid; i < MK * PK; i += THREADS) Zs[i] = 0.f;
   // scores in base-2 units: q carries 1 / sqrt(hd) and log2(e), the softmax is exp2(s - max); dQ gets the plain
   // 1 / sqrt(hd) at the end and the dK sums (products with this q) are multiplied by ln 2 when they leave the registers
   const float scale = rsqrtf((float)HD), scale2 = scale * 1.44269504088896340736f, ln2 = 0.69314718055994530942f;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
 
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
     const long ep = (long)b * g.N;
-    // first tile of this wave: its loads fly while the key list and K / V are built
+    // first tile of this wave: its loads fly while K / V arrive
     f32x4 nx[2], ngo[2];
     int nrole = 0;
     {
@@ -267,44 +270,14 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
       }
       if (row < g.P) nrole = load_role(g, b, row);
     }
-    __syncthreads();      // the previous instance is done with the arrays
-    // ---- key list: context points in slot order, then the visible targets ---------------------------------------
-    int n_ck = 0;
-    for (int c0 = 0; c0 < g.P; c0 += THREADS) {
-      const int row = c0 + tid;
-      const bool key = row < g.P && role_is_ctx(g, b, load_role(g, b, min(row, g.P - 1)));
-      const unsigned long long bal = __ballot(key);
-      if (lane == 0) wave_cnt[wave] = __popcll(bal);
-      __syncthreads();
-      int off = n_ck;
-      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-      const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
-      if (key && k < MK) keyrow[k] = row;
-      n_ck += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-      __syncthreads();
-    }
-    n_ck = min(n_ck, MK);
-    int n_ak = n_ck;
-    for (int j = 0; j < n_t; ++j)
-      if ((!g.tmask || g.tmask[j]) && n_ak < MK) { if (tid == 0) keyrow[n_ak] = g.P + j; ++n_ak; }
-    __syncthreads();
+    const int n_ck = min(a.kcnt[2 * b], MK), n_ak = min(a.kcnt[2 * b + 1], MK);
     const int nkt = (n_ak + 15) >> 4;
-    for (int i = tid; i < 16 * nkt * 8; i += THREADS) {
-      const int j = i >> 3, c4 = (i & 7) * 4;
-      *reinterpret_cast<f32x4 *>(Xk + j * PK + c4) = j < n_ak ? ld4(a.X + (ep + keyrow[j]) * D + c4) : zero4();
-      *reinterpret_cast<f32x4 *>(dKs + j * PK + c4) = zero4();
-      *reinterpret_cast<f32x4 *>(dVs + j * PK + c4) = zero4();
-    }
-    __syncthreads();
-    // ---- K, V of the key rows (T layout: key on lane) -------------------------------------------------------------
-    for (int u = wave; u < 2 * nkt; u += WAVES) {
-      const int kt = u >> 1, which = u & 1;
-      const f32x4 xin[2] = {ld4(Xk + (16 * kt + tok) * PK + 4 * gq), ld4(Xk + (16 * kt + tok) * PK + 16 + 4 * gq)};
-      f32x4 acc[2] = {ld4(bi + D * (1 + which) + 4 * gq), ld4(bi + D * (1 + which) + 16 + 4 * gq)};
-      tailbwd::mm_fwd<2, 2>(acc, Wi + D * (1 + which) * PK, PK, xin, tok, gq);
-      float *dst = (which ? Vs : Ks) + (16 * kt + tok) * PK + 4 * gq;
-      *reinterpret_cast<f32x4 *>(dst) = acc[0];
-      *reinterpret_cast<f32x4 *>(dst + 16) = acc[1];
+    __syncthreads();      // the previous instance is done with the arrays
+    for (int i = tid; i < 16 * nkt * 16; i += THREADS) {      // a key row = 16 float4: K | V
+      const int j = i >> 4, c4 = (i & 15) * 4;
+      const f32x4 v = j < n_ak ? ld4(a.kvc + ((long)b * a.max_keys + j) * 2 * D + c4) : zero4();
+      *reinterpret_cast<f32x4 *>((c4 < D ? Ks : Vs - D) + j * PK + c4) = v;
+      *reinterpret_cast<f32x4 *>((c4 < D ? dKs : dVs - D) + j * PK + c4) = zero4();
     }
     __syncthreads();
 
@@ -400,9 +373,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
         for (int kt = 0; kt < KT; ++kt) {
           if (kt < nkt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              MFMAO(dq[mt], Kc[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok], dp[kt][r]);
-            }
+            for (int r = 0; r < 4; ++r) MFMAO(dq[mt], Kc[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok], dp[kt][r]);
             f32x4 pn[2];
             tailbwd::to_n(pn, s[kt], dp[kt], scr, tok, gq);      // pn[0] = P_N, pn[1] = dS_N  (key on lane, row on (g, r))
 #pragma unroll
@@ -429,7 +400,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
         gBq[i] += tailbwd::sum4(dqN[i]);
       }
     }
-    // ---- dK / dV of the key rows: sum over the waves through LDS ---------------------------------------------------
+    // ---- dK / dV of the key rows: sum over the waves through LDS, then to the compact buffer ---------------------------
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -441,52 +412,15 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
             atomicAdd(&dVs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dVt[mt][kt][r]);
           }
         }
-    __syncthreads();      // (also: every wave's dX rows are stored before the key rows are updated)
-    // ---- key rows: dx += Wk^T dK + Wv^T dV; one (key tile, 16 input features) unit per wave at a time ---------------
-    for (int u = wave; u < 2 * nkt; u += WAVES) {
-      const int kt = u >> 1, ib = u & 1;
-      const int key = 16 * kt + tok;
-      float *dst = a.dX + (ep + keyrow[min(key, n_ak - 1)]) * D + 16 * ib + 4 * gq;
-      const f32x4 old = ld4(dst);
-      const f32x4 dk[2] = {ld4(dKs + key * PK + 4 * gq), ld4(dKs + key * PK + 16 + 4 * gq)};
-      const f32x4 dv[2] = {ld4(dVs + key * PK + 4 * gq), ld4(dVs + key * PK + 16 + 4 * gq)};
-      f32x4 acc[1] = {zero4()};
-      tailbwd::mm_bwd<1, 2>(acc, Wi + D * PK + 16 * ib, PK, dk, tok, gq);
-      tailbwd::mm_bwd<1, 2>(acc, Wi + 2 * D * PK + 16 * ib, PK, dv, tok, gq);
-      if (key < n_ak) *reinterpret_cast<f32x4 *>(dst) = old + acc[0];
-    }
-    // ---- Wk / Wv gradients: contraction over the keys of a tile (N-layout operands read column-wise from LDS), added
-    // to the workgroup's LDS accumulators (32 registers per wave that would otherwise stay resident for this alone)
-    for (int kt = wave; kt < nkt; kt += WAVES) {
-      f32x4 kN[2], vN[2], xkN[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = (16 * kt + 4 * gq + r) * PK + 16 * i + tok;
-          kN[i][r] = dKs[o]; vN[i][r] = dVs[o]; xkN[i][r] = Xk[o];
-        }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x4 wk = zero4(), wv = zero4();
-          tailbwd::mm_dw(wk, kN[i], xkN[j]);
-          tailbwd::mm_dw(wv, vN[i], xkN[j]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            atomicAdd(&gkv[(16 * i + 4 * gq + r) * D + 16 * j + tok], wk[r]);
-            atomicAdd(&gkv[D * D + (16 * i + 4 * gq + r) * D + 16 * j + tok], wv[r]);
-          }
-        }
-        atomicAdd(&gkv[2 * D * D + 16 * i + tok], tailbwd::sum4(kN[i]));
-        atomicAdd(&gkv[2 * D * D + D + 16 * i + tok], tailbwd::sum4(vN[i]));
-      }
+    __syncthreads();
+    for (int i = tid; i < n_ak * 16; i += THREADS) {
+      const int j = i >> 4, c4 = (i & 15) * 4;
+      *reinterpret_cast<f32x4 *>(a.dkvc + ((long)b * a.max_keys + j) * 2 * D + c4) = ld4((c4 < D ? dKs : dVs - D) + j * PK + c4);
     }
   }
-  // ---- the workgroup's in-projection gradients: LDS staging, then one atomic per element ----------------------------
+  // ---- the workgroup's Wq gradients: LDS staging, then one atomic per element ---------------------------------------
   __syncthreads();
-  float *stg = kvs;      // Wq [32][32], then bq [32]
+  float *stg = Ks;      // Wq [32][32], then bq [32]
   for (int i = tid; i < D * D + D; i += THREADS) stg[i] = 0.f;
   __syncthreads();
 #pragma unroll
@@ -499,9 +433,89 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
   }
   __syncthreads();
   for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwin + i, stg[i]);
-  for (int i = tid; i < 2 * D * D; i += THREADS) unsafeAtomicAdd(a.dwin + D * D + i, gkv[i]);
   if (tid < D) unsafeAtomicAdd(a.dbin + tid, stg[D * D + tid]);
-  if (tid < 2 * D) unsafeAtomicAdd(a.dbin + D + tid, gkv[2 * D * D + tid]);
+}
+
+// Key rows of the attention block, backward: dx[key row] += Wk^T dK + Wv^T dV, dWk / dWv += dK^T / dV^T x[key rows], biases.
+// One wave per (instance, key tile) unit, no barriers; the 8 accumulator tiles of a wave stay in registers.
+__global__ __launch_bounds__(THREADS) void kv_bwd_kernel(BlockArgs a) {
+  __shared__ __attribute__((aligned(16))) float Wkv[2 * D * PK];      // Wk, Wv row-major [out][in]
+  __shared__ float stg[2 * D * D + 2 * D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gq = lane >> 4;
+  for (int i = tid; i < 2 * D * D; i += THREADS) Wkv[(i >> 5) * PK + (i & 31)] = a.win[D * D + i];
+  for (int i = tid; i < 2 * D * D + 2 * D; i += THREADS) stg[i] = 0.f;
+  __syncthreads();
+  f32x4 gWk[2][2], gWv[2][2];
+  float gBk[2] = {0.f, 0.f}, gBv[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gWk[i][j] = gWv[i][j] = zero4();
+  const int KTI = (a.max_keys + 15) >> 4;                    // key tiles per instance (upper bound)
+  const long units = (long)a.g.B * KTI;
+  for (long u = (long)blockIdx.x * WAVES + wave; u < units; u += (long)gridDim.x * WAVES) {
+    const int b = (int)(u / KTI), kt = (int)(u % KTI);
+    const int n_ak = min(a.kcnt[2 * b + 1], a.max_keys);
+    if (16 * kt >= n_ak) continue;
+    const long base = (long)b * a.max_keys;
+    // T layout (key on lane): dK / dV rows of the tile -> the key rows' dx
+    const int keyT = 16 * kt + tok;
+    const bool okT = keyT < n_ak;
+    const float *src = a.dkvc + (base + (okT ? keyT : 0)) * 2 * D;
+    f32x4 dk[2], dv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      dk[mt] = okT ? ld4(src + 16 * mt + 4 * gq) : zero4();
+      dv[mt] = okT ? ld4(src + D + 16 * mt + 4 * gq) : zero4();
+    }
+    const int rowT = okT ? a.keyidx[base + keyT] : 0;        // global token row
+    f32x4 acc[2] = {zero4(), zero4()};
+    tailbwd::mm_bwd<2, 2>(acc, Wkv, PK, dk, tok, gq);
+    tailbwd::mm_bwd<2, 2>(acc, Wkv + D * PK, PK, dv, tok, gq);
+    if (okT) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float *dst = a.dX + (long)rowT * D + 16 * mt + 4 * gq;
+        *reinterpret_cast<f32x4 *>(dst) = ld4(dst) + acc[mt];
+      }
+    }
+    // N layout (channel on lane, key on (g, r)): weight gradients
+    f32x4 kN[2], vN[2], xkN[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * kt + 4 * gq + r;
+      const bool ok = key < n_ak;
+      const float *s2 = a.dkvc + (base + (ok ? key : 0)) * 2 * D;
+      const float *xr = a.X + (long)(ok ? a.keyidx[base + key] : 0) * D;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        kN[i][r] = ok ? s2[16 * i + tok] : 0.f;
+        vN[i][r] = ok ? s2[D + 16 * i + tok] : 0.f;
+        xkN[i][r] = ok ? xr[16 * i + tok] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      tailbwd::mm_dw4(gWk[i][0], gWk[i][1], gWv[i][0], gWv[i][1], kN[i], xkN[0], kN[i], xkN[1], vN[i], xkN[0], vN[i], xkN[1]);
+      gBk[i] += tailbwd::sum4(kN[i]);
+      gBv[i] += tailbwd::sum4(vN[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(&stg[(16 * i + 4 * gq + r) * D + 16 * j + tok], gWk[i][j][r]);
+        atomicAdd(&stg[D * D + (16 * i + 4 * gq + r) * D + 16 * j + tok], gWv[i][j][r]);
+      }
+    atomicAdd(&stg[2 * D * D + 16 * i + tok], gBk[i]);
+    atomicAdd(&stg[2 * D * D + D + 16 * i + tok], gBv[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * D * D; i += THREADS) unsafeAtomicAdd(a.dwin + D * D + i, stg[i]);
+  if (tid < 2 * D) unsafeAtomicAdd(a.dbin + D + tid, stg[2 * D * D + tid]);
 }
 
 }  // namespace abwd

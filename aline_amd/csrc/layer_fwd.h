@@ -3,8 +3,9 @@
 // (model/encoder.py:8-46, 83-126, 128-141).  It replaces the Q-projection GEMM, the K / V gather GEMM, the attention
 // kernel and the tail kernel of the per-op recompute (2.25 ms per layer at the headline shape): x is read once, a (the
 // tail backward needs it) and y are written once, q / K / V never leave the CU.
-// Persistent workgroups walk the (step, episode) instances; per instance the key list, the key rows of x and their K / V
-// (MFMA prologue, attn_bwd_mfma.h) live in LDS; a wave owns a 16-row token tile from x to y in the T layout of tail_bwd.h:
+// Persistent workgroups walk the (step, episode) instances; per instance K / V of the key rows are copied from the compact
+// buffer a small GEMM filled (one coalesced copy and one barrier: building the key list and projecting K / V inside this
+// kernel cost more than the tiles -- four dependent global round trips and five barriers per instance); a wave owns a 16-row token tile from x to y in the T layout of tail_bwd.h:
 //   S^T [keys x rows] = Kblk q^T (key mask = initial accumulator), softmax over registers + lane groups,
 //   a^T [chan x rows] = Vblk^T P^T with P^T, register for register, as the B operand; then the tail in the same registers.
 #pragma once
@@ -24,23 +25,22 @@ struct Args {
   const float *X;            // [M, 32] layer input
   float *A, *Y;              // [M, 32] attention output (kept for the tail backward), layer output
   const float *win, *bin;    // in_proj_weight [96, 32], in_proj_bias [96]
+  const float *kvc;          // [I * max_keys, 64] K | V of the key rows (key_list_kernel + row-gather GEMM), key-list order
+  const int *kcnt;           // [I, 2] context keys, all keys
+  int max_keys;
   const float *wo, *bo, *w1, *b1, *w2, *b2, *g1, *e1, *g2, *e2;
 };
 
-// LDS (floats): tail image [L_SCR] | in-projection image [96][36] | bias [96] | Xk, Ks, Vs, zeros [4][16 KT][36]
-constexpr int lds_floats(int KT) { return L_SCR + 3 * D * PK + 3 * D + 4 * 16 * KT * PK; }
+// LDS (floats): tail image [L_SCR] | Wq image [32][36] | bq [32] | Ks, Vs, zeros [3][16 KT][36]
+constexpr int lds_floats(int KT) { return L_SCR + D * PK + D + 3 * 16 * KT * PK; }
 
 template <int KT>
 __global__ __launch_bounds__(THREADS, 2) void layer_fwd_kernel(Args a) {
   constexpr int MK = 16 * KT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *const Wi = lds + L_SCR, *const bi = Wi + 3 * D * PK, *const Xk = bi + 3 * D, *const Ks = Xk + MK * PK,
-               *const Vs = Ks + MK * PK, *const Zs = Vs + MK * PK;
-  __shared__ int keyrow[MK];
-  __shared__ int wave_cnt[WAVES];
+  float *const Wi = lds + L_SCR, *const bi = Wi + D * PK, *const Ks = bi + D, *const Vs = Ks + MK * PK, *const Zs = Vs + MK * PK;
   const Geo &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gq = lane >> 4;
-  const int n_t = g.n_td + g.n_th;
   for (int i = tid; i < D * D; i += THREADS) lds[L_WO + (i >> 5) * PW + (i & 31)] = a.wo[i];
   for (int i = tid; i < F * D; i += THREADS) lds[L_W1 + (i >> 5) * PW + (i & 31)] = a.w1[i];
   for (int i = tid; i < D * F; i += THREADS) lds[L_W2 + (i >> 7) * PW2 + (i & 127)] = a.w2[i];
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(THREADS, 2) void layer_fwd_kernel(Args a) {
     lds[L_PRM + P_G1 + tid] = a.g1[tid]; lds[L_PRM + P_E1 + tid] = a.e1[tid];
     lds[L_PRM + P_G2 + tid] = a.g2[tid]; lds[L_PRM + P_E2 + tid] = a.e2[tid];
   }
-  for (int i = tid; i < 3 * D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
-  if (tid < 3 * D) bi[tid] = a.bin[tid];
+  for (int i = tid; i < D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
+  if (tid < D) bi[tid] = a.bin[tid];
   for (int i = tid; i < MK * PK; i += THREADS) Zs[i] = 0.f;
   // scores in base-2 units: q carries 1 / sqrt(hd) and log2(e)
   const float scale2 = rsqrtf((float)HD) * 1.44269504088896340736f;
@@ -67,41 +67,13 @@ __global__ __launch_bounds__(THREADS, 2) void layer_fwd_kernel(Args a) {
       nx[1] = ld4(a.X + (ep + row) * D + 16 + 4 * gq);
       if (row < g.P) nrole = abwd::load_role(g, b, row);
     }
-    __syncthreads();      // the previous instance is done with the arrays (and the images are in place)
-    // ---- key list: context points in slot order, then the visible targets ---------------------------------------
-    int n_ck = 0;
-    for (int c0 = 0; c0 < g.P; c0 += THREADS) {
-      const int row = c0 + tid;
-      const bool key = row < g.P && abwd::role_is_ctx(g, b, abwd::load_role(g, b, min(row, g.P - 1)));
-      const unsigned long long bal = __ballot(key);
-      if (lane == 0) wave_cnt[wave] = __popcll(bal);
-      __syncthreads();
-      int off = n_ck;
-      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-      const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
-      if (key && k < MK) keyrow[k] = row;
-      n_ck += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-      __syncthreads();
-    }
-    n_ck = min(n_ck, MK);
-    int n_ak = n_ck;
-    for (int j = 0; j < n_t; ++j)
-      if ((!g.tmask || g.tmask[j]) && n_ak < MK) { if (tid == 0) keyrow[n_ak] = g.P + j; ++n_ak; }
-    __syncthreads();
+    const int n_ck = min(a.kcnt[2 * b], MK), n_ak = min(a.kcnt[2 * b + 1], MK);
     const int nkt = (n_ak + 15) >> 4;
-    for (int i = tid; i < 16 * nkt * 8; i += THREADS) {
-      const int j = i >> 3, c4 = (i & 7) * 4;
-      *reinterpret_cast<f32x4 *>(Xk + j * PK + c4) = j < n_ak ? ld4(a.X + (ep + keyrow[j]) * D + c4) : zero4();
-    }
-    __syncthreads();
-    for (int u = wave; u < 2 * nkt; u += WAVES) {      // K, V of the key rows (T layout: key on lane)
-      const int kt = u >> 1, which = u & 1;
-      const f32x4 xin[2] = {ld4(Xk + (16 * kt + tok) * PK + 4 * gq), ld4(Xk + (16 * kt + tok) * PK + 16 + 4 * gq)};
-      f32x4 acc[2] = {ld4(bi + D * (1 + which) + 4 * gq), ld4(bi + D * (1 + which) + 16 + 4 * gq)};
-      mm_fwd<2, 2>(acc, Wi + D * (1 + which) * PK, PK, xin, tok, gq);
-      float *dst = (which ? Vs : Ks) + (16 * kt + tok) * PK + 4 * gq;
-      *reinterpret_cast<f32x4 *>(dst) = acc[0];
-      *reinterpret_cast<f32x4 *>(dst + 16) = acc[1];
+    __syncthreads();      // the previous instance is done with K / V (and the images are in place)
+    for (int i = tid; i < 16 * nkt * 16; i += THREADS) {      // a key row = 16 float4: K | V
+      const int j = i >> 4, c4 = (i & 15) * 4;
+      const f32x4 v = j < n_ak ? ld4(a.kvc + ((long)b * a.max_keys + j) * 2 * D + c4) : zero4();
+      *reinterpret_cast<f32x4 *>((c4 < D ? Ks : Vs - D) + j * PK + c4) = v;
     }
     __syncthreads();
 
