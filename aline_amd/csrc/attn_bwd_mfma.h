@@ -229,16 +229,16 @@ __device__ __forceinline__ bool role_is_ctx(const Geo &g, int b, int r) {
   return r > 0;
 }
 
-// LDS (floats): Wq image [32][36] | bq [32] | Ks, Vs, dKs, dVs, zeros [5][16 KT][36] | wave scratch [4][16][36]
-constexpr int block_lds_floats(int KT) { return D * PK + D + 5 * 16 * KT * PK + WAVES * 16 * PK; }
+// LDS (floats): Wq image [32][36] | bq [32] | Ks, Vs, zeros [3][16 KT][36] | wave scratch [4][16][36] | dK / dV slots [4][2][16 KT][36]
+constexpr int block_lds_floats(int KT) { return D * PK + D + 3 * 16 * KT * PK + WAVES * 16 * PK + WAVES * 2 * 16 * KT * PK; }
 
 template <int KT>
 __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kernel(BlockArgs a) {
   constexpr int MK = 16 * KT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *const Wi = lds, *const bi = Wi + D * PK, *const Ks = bi + D, *const Vs = Ks + MK * PK, *const dKs = Vs + MK * PK,
-               *const dVs = dKs + MK * PK, *const Zs = dVs + MK * PK, *const scrs = Zs + MK * PK;
-  static_assert(4 * MK * PK >= D * D + D, "gradient staging reuses the key-row arrays");
+  float *const Wi = lds, *const bi = Wi + D * PK, *const Ks = bi + D, *const Vs = Ks + MK * PK, *const Zs = Vs + MK * PK,
+               *const scrs = Zs + MK * PK, *const slots = scrs + WAVES * 16 * PK;      // slots [wave][dK | dV][MK][PK]
+  static_assert(2 * MK * PK >= D * D + D, "gradient staging reuses the key-row arrays");
   const Geo &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gq = lane >> 4;
   for (int i = tid; i < D * D; i += THREADS) Wi[(i >> 5) * PK + (i & 31)] = a.win[i];
@@ -256,6 +256,17 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
     for (int j = 0; j < 2; ++j) gWq[i][j] = zero4();
   const int ntile = (g.N + 15) >> 4;
 
+  // K | V of an instance's key rows: 16 KT rows of 16 float4, KT per thread, fetched one instance ahead.  Rows beyond the
+  // instance's keys hold the projection of a zero row (finite) and are masked; rows beyond max_keys are clamped.
+  f32x4 nkv[KT];
+  auto load_kv = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int i = tid + u * THREADS, j = min(i >> 4, a.max_keys - 1), c4 = (i & 15) * 4;
+      nkv[u] = ld4(a.kvc + ((long)b * a.max_keys + j) * 2 * D + c4);
+    }
+  };
+  if ((int)blockIdx.x < g.B) load_kv(blockIdx.x);
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
     const long ep = (long)b * g.N;
     // first tile of this wave: its loads fly while K / V arrive
@@ -273,13 +284,13 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
     const int n_ck = min(a.kcnt[2 * b], MK), n_ak = min(a.kcnt[2 * b + 1], MK);
     const int nkt = (n_ak + 15) >> 4;
     __syncthreads();      // the previous instance is done with the arrays
-    for (int i = tid; i < 16 * nkt * 16; i += THREADS) {      // a key row = 16 float4: K | V
-      const int j = i >> 4, c4 = (i & 15) * 4;
-      const f32x4 v = j < n_ak ? ld4(a.kvc + ((long)b * a.max_keys + j) * 2 * D + c4) : zero4();
-      *reinterpret_cast<f32x4 *>((c4 < D ? Ks : Vs - D) + j * PK + c4) = v;
-      *reinterpret_cast<f32x4 *>((c4 < D ? dKs : dVs - D) + j * PK + c4) = zero4();
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {      // (loaded while the previous instance was computed)
+      const int i = tid + u * THREADS, j = i >> 4, c4 = (i & 15) * 4;
+      *reinterpret_cast<f32x4 *>((c4 < D ? Ks : Vs - D) + j * PK + c4) = nkv[u];
     }
     __syncthreads();
+    if (b + (int)gridDim.x < g.B) load_kv(b + gridDim.x);
 
     f32x4 dKt[2][KT], dVt[2][KT];      // [chan 16 mt + 4 g + r][key 16 kt + tok], summed over this wave's tiles
 #pragma unroll
@@ -400,22 +411,27 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
         gBq[i] += tailbwd::sum4(dqN[i]);
       }
     }
-    // ---- dK / dV of the key rows: sum over the waves through LDS, then to the compact buffer ---------------------------
+    // ---- dK / dV of the key rows: every wave leaves its partial sums in its own LDS slot (plain 16-byte stores: LDS float
+    // atomics retire a few lanes per cycle), the store to the compact buffer adds the four slots -------------------------
+    {
+      float *my = slots + wave * 2 * MK * PK;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-        if (kt < nkt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            atomicAdd(&dKs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dKt[mt][kt][r] * ln2);
-            atomicAdd(&dVs[(16 * kt + tok) * PK + 16 * mt + 4 * gq + r], dVt[mt][kt][r]);
+        for (int kt = 0; kt < KT; ++kt)
+          if (kt < nkt) {
+            *reinterpret_cast<f32x4 *>(my + (16 * kt + tok) * PK + 16 * mt + 4 * gq) = dKt[mt][kt] * ln2;
+            *reinterpret_cast<f32x4 *>(my + MK * PK + (16 * kt + tok) * PK + 16 * mt + 4 * gq) = dVt[mt][kt];
           }
-        }
+    }
     __syncthreads();
     for (int i = tid; i < n_ak * 16; i += THREADS) {
       const int j = i >> 4, c4 = (i & 15) * 4;
-      *reinterpret_cast<f32x4 *>(a.dkvc + ((long)b * a.max_keys + j) * 2 * D + c4) = ld4((c4 < D ? dKs : dVs - D) + j * PK + c4);
+      const float *src = slots + (c4 < D ? 0 : MK * PK - D) + j * PK + c4;
+      f32x4 v = ld4(src);
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) v += ld4(src + w * 2 * MK * PK);
+      *reinterpret_cast<f32x4 *>(a.dkvc + ((long)b * a.max_keys + j) * 2 * D + c4) = v;
     }
   }
   // ---- the workgroup's Wq gradients: LDS staging, then one atomic per element ---------------------------------------

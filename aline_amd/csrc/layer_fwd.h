@@ -57,6 +57,17 @@ __global__ __launch_bounds__(THREADS, 2) void layer_fwd_kernel(Args a) {
   const float scale2 = rsqrtf((float)HD) * 1.44269504088896340736f;
   const int ntile = (g.N + 15) >> 4;
 
+  // K | V of an instance's key rows: 16 KT rows of 16 float4, KT per thread, fetched one instance ahead.  Rows beyond the
+  // instance's keys hold the projection of a zero row (finite) and are masked; rows beyond max_keys are clamped.
+  f32x4 nkv[KT];
+  auto load_kv = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int i = tid + u * THREADS, j = min(i >> 4, a.max_keys - 1), c4 = (i & 15) * 4;
+      nkv[u] = ld4(a.kvc + ((long)b * a.max_keys + j) * 2 * D + c4);
+    }
+  };
+  if ((int)blockIdx.x < g.B) load_kv(blockIdx.x);
   for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
     const long ep = (long)b * g.N;
     f32x4 nx[2];
@@ -70,12 +81,13 @@ __global__ __launch_bounds__(THREADS, 2) void layer_fwd_kernel(Args a) {
     const int n_ck = min(a.kcnt[2 * b], MK), n_ak = min(a.kcnt[2 * b + 1], MK);
     const int nkt = (n_ak + 15) >> 4;
     __syncthreads();      // the previous instance is done with K / V (and the images are in place)
-    for (int i = tid; i < 16 * nkt * 16; i += THREADS) {      // a key row = 16 float4: K | V
-      const int j = i >> 4, c4 = (i & 15) * 4;
-      const f32x4 v = j < n_ak ? ld4(a.kvc + ((long)b * a.max_keys + j) * 2 * D + c4) : zero4();
-      *reinterpret_cast<f32x4 *>((c4 < D ? Ks : Vs - D) + j * PK + c4) = v;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {      // (loaded while the previous instance was computed)
+      const int i = tid + u * THREADS, j = i >> 4, c4 = (i & 15) * 4;
+      *reinterpret_cast<f32x4 *>((c4 < D ? Ks : Vs - D) + j * PK + c4) = nkv[u];
     }
     __syncthreads();
+    if (b + (int)gridDim.x < g.B) load_kv(b + gridDim.x);
 
     for (int tile = wave; tile < ntile; tile += WAVES) {
       int zoff = 0;
