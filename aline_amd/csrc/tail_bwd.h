@@ -37,7 +37,10 @@ constexpr int P_BO = 0, P_B1 = 32, P_B2 = 160, P_G1 = 192, P_E1 = 224, P_G2 = 25
 constexpr int L_SCR = L_PRM + NPRM;
 constexpr int SCR = 2 * 16 * PW;       // two 16 x 32 blocks per wave (backward only)
 constexpr int WAVES = 4, THREADS = 64 * WAVES;
-constexpr int LDS_FLOATS_FWD = L_SCR, LDS_FLOATS = L_SCR + WAVES * SCR;       // 41.2 KB forward, 59.6 KB backward
+// backward only: transposed copies of the three images behind the scratch, so that the dX products read their A fragments
+// like the forward ones (one ds_read_b128 per four MFMAs instead of one ds_read_b32 per MFMA)
+constexpr int L_T = L_SCR + WAVES * SCR, L_WOT = L_T, L_W1T = L_WOT + D * PW, L_W2T = L_W1T + D * PW2, L_TEND = L_W2T + F * PW;
+constexpr int LDS_FLOATS_FWD = L_SCR, LDS_FLOATS = L_TEND;       // 41.2 KB forward, 99.5 KB backward
 // backward with the weight-gradient accumulators in LDS (8 waves of <= 256 registers, two per SIMD): image | 8 scratches | sums
 constexpr int WAVES_ACC = 8, L_ACC = L_SCR + WAVES_ACC * SCR;
 // gradient staging, reusing the image region after the tile loop
@@ -209,6 +212,12 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
     lds[L_PRM + P_G1 + tid] = a.g1[tid]; lds[L_PRM + P_E1 + tid] = a.e1[tid];
     lds[L_PRM + P_G2 + tid] = a.g2[tid]; lds[L_PRM + P_E2 + tid] = a.e2[tid];
   }
+  constexpr bool TIMG = BWD && !LDSACC;      // Wo^T [32][36], W1^T [32][132], W2^T [128][36]
+  if (TIMG) {
+    for (int i = tid; i < D * D; i += THREADS) lds[L_WOT + (i & 31) * PW + (i >> 5)] = a.wo[i];
+    for (int i = tid; i < F * D; i += THREADS) lds[L_W1T + (i & 31) * PW2 + (i >> 5)] = a.w1[i];
+    for (int i = tid; i < D * F; i += THREADS) lds[L_W2T + (i & 127) * PW + (i >> 7)] = a.w2[i];
+  }
   __syncthreads();
 
   // weight-gradient accumulators of this wave (MFMA accumulator layout: [16 ib + 4 g + r][16 jb + tok])
@@ -302,12 +311,14 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {          // 32 hidden units at a time
       f32x4 dh[2] = {fused::zero4(), fused::zero4()};
-      mm_bwd<2, 2>(dh, W + L_W2 + 32 * kc, PW2, du2, tok, g);
+      if (TIMG) mm_fwd<2, 2>(dh, W + L_W2T + 32 * kc * PW, PW, du2, tok, g);
+      else mm_bwd<2, 2>(dh, W + L_W2 + 32 * kc, PW2, du2, tok, g);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh[j][r] = h[2 * kc + j][r] > 0.f ? dh[j][r] : 0.f;
-      mm_bwd<2, 2>(dx1, W + L_W1 + 32 * kc * PW, PW, dh, tok, g);
+      if (TIMG) mm_fwd<2, 2>(dx1, W + L_W1T + 32 * kc, PW2, dh, tok, g);
+      else mm_bwd<2, 2>(dx1, W + L_W1 + 32 * kc * PW, PW, dh, tok, g);
       f32x4 hN[2], dhN[2];
       to_n2(hN, dhN, h[2 * kc], h[2 * kc + 1], dh[0], dh[1], scr, tok, g);
 #pragma unroll
@@ -330,7 +341,8 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
     f32x4 du1[2];
     ln_backward(du1, dx1, n1, rstd1, prm + P_G1, gG1, gE1, g);
     f32x4 da[2] = {fused::zero4(), fused::zero4()};
-    mm_bwd<2, 2>(da, W + L_WO, PW, du1, tok, g);
+    if (TIMG) mm_fwd<2, 2>(da, W + L_WOT, PW, du1, tok, g);
+    else mm_bwd<2, 2>(da, W + L_WO, PW, du1, tok, g);
     if (ok) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
