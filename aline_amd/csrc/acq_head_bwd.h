@@ -75,27 +75,29 @@ struct DlArgs {
   int T;
   float *db2;
 };
-// one wave per instance
+// one wave per instance at a time (persistent waves: the db2 sums leave as one atomic per wave, not per instance --
+// 30 000 adds to one address were most of the 0.39 ms this kernel took)
 __global__ __launch_bounds__(256) void dlogit_kernel(DlArgs a) {
-  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= a.g.B) return;
+  const int lane = threadIdx.x & 63;
   const int P = a.g.P, N = a.g.N;
-  const int b = i % a.g.inst_B, t = a.g.inst_t0 + i / a.g.inst_B;
-  float *lg = a.logit + (long)i * N;
-  float mx = -INFINITY;
-  for (int p = lane; p < P; p += 64) if (!is_ctx(a.g, i, p)) mx = fmaxf(mx, lg[p]);
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int p = lane; p < P; p += 64) if (!is_ctx(a.g, i, p)) sum += __expf(lg[p] - mx);
-  const float inv = 1.f / wave_sum(sum);
-  const float gl = a.g_logp[(long)b * a.T + t];
-  const int chosen = a.slot[(long)b * a.T + t];
   float dbl = 0.f;
-  for (int p = lane; p < N; p += 64) {
-    float dl = 0.f;
-    if (p < P && !is_ctx(a.g, i, p)) dl = gl * ((p == chosen ? 1.f : 0.f) - __expf(lg[p] - mx) * inv);
-    lg[p] = dl;
-    dbl += dl;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < a.g.B; i += gridDim.x * 4) {
+    const int b = i % a.g.inst_B, t = a.g.inst_t0 + i / a.g.inst_B;
+    float *lg = a.logit + (long)i * N;
+    float mx = -INFINITY;
+    for (int p = lane; p < P; p += 64) if (!is_ctx(a.g, i, p)) mx = fmaxf(mx, lg[p]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int p = lane; p < P; p += 64) if (!is_ctx(a.g, i, p)) sum += __expf(lg[p] - mx);
+    const float inv = 1.f / wave_sum(sum);
+    const float gl = a.g_logp[(long)b * a.T + t];
+    const int chosen = a.slot[(long)b * a.T + t];
+    for (int p = lane; p < N; p += 64) {
+      float dl = 0.f;
+      if (p < P && !is_ctx(a.g, i, p)) dl = gl * ((p == chosen ? 1.f : 0.f) - __expf(lg[p] - mx) * inv);
+      lg[p] = dl;
+      dbl += dl;
+    }
   }
   dbl = wave_sum(dbl);
   if (lane == 0) atomicAdd(a.db2, dbl);

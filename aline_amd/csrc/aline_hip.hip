@@ -1830,7 +1830,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       CHECK_LAUNCH();
       acqb::DlArgs dl{};
       dl.g = g; dl.logit = dTmp; dl.g_logp = g_logp; dl.slot = r->slot; dl.T = r->T; dl.db2 = gr->acq_b2;
-      hipLaunchKernelGGL(acqb::dlogit_kernel, dim3((unsigned)((I + 3) / 4)), dim3(256), 0, c.st, dl);
+      hipLaunchKernelGGL(acqb::dlogit_kernel, dim3((unsigned)std::min((I + 3) / 4, 2048)), dim3(256), 0, c.st, dl);
       CHECK_LAUNCH();
       hipLaunchKernelGGL(acqb::bwd_kernel, dim3((unsigned)std::min<long>(groups, 512)), dim3(acqb::THREADS), acqb::LDS_FLOATS * sizeof(float), c.st, a);
       CHECK_LAUNCH();

@@ -117,9 +117,9 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
                burn_in=False, forced_idx=None, clip_grads=True, dist=None, world=1, t_chunk=None):
     """One epoch body of train_aline.py:55-152 (without the hydra / logging shell)."""
     model.train()
-    for p in model.parameters():
-        if p.grad is not None:
-            p.grad.zero_()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    if grads:
+        torch._foreach_zero_(grads)              # one launch instead of one per parameter (137 at the default model)
     with torch.no_grad():
         select = "forced" if forced_idx is not None else "sample"
         ro = Rollout(model, batch, T, select=select, forced_idx=forced_idx).run()
