@@ -56,7 +56,26 @@ struct Args {
   long M;
   const float *wo, *bo, *w1, *b1, *w2, *b2, *g1, *e1, *g2, *e2;
   float *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dg1, *de1, *dg2, *de2;     // accumulated into (+=)
+#if defined(TAIL_STAMPS)      // (tools/probes/tail_probe.hip: s_memtime deltas per phase, wave 0 of workgroup 0)
+  unsigned long long *stamps;
+#endif
 };
+#if defined(TAIL_STAMPS)
+#define TAIL_NSTAMP 8
+struct Stamps {
+  unsigned long long t_prev, acc[TAIL_NSTAMP];
+  __device__ __forceinline__ void start() { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory"); }
+  __device__ __forceinline__ void lap(int k) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    acc[k] += t - t_prev;
+    t_prev = t;
+  }
+};
+#define TAIL_LAP(k, ...) do { asm volatile("" :: __VA_ARGS__); st.lap(k); } while (0)
+#else
+#define TAIL_LAP(k, ...) do { } while (0)
+#endif
 
 using fused::ld4;
 using fused::group_sum;
@@ -238,6 +257,10 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
     for (int j = 0; j < 8; ++j) gB1[j] = 0.f;
   }
 
+#if defined(TAIL_STAMPS)
+  Stamps st{};
+  st.start();
+#endif
   const long ntiles = (a.M + 15) / 16;
   const long tstep = (long)gridDim.x * WAVES;
   // the tile after this one is loaded while this one is computed (one wave per SIMD: nobody else hides the latency)
@@ -276,6 +299,7 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
     for (int mt = 0; mt < 2; ++mt) n1[mt] = ld4(prm + P_BO + 16 * mt + 4 * g) + x[mt];
     mm_fwd<2, 2>(n1, W + L_WO, PW, at, tok, g);
     const float rstd1 = normalise(n1);
+    TAIL_LAP(0, "v"(n1[0]), "v"(n1[1]));
     f32x4 x1[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) x1[mt] = n1[mt] * ld4(prm + P_G1 + 16 * mt + 4 * g) + ld4(prm + P_E1 + 16 * mt + 4 * g);
@@ -287,11 +311,13 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
     for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[ob][r] = relu_nn(h[ob][r]);
+    TAIL_LAP(1, "v"(h[0]), "v"(h[7]));
     f32x4 n2[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) n2[mt] = ld4(prm + P_B2 + 16 * mt + 4 * g) + x1[mt];
     mm_fwd<2, 8>(n2, W + L_W2, PW2, h, tok, g);
     const float rstd2 = normalise(n2);
+    TAIL_LAP(2, "v"(n2[0]), "v"(n2[1]));
     if (!BWD) {
       if (ok) {
 #pragma unroll
@@ -307,20 +333,31 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
     f32x4 du2N[2], x1N[2];
     to_n2(du2N, x1N, du2[0], du2[1], x1[0], x1[1], scr, tok, g);
     gB2[0] += sum4(du2N[0]); gB2[1] += sum4(du2N[1]);
+    TAIL_LAP(3, "v"(du2N[0]), "v"(x1N[1]));
     f32x4 dx1[2] = {du2[0], du2[1]};
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {          // 32 hidden units at a time
-      f32x4 dh[2] = {fused::zero4(), fused::zero4()};
+    // 32 hidden units at a time, software-pipelined so that the MFMAs of independent products follow each other:
+    //   dx1 += W1^T dh(kc)  |  dh(kc + 1) = W2^T du2  |  dW2, dW1 of chunk kc  -- the ReLU gate of chunk kc + 1 and the LDS
+    // transposes of chunk kc are vector / LDS work beside them (written one product after the other, every 16-MFMA group
+    // drained the pipe before the next could start)
+    auto dh_chunk = [&](f32x4 (&dh)[2], int kc) {
+      dh[0] = dh[1] = fused::zero4();
       if (TIMG) mm_fwd<2, 2>(dh, W + L_W2T + 32 * kc * PW, PW, du2, tok, g);
       else mm_bwd<2, 2>(dh, W + L_W2 + 32 * kc, PW2, du2, tok, g);
+    };
+    f32x4 dhc[2];
+    dh_chunk(dhc, 0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh[j][r] = h[2 * kc + j][r] > 0.f ? dh[j][r] : 0.f;
-      if (TIMG) mm_fwd<2, 2>(dx1, W + L_W1T + 32 * kc, PW2, dh, tok, g);
-      else mm_bwd<2, 2>(dx1, W + L_W1 + 32 * kc * PW, PW, dh, tok, g);
+      for (int r = 0; r < 4; ++r) dhc[j][r] = h[j][r] > 0.f ? dhc[j][r] : 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
       f32x4 hN[2], dhN[2];
-      to_n2(hN, dhN, h[2 * kc], h[2 * kc + 1], dh[0], dh[1], scr, tok, g);
+      to_n2(hN, dhN, h[2 * kc], h[2 * kc + 1], dhc[0], dhc[1], scr, tok, g);
+      if (TIMG) mm_fwd<2, 2>(dx1, W + L_W1T + 32 * kc, PW2, dhc, tok, g);
+      else mm_bwd<2, 2>(dx1, W + L_W1 + 32 * kc * PW, PW, dhc, tok, g);
+      f32x4 dhn[2];
+      if (kc < 3) dh_chunk(dhn, kc + 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (LDSACC) {
@@ -337,7 +374,14 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
         }
         gB1[2 * kc + j] += sum4(dhN[j]);
       }
+      if (kc < 3) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhc[j][r] = h[2 * kc + 2 + j][r] > 0.f ? dhn[j][r] : 0.f;
+      }
     }
+    TAIL_LAP(4, "v"(dx1[0]), "v"(dx1[1]));
     f32x4 du1[2];
     ln_backward(du1, dx1, n1, rstd1, prm + P_G1, gG1, gE1, g);
     f32x4 da[2] = {fused::zero4(), fused::zero4()};
@@ -350,6 +394,7 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
         *reinterpret_cast<f32x4 *>(a.dU + row * D + 16 * mt + 4 * g) = du1[mt];
       }
     }
+    TAIL_LAP(5, "v"(da[0]), "v"(da[1]));
     f32x4 du1N[2], aN[2];
     to_n2(du1N, aN, du1[0], du1[1], at[0], at[1], scr, tok, g);
     if (LDSACC) {
@@ -364,7 +409,11 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
       mm_dw4(gWo[0][0], gWo[0][1], gWo[1][0], gWo[1][1], du1N[0], aN[0], du1N[0], aN[1], du1N[1], aN[0], du1N[1], aN[1]);
     }
     gBo[0] += sum4(du1N[0]); gBo[1] += sum4(du1N[1]);
+    TAIL_LAP(6, "v"(gWo[0][0]), "v"(gWo[1][1]));
   }
+#if defined(TAIL_STAMPS)
+  if (BWD && a.stamps && blockIdx.x == 0 && tid == 0) for (int q = 0; q < TAIL_NSTAMP; ++q) a.stamps[q] = st.acc[q];
+#endif
   if (!BWD) return;
 
   // ---- the workgroup's gradients: LDS staging, then one atomic per element ------------------------------------
@@ -470,6 +519,7 @@ __global__ __launch_bounds__(512) void tail_bwd_pc_kernel(Args a) {
   float *const buf = lds + L_SCR + pair * PC_BUF;
 
   if (producer) {
+    __builtin_amdgcn_s_setprio(3);             // the producer's chain is the critical path: the consumer fills its bubbles
     f32x4 gG1[2], gE1[2], gG2[2], gE2[2];      // LayerNorm parameters, T layout (partial over rows)
 #pragma unroll
     for (int i = 0; i < 2; ++i) gG1[i] = gE1[i] = gG2[i] = gE2[i] = fused::zero4();

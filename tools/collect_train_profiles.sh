@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 evidence for the training step (GPU box, repo root): bench line, kernel stats of the bench and of a
 # profiled training probe (t_chunk 30), PMC utilisation counters and HBM traffic of the backward kernels.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02t; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02t; rm -rf $O $R/gpurun_out/pmc_train2; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
 echo "bench done"

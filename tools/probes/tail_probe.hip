@@ -48,6 +48,17 @@ int main(int argc, char **argv) {
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     if (pass) printf("backward, producer / consumer wave pairs, grid %4d x 8 waves: %.3f ms\n", gb, ms / 3);
   }
+#if defined(TAIL_STAMPS)
+  {
+    unsigned long long *st; hipMalloc(&st, 64); hipMemset(st, 0, 64);
+    a.stamps = st;
+    tailbwd::tail_kernel<true><<<gb, tailbwd::THREADS, tailbwd::LDS_FLOATS * 4>>>(a);
+    unsigned long long h[8]; hipMemcpy(h, st, 64, hipMemcpyDeviceToHost);
+    const char *nm[7] = {"load + u1 + LN1", "h (W1) + ReLU", "u2 (W2) + LN2", "LN2 bwd + transposes", "FFN bwd chunks (dh, dx1, dW2, dW1)", "LN1 bwd + da + stores", "transposes + dWo"};
+    double tot = 0; for (int i = 0; i < 7; ++i) tot += h[i];
+    for (int i = 0; i < 7; ++i) printf("  %-36s %5.1f %%  (%llu ticks)\n", nm[i], 100.0 * h[i] / tot, h[i]);
+  }
+#endif
   printf("%s\n", hipGetErrorString(hipGetLastError()));
   return 0;
 }
