@@ -1768,6 +1768,15 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
           (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(3) * (int)sizeof(float));
           attr = true;
         }
+        if (env_on("ALINE_BWD_LAYER_FWD_FLAT")) {      // (instance, tile) units from one flat list, K / V fragments from L2
+          const long units = (long)I * ((N + 15) / 16);
+          const unsigned fgrid = (unsigned)std::min<long>((units + lfwd::WAVES - 1) / lfwd::WAVES, 768);      // three workgroups per CU
+          const size_t fl = lfwd::LDS_FLOATS_FLAT * sizeof(float);
+          if (max_keys <= 32) hipLaunchKernelGGL(lfwd::layer_fwd_flat_kernel<2>, dim3(fgrid), dim3(lfwd::THREADS), fl, c.st, fa);
+          else hipLaunchKernelGGL(lfwd::layer_fwd_flat_kernel<3>, dim3(fgrid), dim3(lfwd::THREADS), fl, c.st, fa);
+          CHECK_LAUNCH();
+          continue;
+        }
         const unsigned grid = (unsigned)std::min(I, 512);      // two persistent workgroups per CU
         if (max_keys <= 32) hipLaunchKernelGGL(lfwd::layer_fwd_kernel<2>, dim3(grid), dim3(lfwd::THREADS), lfwd::lds_floats(2) * sizeof(float), c.st, fa);
         else hipLaunchKernelGGL(lfwd::layer_fwd_kernel<3>, dim3(grid), dim3(lfwd::THREADS), lfwd::lds_floats(3) * sizeof(float), c.st, fa);
