@@ -1730,6 +1730,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
 
     // ---- forward recompute, saving what the backward needs --------------------------------------------
     if (do_emb && do_enc) {
+      if (d % 4 == 0) hipLaunchKernelGGL(assemble4_kernel, grid1d((size_t)M * d / 4), dim3(256), 0, c.st, g, d, Ex, Ey, P, m->theta_tokens, Xs(0));
+      else
       hipLaunchKernelGGL(assemble_kernel, grid1d((size_t)M * d), dim3(256), 0, c.st, g, d, Ex, Ey, P,
                          m->theta_tokens, Xs(0));
       CHECK_LAUNCH();
@@ -1954,6 +1956,9 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       continue;
     }
     // ---- embeddings: sum over the chunk's steps ------------------------------------------------------------
+    if (d % 4 == 0) hipLaunchKernelGGL(assemble_bwd4_kernel, grid1d((size_t)B * N * d / 4), dim3(256), 0, c.st, g, d, nt_steps, dX,
+                       c.at(c.pl.dEx), c.at(c.pl.dEy), P, gr->theta_tokens ? gr->theta_tokens : c.at(c.pl.dTmp));
+    else
     hipLaunchKernelGGL(assemble_bwd_kernel, grid1d((size_t)B * N * d), dim3(256), 0, c.st, g, d, nt_steps, dX,
                        c.at(c.pl.dEx), c.at(c.pl.dEy), P, gr->theta_tokens ? gr->theta_tokens : c.at(c.pl.dTmp));
     CHECK_LAUNCH();

@@ -696,6 +696,33 @@ __global__ void assemble_bwd_kernel(Geo g, int d, int n_inst_t, const float *__r
   }
 }
 
+// the same, 16 bytes per thread (d a multiple of 4)
+__global__ void assemble_bwd4_kernel(Geo g, int d, int n_inst_t, const float *__restrict__ dX0,
+                                     float *__restrict__ dEx, float *__restrict__ dEy, int ey_rows,
+                                     float *__restrict__ dtheta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int B = g.inst_B, d4 = d >> 2;
+  if (i >= (long)B * g.N * d4) return;
+  const int c = (int)(i % d4) * 4;
+  const long r = i / d4;
+  const int b = (int)(r / g.N), row = (int)(r % g.N);
+  f32x4 sx = {0.f, 0.f, 0.f, 0.f}, sy = sx;
+  for (int tt = 0; tt < n_inst_t; ++tt) {
+    const long inst = (long)tt * B + b;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(dX0 + (inst * g.N + row) * d + c);
+    sx += v;
+    if (row < g.P && is_ctx(g, (int)inst, row)) sy += v;
+  }
+  if (row < g.P + g.n_td) {
+    f32x4 *px = reinterpret_cast<f32x4 *>(dEx + ((long)b * (g.P + g.n_td) + row) * d + c);
+    *px += sx;
+    if (row < g.P) { f32x4 *py = reinterpret_cast<f32x4 *>(dEy + ((long)b * ey_rows + row) * d + c); *py += sy; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(dtheta + (row - g.P - g.n_td) * d + c + q, sx[q]);
+  }
+}
+
 // First layer of the point embedder, backward:  hid = relu(b1 + x W1^T) with tiny K.
 // dhid [rows, F] (already masked by relu) -> dW1[f,k] += sum_r dhid[r,f] x[r,k], db1[f] += sum_r dhid[r,f]
 __global__ __launch_bounds__(256) void embed_first_bwd_kernel(Src3 src, int rows_per_ep, int B, int K, int F,
