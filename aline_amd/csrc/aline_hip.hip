@@ -1875,6 +1875,26 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();
       float *Wt = c.at(c.pl.Wt);   // [d, C*F]: column block k = W1_k^T
+      if (F == 128 && d % 32 == 0 && env_on("ALINE_BWD_GMM_BATCHED")) {
+        // all C components in one launch each: dW1_k / db1_k (column block k of the hidden gradients), and dz as one K = C F product
+        GemmTnArgs ta{};
+        ta.dY = HidG; ta.ldy = C * F; ta.Ry = 1; ta.Gy = 1; ta.offy = 0;
+        ta.X = Z; ta.ldx = d; ta.Rx = n_t; ta.Gx = N; ta.offx = P;
+        ta.ldw = d; ta.M = (long)I * n_t; ta.N = C * F; ta.K = d; ta.grouped = 1;
+        for (int k = 0; k < C; ++k) { ta.dWg[k] = gr->gmm_w1[k]; ta.dbg[k] = gr->gmm_b1[k]; }
+        ta.mchunk = 4096;
+        while (ta.mchunk > 256 && ((ta.M + ta.mchunk - 1) / ta.mchunk) * C * (d / 32) < 512) ta.mchunk /= 2;
+        hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3((unsigned)((ta.M + ta.mchunk - 1) / ta.mchunk), C, d / 32), dim3(256), 0, c.st, ta);
+        CHECK_LAUNCH();
+        PackW1Args pa{};
+        for (int k = 0; k < C; ++k) pa.w1[k] = m->gmm_w1[k];
+        pa.C = C; pa.F = F; pa.d = d; pa.out = Wt;
+        hipLaunchKernelGGL(gmm_w1_pack_kernel, grid1d((size_t)C * F * d), dim3(256), 0, c.st, pa);
+        CHECK_LAUNCH();
+        GemmArgs ga = gemm_args(HidG, C * F, Wt, nullptr, C * F, dX, d, I * n_t, d, C * F, false);
+        ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
+        TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
+      } else {
       for (int k = 0; k < C; ++k) {
         TRY(gemm_dw(c, HidG + (size_t)k * F, C * F, Z, d, gr->gmm_w1[k], gr->gmm_b1[k], (long)I * n_t, F, d, 1, 1, 0,
                     n_t, N, P));
@@ -1888,6 +1908,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         GemmArgs ga = gemm_args(HidG + (size_t)k * F, C * F, Wt + (size_t)k * F * d, nullptr, F, dX, d, I * n_t, d, F, false);
         ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
         TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
+      }
       }
       CHECK_LAUNCH();
     }

@@ -17,6 +17,9 @@ struct GemmTnArgs {
   float *db;                                     // [N] or null
   long M; int N, K; long mchunk;
   int swap;                                      // block kernel: roles exchanged (dY is the 32-wide operand), see gemm_dw
+  // optional (TN = 8, no swap): one [128, K] gradient per column block of dY -- the C first layers of the GMM heads, whose hidden
+  // gradients sit side by side in one [rows, C F] matrix, in ONE launch (blockIdx.y = component)
+  float *dWg[16]; float *dbg[16]; int grouped;
 };
 
 // The workgroup owns a [16 TN x 32] block of dW for its row chunk (TN = 8, 6, 4, 2 by the divisibility of N):
@@ -76,17 +79,19 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
       for (int r = 0; r < 4; ++r) atomicAdd(&red[16 * i + 4 * fg + r][16 * j + fr], acc[i][j][r]);
   __syncthreads();
   if (!a.swap) {
+    float *dWo = a.grouped ? a.dWg[blockIdx.y] : a.dW + (long)n0 * a.ldw;
+    float *dbo = a.grouped ? a.dbg[blockIdx.y] : (a.db ? a.db + n0 : nullptr);
     for (int e = threadIdx.x; e < BN * 32; e += 256) {
       const int n = e >> 5, k = e & 31;
-      atomicAdd(a.dW + (long)(n0 + n) * a.ldw + k0 + k, red[n][k]);
+      atomicAdd(dWo + (long)n * a.ldw + k0 + k, red[n][k]);
     }
-    if (a.db && blockIdx.z == 0) {
+    if (dbo && blockIdx.z == 0) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         float s = bsum[i];
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        if (fg == 0) atomicAdd(a.db + n0 + 16 * i + fr, s);
+        if (fg == 0) atomicAdd(dbo + 16 * i + fr, s);
       }
     }
   } else {
@@ -667,6 +672,16 @@ __global__ __launch_bounds__(256) void gmm_bwd128_kernel(GmmBwdArgs a) {
   __syncthreads();
   for (int e = threadIdx.x; e < a.C * 3 * F; e += 256) atomicAdd(a.dw2[e / (3 * F)] + e % (3 * F), sw[e]);
   if (threadIdx.x < a.C * 3) atomicAdd(a.db2[threadIdx.x / 3] + threadIdx.x % 3, sw[16 * 3 * F + (threadIdx.x / 3) * 4 + threadIdx.x % 3]);
+}
+
+// Wcat[i][c F + f] = W1_c[f][i]: the C first-layer weights [F, d] of the GMM heads as ONE [d, C F] operand, so that
+// dz = sum_c dhid_c W1_c is one GEMM with K = C F instead of C accumulating ones
+struct PackW1Args { const float *w1[16]; int C, F, d; float *out; };
+__global__ void gmm_w1_pack_kernel(PackW1Args a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.C * a.F * a.d) return;
+  const int row = i / (a.C * a.F), col = i % (a.C * a.F), c = col / a.F, f = col % a.F;
+  a.out[i] = a.w1[c][f * a.d + row];
 }
 
 // Gradient of the step-invariant embeddings: X0[(t,b), row] = Ex[b, row] (+ Ey[b, p] while p is context),
