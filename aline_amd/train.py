@@ -47,6 +47,35 @@ def _grad_struct(model, into=None):
 _bwd_ws = _lib.Workspace()
 
 
+def flat_grads(model):
+    """One flat fp32 buffer that holds every gradient of `model`; `param.grad` are views into it.  The training step then
+    zeroes, all-reduces and clips the gradients with one kernel each, and the `aline_grads` pointer table is built once
+    (137 tensors at the default model: per-tensor zeroing, `clip_grad_norm_` and the ctypes table cost ~1 ms of host time per
+    step, visible as GPU idle gaps).  Returns (flat, grads_struct); rebuilt when somebody replaced a `.grad`."""
+    params = list(model.parameters())
+    cache = getattr(model, "_aline_flat", None)
+    if cache is not None:
+        flat, ptrs, struct = cache
+        try:
+            if [p.grad.data_ptr() for p in params] == ptrs:
+                return flat, struct
+        except AttributeError:                      # a .grad is None
+            pass
+    total = sum(p.numel() for p in params)
+    flat = torch.zeros(total, device=params[0].device, dtype=torch.float32)
+    off = 0
+    for p in params:
+        n = p.numel()
+        view = flat[off:off + n].view_as(p)
+        if p.grad is not None:
+            view.copy_(p.grad)
+        p.grad = view
+        off += n
+    struct = _grad_struct(model)
+    model._aline_flat = (flat, [p.grad.data_ptr() for p in params], struct)
+    return flat, struct
+
+
 def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, burn_in=False):
     """train_aline.py:97-132 on the rollout's per-step log-likelihoods.  Returns the losses and the two
     upstream gradients of `aline_rollout_backward` (dLoss/dlog_prob [B,T], dLoss/dtarget_ll [T,B,n_t])."""
@@ -77,10 +106,11 @@ def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, b
                 g_ll=g_ll.contiguous(), R=R)
 
 
-def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30):
+def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30, grads=None):
     """Accumulates dLoss/dW into param.grad of every weight of `model` (C ABI aline_rollout_backward)."""
     m, r = ro.m, ro.r
-    grads = _grad_struct(model)
+    if grads is None:
+        grads = _grad_struct(model)
     if t_chunk is None:
         t_chunk = ro.T
         while t_chunk > 1 and _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), t_chunk) > max_ws_bytes:
@@ -98,10 +128,15 @@ def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30):
 ALLREDUCE_CALLS = 0      # collectives issued by this process (bench.py reports the count per optimiser step)
 
 
-def all_reduce_grads(model, dist, world):
-    """One flat-bucket all-reduce (sum, then / world) of every gradient (RCCL over xGMI on the node)."""
+def all_reduce_grads(model, dist, world, flat=None):
+    """One flat-bucket all-reduce (sum, then / world) of every gradient (RCCL over xGMI on the node).  `flat`: the
+    buffer of `flat_grads` (the gradients are views of it: no gather / scatter copies)."""
     global ALLREDUCE_CALLS
     ALLREDUCE_CALLS += 1
+    if flat is not None:
+        dist.all_reduce(flat)
+        flat /= world
+        return
     params = [p for p in model.parameters() if p.grad is not None]
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat)
@@ -117,18 +152,19 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
                burn_in=False, forced_idx=None, clip_grads=True, dist=None, world=1, t_chunk=None):
     """One epoch body of train_aline.py:55-152 (without the hydra / logging shell)."""
     model.train()
-    grads = [p.grad for p in model.parameters() if p.grad is not None]
-    if grads:
-        torch._foreach_zero_(grads)              # one launch instead of one per parameter (137 at the default model)
     with torch.no_grad():
+        flat, gstruct = flat_grads(model)
+        flat.zero_()
         select = "forced" if forced_idx is not None else "sample"
         ro = Rollout(model, batch, T, select=select, forced_idx=forced_idx).run()
         terms = reinforce_terms(ro, embedding_type, mask_type, gamma, alpha, burn_in)
-        backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=t_chunk)
+        backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=t_chunk, grads=gstruct)
         if dist is not None and world > 1:
-            all_reduce_grads(model, dist, world)
+            all_reduce_grads(model, dist, world, flat=flat)
         if clip_grads:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0, norm_type="inf")   # train_aline.py:138
+            # torch.nn.utils.clip_grad_norm_(parameters, max_norm=1.0, norm_type="inf") of train_aline.py:138 on the flat buffer:
+            # total norm = max |g| over all tensors, coefficient = min(1, max_norm / (total + 1e-6))
+            flat.mul_((1.0 / (flat.abs().max() + 1e-6)).clamp(max=1.0))
         if optimizer is not None:
             optimizer.step()
     return terms, ro
