@@ -1869,8 +1869,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       a.g_mean = g_pm ? g_pm + (size_t)tA * B * n_t * C : nullptr;
       a.g_std = g_ps ? g_ps + (size_t)tA * B * n_t * C : nullptr;
       a.g_wgt = g_pw ? g_pw + (size_t)tA * B * n_t * C : nullptr;
-      if (F == 128 && env_on("ALINE_BWD_GMM128"))
-        hipLaunchKernelGGL(gmm_bwd128_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
+      if (F == 128 && C <= 10 && env_on("ALINE_BWD_GMM128"))
+        hipLaunchKernelGGL((gmm_bwd128_kernel<10, 128>), dim3((unsigned)((a.rows + 127) / 128)), dim3(256), 0, c.st, a);
+      else if (F == 128 && env_on("ALINE_BWD_GMM128"))
+        hipLaunchKernelGGL((gmm_bwd128_kernel<16, GMM_BWD_ROWS>), dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       else
       hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();

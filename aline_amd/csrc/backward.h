@@ -573,34 +573,36 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
 // ~25 us per row on the one wave per SIMD its 424 registers allow (1.65 ms per call at the headline shape, VALU busy 9 %).
 // Here the second-layer weights sit in LDS, the 2 C hidden values of a row are loaded in one batch (the next row's while this
 // one is computed) and stay in registers for both passes, and the 3 C reductions of a row run side by side.
-__global__ __launch_bounds__(256) void gmm_bwd128_kernel(GmmBwdArgs a) {
+// (CMAX = 10 or 16 components: the register arrays are sized by it -- 218 instead of 296 registers, two waves per SIMD)
+template <int CMAX, int ROWS>
+__global__ __launch_bounds__(256, CMAX <= 10 ? 2 : 1) void gmm_bwd128_kernel(GmmBwdArgs a) {
   constexpr int F = 128;
   __shared__ float sw[16 * 3 * F + 16 * 4];       // w2 [C][3][F], b2 [C][4]; reused for the gradient sums at the end
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long r_lo = (long)blockIdx.x * GMM_BWD_ROWS, r_hi = min(a.rows, r_lo + GMM_BWD_ROWS);
+  const long r_lo = (long)blockIdx.x * ROWS, r_hi = min(a.rows, r_lo + ROWS);
   for (int e = threadIdx.x; e < a.C * 3 * F; e += 256) sw[e] = a.w2[e / (3 * F)][e % (3 * F)];
   if (threadIdx.x < a.C * 3) sw[16 * 3 * F + (threadIdx.x / 3) * 4 + threadIdx.x % 3] = a.b2[threadIdx.x / 3][threadIdx.x % 3];
   __syncthreads();
-  float pw[16][3][2];
+  float pw[CMAX][3][2];
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
+  for (int c = 0; c < CMAX; ++c)
 #pragma unroll
     for (int o = 0; o < 3; ++o) pw[c][o][0] = pw[c][o][1] = 0.f;
   float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;      // lane c: bias gradients of component c
-  float nh[16][2];
+  float nh[CMAX][2];
   auto load_row = [&](long row) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+    for (int c = 0; c < CMAX; ++c)
       if (c < a.C) { const float *hp = a.hid + (row * a.C + c) * F; nh[c][0] = hp[lane]; nh[c][1] = hp[lane + 64]; }
   };
   if (r_lo + wave < r_hi) load_row(r_lo + wave);
   for (long row = r_lo + wave; row < r_hi; row += 4) {
-    float hv[16][2], ps[16][3];
+    float hv[CMAX][2], ps[CMAX][3];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) { hv[c][0] = nh[c][0]; hv[c][1] = nh[c][1]; }
+    for (int c = 0; c < CMAX; ++c) { hv[c][0] = nh[c][0]; hv[c][1] = nh[c][1]; }
     if (row + 4 < r_hi) load_row(row + 4);
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+    for (int c = 0; c < CMAX; ++c)
       if (c < a.C) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) ps[c][o] = fmaf(hv[c][0], sw[(c * 3 + o) * F + lane], hv[c][1] * sw[(c * 3 + o) * F + lane + 64]);
@@ -608,14 +610,14 @@ __global__ __launch_bounds__(256) void gmm_bwd128_kernel(GmmBwdArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
+      for (int c = 0; c < CMAX; ++c)
         if (c < a.C) {
 #pragma unroll
           for (int o = 0; o < 3; ++o) ps[c][o] += __shfl_xor(ps[c][o], off, WAVE);
         }
     float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+    for (int c = 0; c < CMAX; ++c)
       if (c < a.C && lane == c) {
         raw0 = ps[c][0] + sw[16 * 3 * F + c * 4]; raw1 = ps[c][1] + sw[16 * 3 * F + c * 4 + 1]; raw2 = ps[c][2] + sw[16 * 3 * F + c * 4 + 2];
       }
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void gmm_bwd128_kernel(GmmBwdArgs a) {
     const float d1 = dsd * (1.f / (1.f + __expf(-raw1)));                             // softplus'
     pb0 += d0; pb1 += d1; pb2 += d2;
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+    for (int c = 0; c < CMAX; ++c)
       if (c < a.C) {
         const float g0 = __shfl(d0, c, WAVE), g1 = __shfl(d1, c, WAVE), g2 = __shfl(d2, c, WAVE);
         float *hp = a.hid + (row * a.C + c) * F;
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void gmm_bwd128_kernel(GmmBwdArgs a) {
   for (int e = threadIdx.x; e < 16 * 3 * F + 16 * 4; e += 256) sw[e] = 0.f;
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
+  for (int c = 0; c < CMAX; ++c)
     if (c < a.C) {
 #pragma unroll
       for (int o = 0; o < 3; ++o) { atomicAdd(&sw[(c * 3 + o) * F + lane], pw[c][o][0]); atomicAdd(&sw[(c * 3 + o) * F + lane + 64], pw[c][o][1]); }
