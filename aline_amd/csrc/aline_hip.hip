@@ -1992,11 +1992,15 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     float *dEx = c.at(c.pl.dEx), *dEy = c.at(c.pl.dEy), *dH = c.at(c.pl.dHid);
     TRY(gemm_dw(c, dEx, d, EHx, F, gr->x_w2, gr->x_b2, rows_x, d, F));
     TRY(gemm_dx(c, dEx, d, m->x_w2, d, F, dH, F, rows_x, false, EHx));
+    if (F <= 128 && 1024 % F == 0) hipLaunchKernelGGL(embed_first_bwd_groups_kernel, dim3((rows_x + 255) / 256), dim3(std::min(1024, 8 * F)), 0, c.st, xs, P + n_td, B, m->dim_x, F, dH, gr->x_w1, gr->x_b1, 256);
+    else
     hipLaunchKernelGGL(embed_first_bwd_kernel, dim3((rows_x + 255) / 256), dim3(128), 0, c.st, xs, P + n_td, B,
                        m->dim_x, F, dH, gr->x_w1, gr->x_b1, 256);
     CHECK_LAUNCH();
     TRY(gemm_dw(c, dEy, d, EHy, F, gr->y_w2, gr->y_b2, rows_y, d, F));
     TRY(gemm_dx(c, dEy, d, m->y_w2, d, F, dH, F, rows_y, false, EHy));
+    if (F <= 128 && 1024 % F == 0) hipLaunchKernelGGL(embed_first_bwd_groups_kernel, dim3((rows_y + 255) / 256), dim3(std::min(1024, 8 * F)), 0, c.st, ys, P, B, m->dim_y, F, dH, gr->y_w1, gr->y_b1, 256);
+    else
     hipLaunchKernelGGL(embed_first_bwd_kernel, dim3((rows_y + 255) / 256), dim3(128), 0, c.st, ys, P, B, m->dim_y,
                        F, dH, gr->y_w1, gr->y_b1, 256);
     CHECK_LAUNCH();
