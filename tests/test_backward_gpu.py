@@ -205,3 +205,32 @@ def test_fused_backward_kernels_match_per_op_pipeline(T, B, monkeypatch):
             worst = (k, err)
     # both sides are exact-fp32 products in different summation orders
     assert worst[1] < 2e-4, worst
+
+
+def test_train_step_graph_rollout_takes_the_new_batch():
+    """`train_step` replays its sampled rollout from a HIP graph kept per (model, shapes, T): a second step on another batch
+    must be the rollout of THAT batch -- same designs, log-probabilities and log-likelihoods as a fresh eager rollout with
+    the uniform numbers the replay used -- and the flat gradient buffer must be what the optimiser sees."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd import train as tr
+    torch.manual_seed(11)
+    model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda()
+    task = HiddenLocation()
+    T, B = 7, 12
+    b1, b2 = task.sample_batch(B), task.sample_batch(B)
+    tr.train_step(model, b1, T)
+    terms, ro = tr.train_step(model, b2, T)                      # replay with b2 copied into the graph's inputs
+    torch.cuda.synchronize()
+    assert ro._graph is not None
+    fresh = Rollout(model, b2, T, select="sample", uniform=ro.uniform.clone()).run()
+    torch.cuda.synchronize()
+    assert torch.equal(fresh.idx, ro.idx) and torch.equal(fresh.log_prob, ro.log_prob)
+    assert torch.equal(fresh.target_ll, ro.target_ll)
+    flat, _ = tr.flat_grads(model)
+    off = 0
+    for p in model.parameters():
+        assert p.grad.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    assert float(flat.abs().max()) <= 1.0 + 1e-6                 # inf-norm clip at 1.0 (train_aline.py:138)
