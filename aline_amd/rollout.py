@@ -124,7 +124,9 @@ class Rollout:
         self._enqueue()                       # warm-up outside capture (function attributes etc.)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: other threads of the process (the RCCL watchdog under torch.distributed polls events) may keep
+        # calling the HIP runtime while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._enqueue()
         self._graph = g
         return self

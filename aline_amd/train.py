@@ -150,6 +150,7 @@ def all_reduce_grads(model, dist, world, flat=None):
 
 _ROLLOUT_GRAPHS = {}          # (model, shapes, T) -> captured Rollout; at most _MAX_GRAPHS of them
 _MAX_GRAPHS = 8
+_GRAPH_OK = True
 
 
 def _sampled_rollout(model, batch, T):
@@ -157,7 +158,8 @@ def _sampled_rollout(model, batch, T):
     per (model, batch shapes, T): the step's data is copied into the graph's input buffers, the uniform numbers are redrawn
     and the graph is replayed (3.2 ms of eager launches -> 2.9 ms at the headline shape).  ALINE_TRAIN_GRAPH=0: eager."""
     import os
-    if os.environ.get("ALINE_TRAIN_GRAPH", "1") == "0":
+    global _GRAPH_OK
+    if os.environ.get("ALINE_TRAIN_GRAPH", "1") == "0" or not _GRAPH_OK:
         return Rollout(model, batch, T, select="sample").run()
     g = lambda k: batch.get(k) if isinstance(batch, dict) else getattr(batch, k, None)    # noqa: E731
     tens = {k: g(k) for k in ("context_x", "context_y", "query_x", "query_y", "target_all", "target_x", "target_mask")}
@@ -168,7 +170,14 @@ def _sampled_rollout(model, batch, T):
     if ro is None:
         if len(_ROLLOUT_GRAPHS) >= _MAX_GRAPHS:
             _ROLLOUT_GRAPHS.pop(next(iter(_ROLLOUT_GRAPHS)))
-        ro = Rollout(model, batch, T, select="sample").capture()
+        try:
+            ro = Rollout(model, batch, T, select="sample").capture()
+        except RuntimeError as e:                   # a runtime that refuses the capture: eager launches from now on
+            import warnings
+            warnings.warn(f"aline_amd: HIP-graph capture of the training rollout failed ({e}); using eager launches")
+            _GRAPH_OK = False
+            torch.cuda.synchronize()
+            return Rollout(model, batch, T, select="sample").run()
         _ROLLOUT_GRAPHS[key] = ro
     else:
         torch.cat([_lib.f32(tens["context_x"]), _lib.f32(tens["query_x"])], dim=1, out=ro.px)
