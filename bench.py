@@ -561,11 +561,17 @@ def main():
         from aline_amd import train as train_mod
         from aline_amd.train import train_step
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
-        train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)        # warm-up
+        try:
+            train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)        # warm-up
+            train_ok = True
+        except Exception as e:      # a secondary leg must not take the headline line with it
+            log(f"train step leg failed: {e!r}")
+            out["train_step"] = {"error": repr(e)}
+            train_ok = False
         barrier()
         ar0 = train_mod.ALLREDUCE_CALLS
         t1 = time.perf_counter()
-        for _ in range(args.train_steps):
+        for _ in range(args.train_steps if train_ok else 0):
             train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)
         barrier()
         tdt = time.perf_counter() - t1
@@ -573,7 +579,8 @@ def main():
             tt = torch.tensor([tdt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tdt = float(tt.item())
-        out["train_step"] = {"value": world * designs_per_rollout * args.train_steps / tdt, "unit": "designs/s",
+        if train_ok:
+          out["train_step"] = {"value": world * designs_per_rollout * args.train_steps / tdt, "unit": "designs/s",
                              "ms_per_step": tdt / args.train_steps * 1e3, "steps": args.train_steps,
                              "includes": f"forward rollout ({path}) + fused exact-fp32 backward of all T steps (layer_fwd / tail / attention-block / acquisition-head kernels) + "
                                          "flat-bucket gradient all-reduce (N>1) + inf-norm clip + AdamW",
