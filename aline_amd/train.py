@@ -76,6 +76,18 @@ def flat_grads(model):
     return flat, struct
 
 
+_DISC = {}
+
+
+def _discounts(gamma, T, dev):
+    """[gamma^1 .. gamma^(T-1)] on the device, built once per (gamma, T): a host list -> device tensor every step is a blocking
+    copy in the middle of the step."""
+    key = (float(gamma), int(T), str(dev))
+    if key not in _DISC:
+        _DISC[key] = torch.tensor([gamma ** t for t in range(1, T)], device=dev)
+    return _DISC[key]
+
+
 def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, burn_in=False):
     """train_aline.py:97-132 on the rollout's per-step log-likelihoods.  Returns the losses and the two
     upstream gradients of `aline_rollout_backward` (dLoss/dlog_prob [B,T], dLoss/dtarget_ll [T,B,n_t])."""
@@ -87,7 +99,7 @@ def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, b
     design_loss = torch.zeros((), device=dev)
     R = None
     if T > 1:
-        disc = torch.tensor([gamma ** t for t in range(1, T)], device=dev)
+        disc = _discounts(gamma, T, dev)
         R = disc * torch.clamp(nll_q[:, :-1] - nll_q[:, 1:], min=0.0)    # [B, T-1], detached by construction
         R = (R - R.mean(dim=0, keepdim=True)) / (R.std(dim=0, keepdim=True) + 1e-9)
         design_loss = -(ro.log_prob[:, :-1] * R).mean()
