@@ -68,6 +68,35 @@ def _grad_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _flat_grad_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aline_amd.train import all_reduce_grads
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    params = list(model.parameters())
+    flat = torch.zeros(sum(p.numel() for p in params))
+    off = 0
+    for i, p in enumerate(params):                      # the layout train.flat_grads builds: every .grad a view of `flat`
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        p.grad.fill_(float(rank + 1) * (i + 1))
+        off += p.numel()
+    all_reduce_grads(model, dist, world, flat=flat)     # ONE collective on the buffer itself, no gather / scatter copies
+    if rank == 0:
+        out.put([float(p.grad.mean()) for p in params] + [float(p.grad.data_ptr() == flat.data_ptr()) for p in params[:1]])
+    dist.destroy_process_group()
+
+
+def test_flat_buffer_all_reduce_keeps_the_gradient_views():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_flat_grad_worker, args=(r, world, port, out)) for r in range(world)]
+    [p.start() for p in procs]
+    res = out.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert res[:4] == [1.5 * (i + 1) for i in range(4)] and res[4] == 1.0
+
+
 def test_flat_bucket_gradient_all_reduce_averages_over_ranks():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
