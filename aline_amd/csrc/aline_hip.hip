@@ -1809,16 +1809,20 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     const float *Z = do_enc ? Xs(L) : io.z_in;
     float *HidA = c.at(c.pl.HidA), *HidG = c.at(c.pl.HidG);
     const bool facq = do_head && fused_acq_head(*m);
+    // GMM heads without the [rows, C F] hidden activations (acq_head_bwd.h, gmmb).  ALINE_BWD_GMM_FUSED=0: the per-op kernels.
+    const bool fgmm = do_head && d == gmmb::D && F == gmmb::F && C <= 16 && n_t > 0 && env_on("ALINE_BWD_GMM_FUSED");
     if (do_head) {
       if (!facq) {
       GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, d, HidA, F, I * P, F, d, true);
       a.R_in = P; a.G_in = N; a.off_in = 0;
       TRY(launch_gemm(bwd_prec(), a, 1, c.st));
       }
+      if (!fgmm) {
       GemmArgs ag = gemm_args(Z, d, nullptr, nullptr, d, HidG, C * F, I * n_t, F, d, true);
       ag.R_in = n_t; ag.G_in = N; ag.off_in = P; ag.col_per_group = F;
       for (int k = 0; k < C; ++k) { ag.W[k] = m->gmm_w1[k]; ag.bias[k] = m->gmm_b1[k]; }
       TRY(launch_gemm(bwd_prec(), ag, C, c.st));
+      }
       CHECK_LAUNCH();
     }
 
@@ -1860,7 +1864,29 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
       CHECK_LAUNCH();
     }
-    if (do_head) {
+    if (fgmm) {
+      gmmb::Args a{};
+      a.Z = Z; a.n_t = n_t; a.N = N; a.P = P; a.rows = (long)I * n_t; a.C = C; a.std_min = m->std_min;
+      for (int k = 0; k < C; ++k) {
+        a.w1[k] = m->gmm_w1[k]; a.b1[k] = m->gmm_b1[k]; a.w2[k] = m->gmm_w2[k]; a.b2[k] = m->gmm_b2[k];
+        a.dw1[k] = gr->gmm_w1[k]; a.db1[k] = gr->gmm_b1[k]; a.dw2[k] = gr->gmm_w2[k]; a.db2[k] = gr->gmm_b2[k];
+      }
+      a.raw = HidG; a.draw = a.raw + a.rows * C * 4; a.dzc = a.draw + a.rows * C * 4; a.dZ = dX;      // (40 of the C F floats per row)
+      a.value = r->target_all; a.value_mod = (long)B * n_t;
+      a.g_ll = g_ll ? g_ll + (size_t)tA * B * n_t : nullptr;
+      a.g_mean = g_pm ? g_pm + (size_t)tA * B * n_t * C : nullptr;
+      a.g_std = g_ps ? g_ps + (size_t)tA * B * n_t * C : nullptr;
+      a.g_wgt = g_pw ? g_pw + (size_t)tA * B * n_t * C : nullptr;
+      const long groups = ((a.rows + 15) / 16 + gmmb::WAVES - 1) / gmmb::WAVES;
+      hipLaunchKernelGGL(gmmb::raw_kernel, dim3((unsigned)std::min<long>(groups, std::max(1, 768 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS_RAW * sizeof(float), c.st, a);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(gmmb::draw_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, c.st, a);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(gmmb::bwd_kernel, dim3((unsigned)std::min<long>(groups, std::max(1, 256 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS * sizeof(float), c.st, a);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(gmmb::dzsum_kernel, grid1d((size_t)a.rows * 8), dim3(256), 0, c.st, a);
+      CHECK_LAUNCH();
+    } else if (do_head) {
       GmmBwdArgs a{};
       a.hid = HidG; a.rows = (long)I * n_t; a.C = C; a.F = F; a.std_min = m->std_min;
       for (int k = 0; k < C; ++k) { a.w2[k] = m->gmm_w2[k]; a.b2[k] = m->gmm_b2[k]; a.dw2[k] = gr->gmm_w2[k]; a.db2[k] = gr->gmm_b2[k]; }

@@ -188,7 +188,7 @@ def test_fused_backward_kernels_match_per_op_pipeline(T, B, monkeypatch):
         terms = reinforce_terms(ro, "theta")
         grads = []
         for fused in ("1", "0"):
-            for k in ("ALINE_BWD_TAIL", "ALINE_BWD_ATTN_BLOCK", "ALINE_BWD_ACQ", "ALINE_BWD_LAYER_FWD", "ALINE_BWD_GMM128", "ALINE_BWD_GMM_BATCHED"):
+            for k in ("ALINE_BWD_TAIL", "ALINE_BWD_ATTN_BLOCK", "ALINE_BWD_ACQ", "ALINE_BWD_LAYER_FWD", "ALINE_BWD_GMM128", "ALINE_BWD_GMM_BATCHED", "ALINE_BWD_GMM_FUSED"):
                 monkeypatch.setenv(k, fused)
             for p in model.parameters():
                 p.grad = None
