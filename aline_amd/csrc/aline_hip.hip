@@ -1472,6 +1472,8 @@ static bool bwd_fused_tail(const aline_model &m) { return m.d == tailbwd::D && m
 // Acquisition head backward without the [I P, F] hidden activations (acq_head_bwd.h).  ALINE_BWD_ACQ=0: the per-op kernels.
 static bool fused_acq_head(const aline_model &m) { return m.d == acqb::D && m.F == acqb::F && env_on("ALINE_BWD_ACQ"); }
 
+static bool fused_gmm_heads(const aline_model &m) { return m.d == gmmb::D && m.F == gmmb::F && m.C <= 16 && env_on("ALINE_BWD_GMM_FUSED"); }
+
 // In-projection + attention backward as one kernel (attn_bwd_mfma.h).  ALINE_BWD_ATTN_BLOCK=0: the per-op kernels.
 static bool fused_attn_block(const aline_model &m, int max_keys) {
   return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK && env_on("ALINE_BWD_ATTN_BLOCK");
@@ -1492,7 +1494,8 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   p.Hid = take(ft ? 0 : L * M * F);
   p.U2 = take(ft ? 0 : L * M * d);
   p.HidA = take(fused_acq_head(m) ? 0 : I * P * F);
-  p.HidG = take(I * n_t * m.C * F);
+  // (fused GMM kernels: raw / draw [rows, C, 4] each + dz per component [C, rows, 32] instead of the hidden units [rows, C F])
+  p.HidG = take(I * n_t * m.C * (fused_gmm_heads(m) ? 40 : F));
   p.dXa = take(M * d);
   p.dXb = take(M * d);
   p.dQKV = take(M * 3 * d);
@@ -1810,7 +1813,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     float *HidA = c.at(c.pl.HidA), *HidG = c.at(c.pl.HidG);
     const bool facq = do_head && fused_acq_head(*m);
     // GMM heads without the [rows, C F] hidden activations (acq_head_bwd.h, gmmb).  ALINE_BWD_GMM_FUSED=0: the per-op kernels.
-    const bool fgmm = do_head && d == gmmb::D && F == gmmb::F && C <= 16 && n_t > 0 && env_on("ALINE_BWD_GMM_FUSED");
+    const bool fgmm = do_head && n_t > 0 && fused_gmm_heads(*m);
     if (do_head) {
       if (!facq) {
       GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, d, HidA, F, I * P, F, d, true);
