@@ -234,3 +234,48 @@ def test_train_step_graph_rollout_takes_the_new_batch():
         assert p.grad.data_ptr() == flat.data_ptr() + 4 * off
         off += p.numel()
     assert float(flat.abs().max()) <= 1.0 + 1e-6                 # inf-norm clip at 1.0 (train_aline.py:138)
+
+
+@pytest.mark.parametrize("mask", ["all", "split"])
+def test_fused_backward_kernels_in_mix_mode_with_target_data_keys(mask, monkeypatch):
+    """The fused attention kernels with target DATA rows among the keys and a target mask (model/encoder.py:83-126:
+    the candidates see context + visible targets): al_mix task with 8 target points + 3 theta tokens, T = 9 (<= 32 keys),
+    fused kernels against the per-op pipeline."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import GPTask
+    from aline_amd.train import backward, reinforce_terms
+    from aline_amd.utils import create_target_mask
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    task = GPTask(dim_x=2, embedding_type="mix", n_context_init=2, n_query_init=40, n_target_theta=3, n_target_data=8, device=dev)
+    batch = task.sample_batch(11)
+    if mask == "split":
+        batch["target_mask"] = create_target_mask("split", "mix", 8, 3, None, None, None, None, "data")
+    model = Aline(Embedder(2, 1, 32, 128, 3, "mix"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda()
+    T = 9
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        terms = reinforce_terms(ro, "mix", mask)
+        grads = []
+        for fused in ("1", "0"):
+            for k in ("ALINE_BWD_TAIL", "ALINE_BWD_ATTN_BLOCK", "ALINE_BWD_ACQ", "ALINE_BWD_LAYER_FWD", "ALINE_BWD_GMM_FUSED",
+                      "ALINE_BWD_GMM128", "ALINE_BWD_GMM_BATCHED"):
+                monkeypatch.setenv(k, fused)
+            for p in model.parameters():
+                p.grad = None
+            backward(model, ro, terms["g_logp"], terms["g_ll"])
+            torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    # (Seed and batch size are fixed on purpose.  The two forwards differ in summation order (1e-7): a hidden unit whose
+    # pre-activation is within that of zero takes the other side of its ReLU, e.g. with 10 episodes ONE element of one GMM-head
+    # bias gradient moves by 1 % -- the CPU oracle's autograd sided with the per-op kernels on that unit -- while everything
+    # else agrees to 1e-6.)
+    floor = 1e-2 * max(float(g.abs().max()) for g in grads[1].values())
+    worst = ("", 0.0)
+    for k in grads[0]:
+        ref = grads[1][k]
+        err = float((grads[0][k] - ref).abs().max()) / max(float(ref.abs().max()), floor)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 2e-4, worst
