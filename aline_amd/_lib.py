@@ -93,6 +93,7 @@ def _load():
         "aline_rollout_step": (C.c_int, [MP, RP, C.c_int, _fp, C.c_size_t, _fp]),
         "aline_rollout_forward": (C.c_int, [MP, RP, _fp, C.c_size_t, _fp]),
         "aline_rollout_path": (C.c_int, [MP, RP]),
+        "aline_rollout_kernel_name": (C.c_int, [MP, RP, C.c_char_p, C.c_size_t]),
         "aline_rollout_export": (C.c_int, [RP, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
         "aline_compute_ll": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, _fp, _fp]),
         "aline_eig_location_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_int,
@@ -100,6 +101,11 @@ def _load():
         "aline_eig_ces_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_float,
                                          C.c_float, _fp, _fp]),
         "aline_eig_finalize_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+        "aline_f16_range_offset": (C.c_size_t, []),
+        "aline_f16_range_status": (C.c_int, [_fp, _fp]),
+        "aline_debug_set_flags": (C.c_uint32, [C.c_uint32]),
+        "aline_debug_get_flags": (C.c_uint32, []),
+        "aline_debug_set_param": (C.c_int, [C.c_int, C.c_int]),
         "aline_debug_stamps_offset": (C.c_size_t, [MP, RP]),
         "aline_debug_wlog_offset": (C.c_size_t, [MP, RP]),
         "aline_debug_xraw_offset": (C.c_size_t, [MP, RP]),
@@ -115,12 +121,91 @@ def _load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.aline_abi_version() != 2:
+    if lib.aline_abi_version() != 3:
         raise RuntimeError("aline_amd: libaline_hip.so ABI version mismatch")
     return lib, sig
 
 
 lib, SIGNATURES = _load()
+
+# ---- diagnostics: the library never reads the environment; tests and A/B tools set its diagnostic word explicitly -------
+DBG = {"DISABLE_FUSED": 1 << 0, "DISABLE_WIDE": 1 << 1, "DISABLE_X3": 1 << 2, "DISABLE_S3": 1 << 3, "WIDE_BLOCKS": 1 << 4,
+       "NO_LAYER_TAIL": 1 << 5, "FULL_QKV": 1 << 6, "VALU_ATTENTION": 1 << 7, "S3_GENERIC_EMBED": 1 << 8, "CES_GENERIC": 1 << 9,
+       "FUSED_STAMPS": 1 << 10, "WIDE_STAMPS": 1 << 11, "BWD_TAIL_PC": 1 << 12,
+       "NO_BWD_TAIL": 1 << 16, "NO_BWD_ATTN_BLOCK": 1 << 17, "NO_BWD_ACQ": 1 << 18, "NO_BWD_LAYER_FWD": 1 << 19,
+       "NO_BWD_LAYER_FWD_FLAT": 1 << 20, "NO_BWD_GMM_FUSED": 1 << 21, "NO_BWD_GMM128": 1 << 22, "NO_BWD_GMM_BATCHED": 1 << 23,
+       "NO_BWD_ATTN_MFMA": 1 << 24, "X3_LEGACY_HEAD": 1 << 25}
+DBG_PARAM = {"S3_WAVES": 0, "S3_EPW": 1, "BWD_PREC": 2}
+
+
+class debug:
+    """with _lib.debug("DISABLE_FUSED", S3_WAVES=16): ...   -- sets bits / knobs of the library's diagnostic word for the
+    block (names: DBG / DBG_PARAM = the ALINE_DBG_* enumerators of include/aline_hip.h) and restores them afterwards."""
+
+    def __init__(self, *flags, **params):
+        self.bits = 0
+        for f in flags:
+            self.bits |= DBG[f]
+        self.params = {DBG_PARAM[k]: int(v) for k, v in params.items()}
+
+    def __enter__(self):
+        self.old = lib.aline_debug_get_flags()
+        lib.aline_debug_set_flags(self.old | self.bits)
+        for k, v in self.params.items():
+            check(lib.aline_debug_set_param(k, v), "debug_set_param")
+        return self
+
+    def __exit__(self, *exc):
+        lib.aline_debug_set_flags(self.old)
+        for k in self.params:
+            lib.aline_debug_set_param(k, 0)
+        return False
+
+
+def debug_env(env):
+    """The same from a dict keyed like the former environment switches, e.g. {"ALINE_DISABLE_WIDE": "1", "ALINE_S3_WAVES": "16",
+    "ALINE_BWD_TAIL": "0"} (tests / tools keep their tables of variants in this form)."""
+    flags, params = [], {}
+    for k, v in env.items():
+        name = k[len("ALINE_"):] if k.startswith("ALINE_") else k
+        if name in DBG_PARAM:
+            params[name] = int(v)
+        elif name in DBG:
+            if str(v) not in ("", "0"):
+                flags.append(name)
+        elif "NO_" + name in DBG:               # ALINE_BWD_TAIL = 0  ->  NO_BWD_TAIL
+            if str(v) == "0":
+                flags.append("NO_" + name)
+        else:
+            raise KeyError(f"unknown diagnostic switch {k}")
+    return debug(*flags, **params)
+
+
+def _flags_from_environment():
+    """Command-line convenience for the tools/ scripts (`ALINE_DBG=DISABLE_FUSED,S3_WAVES=16 python tools/...`), applied once
+    at import by THIS module -- the shared library itself has no environment switches."""
+    spec = os.environ.get("ALINE_DBG", "")
+    bits = 0
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            check(lib.aline_debug_set_param(DBG_PARAM[k], int(v)), "debug_set_param")
+        else:
+            bits |= DBG[item]
+    if bits:
+        lib.aline_debug_set_flags(bits)
+
+
+_flags_from_environment()
+
+
+def f16_range_status(ws, device):
+    """Reads (host-synchronising) the f16 range status word of a workspace: 0 = clean, bit 0 = an activation operand,
+    bit 1 = a weight left f16's range in an F16X3 kernel (include/aline_hip.h)."""
+    rc = lib.aline_f16_range_status(ws.data_ptr(), stream_ptr(device))
+    if rc < 0:
+        check(rc, "f16_range_status")
+    return rc
 
 
 def check(rc, what):

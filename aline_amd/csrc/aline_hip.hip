@@ -20,10 +20,19 @@
 #include "layer_fwd.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 
 namespace {
+
+// Diagnostic word / knobs of include/aline_hip.h (aline_debug_set_flags / aline_debug_set_param): 0 in normal operation.
+// The library never reads the environment; the Python mirror translates its ALINE_* debug variables into this word.
+std::atomic<uint32_t> g_debug_flags{0};
+std::atomic<int> g_debug_params[ALINE_DBG_NPARAMS] = {};
+inline bool dbg(uint32_t bit) { return (g_debug_flags.load(std::memory_order_relaxed) & bit) != 0; }
+inline int dbg_param(int key) { return g_debug_params[key].load(std::memory_order_relaxed); }
 
 inline size_t align_up(size_t v, size_t a = 64) { return (v + a - 1) / a * a; }
 
@@ -42,7 +51,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
+  size_t Flag, Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -53,6 +62,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
   const size_t Cc = (size_t)std::max(m.C, 1);
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
+  p.Flag = take(16);     // f16 range status word (aline_f16_range_offset() == 0 for every plan)
   p.Ex = take((size_t)B * (P + n_td) * d);
   p.Ey = take((size_t)B * ey_rows * d);
   size_t hid = std::max({(size_t)B * (P + n_td) * F, (size_t)B * ey_rows * F, M * F,
@@ -168,9 +178,28 @@ struct Ctx {
   float *ws;
   hipStream_t st;
   float *at(size_t off) const { return ws + off; }
+  unsigned *flag() const { return reinterpret_cast<unsigned *>(ws + pl.Flag); }     // f16 range guard (common.h)
+  int clear_flag() const { return hipMemsetAsync(ws + pl.Flag, 0, 64, st) == hipSuccess ? ALINE_OK : ALINE_ELAUNCH; }
 };
 
 inline dim3 grid1d(size_t total, int block = 256) { return dim3((unsigned)((total + block - 1) / block)); }
+
+// design selection of one step (model/head.py:347-362): LDS = logits | compacted slots | probabilities, 12 bytes per point slot.
+// ALINE_MAX_POINTS (4096) covers the evaluation protocol's n_query = 2000 (README.md:45,50) within the default 64 KB of dynamic LDS.
+int launch_acq_select(const Ctx &c, const SelectArgs &sel) {
+  if (sel.g.P > ALINE_MAX_POINTS) return ALINE_EUNSUPPORTED;
+  SelectArgs a = sel;
+  a.range_flag = c.flag();
+  hipLaunchKernelGGL(acq_select_kernel, dim3(a.g.B), dim3(256), (size_t)a.g.P * 12, c.st, a);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// forward GEMM in the model's precision, with the f16 range guard attached
+int launch_gemm_fwd(const Ctx &c, GemmArgs a, int groups) {
+  a.range_flag = c.flag();
+  return launch_gemm(c.m->precision, a, groups, c.st);
+}
 
 // x/y point embedders -> Ex [B*(P+n_td), d], Ey [B*ey_rows, d]     (model/embedder.py:47-57)
 int do_embed_points(const Ctx &c, Src3 xs, const float *ysrc, int ey_rows) {
@@ -180,8 +209,8 @@ int do_embed_points(const Ctx &c, Src3 xs, const float *ysrc, int ey_rows) {
   hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_x * m.F), dim3(256), 0, c.st, xs,
                      c.g.P + c.g.n_td, c.g.B, m.dim_x, m.F, m.x_w1, m.x_b1, hid);
   CHECK_LAUNCH();
-  TRY(launch_gemm(m.precision, gemm_args(hid, m.F, m.x_w2, m.x_b2, m.F, c.at(c.pl.Ex), m.d, rows_x,
-                                         m.d, m.F, false), 1, c.st));
+  TRY(launch_gemm_fwd(c, gemm_args(hid, m.F, m.x_w2, m.x_b2, m.F, c.at(c.pl.Ex), m.d, rows_x,
+                                         m.d, m.F, false), 1));
   CHECK_LAUNCH();
   const int rows_y = c.g.B * ey_rows;
   if (rows_y > 0) {
@@ -189,8 +218,8 @@ int do_embed_points(const Ctx &c, Src3 xs, const float *ysrc, int ey_rows) {
     hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_y * m.F), dim3(256), 0, c.st, ys,
                        ey_rows, c.g.B, m.dim_y, m.F, m.y_w1, m.y_b1, hid);
     CHECK_LAUNCH();
-    TRY(launch_gemm(m.precision, gemm_args(hid, m.F, m.y_w2, m.y_b2, m.F, c.at(c.pl.Ey), m.d, rows_y,
-                                           m.d, m.F, false), 1, c.st));
+    TRY(launch_gemm_fwd(c, gemm_args(hid, m.F, m.y_w2, m.y_b2, m.F, c.at(c.pl.Ey), m.d, rows_y,
+                                           m.d, m.F, false), 1));
     CHECK_LAUNCH();
   }
   return ALINE_OK;
@@ -247,7 +276,7 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
   const int hd = d / m.H;
   // small-width model in reference precision: the token-local tail of a layer (out-projection, LN1, FFN, LN2) is
   // one kernel on the packed layer images of the fused path (fused_tail.h)
-  const bool tail = (m.precision == ALINE_PREC_F32 || m.precision == ALINE_PREC_F16X3) && d == fused::D && F == fused::F && !getenv("ALINE_NO_LAYER_TAIL");
+  const bool tail = (m.precision == ALINE_PREC_F32 || m.precision == ALINE_PREC_F16X3) && d == fused::D && F == fused::F && !dbg(ALINE_DBG_NO_LAYER_TAIL);
   float *wimg = c.at(c.pl.Wpack);
   if (tail) {
     fused::PackArgs pa{};
@@ -267,7 +296,7 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
   }
   // Q for every token row, K / V for the key rows only (context points + visible targets: max_keys of the N rows of an
   // episode, e.g. 34 of 205 at cfg5): the key list is the same for all layers of a step
-  const bool compact_kv = max_keys < c.g.N && !getenv("ALINE_FULL_QKV");
+  const bool compact_kv = max_keys < c.g.N && !dbg(ALINE_DBG_FULL_QKV);
   int *keyidx = reinterpret_cast<int *>(c.at(c.pl.KeyIdx)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.Kcnt));
   float *KVc = QKV + (size_t)M * d;
   const int Mk = c.g.B * max_keys;
@@ -277,21 +306,21 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
   }
   for (int l = 0; l < m.L; ++l) {
     if (compact_kv) {
-      TRY(launch_gemm(m.precision, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, d, M, d, d, false), 1, c.st));
+      TRY(launch_gemm_fwd(c, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, d, M, d, d, false), 1));
       CHECK_LAUNCH();
       GemmArgs ka = gemm_args(cur, d, m.in_proj_w[l] + (size_t)d * d, m.in_proj_b[l] + d, d, KVc, 2 * d, Mk, 2 * d, d, false);
       ka.row_index = keyidx;
-      TRY(launch_gemm(m.precision, ka, 1, c.st));
+      TRY(launch_gemm_fwd(c, ka, 1));
       CHECK_LAUNCH();
     } else {
-      TRY(launch_gemm(m.precision, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, 3 * d, M,
-                                             3 * d, d, false), 1, c.st));
+      TRY(launch_gemm_fwd(c, gemm_args(cur, d, m.in_proj_w[l], m.in_proj_b[l], d, QKV, 3 * d, M,
+                                             3 * d, d, false), 1));
       CHECK_LAUNCH();
     }
     const float *kvc = compact_kv ? KVc : nullptr;
     // head_dim 32 / 64 outside the exact-fp32 mode, up to 64 keys: the attention on the matrix pipe (attn3.h)
     if (compact_kv && (hd == 32 || hd == 64) && max_keys <= 16 * attn3::MAX_KT && m.precision != ALINE_PREC_F32 &&
-        !getenv("ALINE_VALU_ATTENTION")) {
+        !dbg(ALINE_DBG_VALU_ATTENTION)) {
       const dim3 grid((unsigned)((c.g.B + 7) / 8 * 8 * m.H));
       if (hd == 64) hipLaunchKernelGGL(attn3::attention_kernel<64>, grid, dim3(256), 0, c.st, c.g, d, QKV, KVc, kcnt, A, max_keys);
       else hipLaunchKernelGGL(attn3::attention_kernel<32>, grid, dim3(256), 0, c.st, c.g, d, QKV, KVc, kcnt, A, max_keys);
@@ -317,15 +346,13 @@ int do_encoder(const Ctx &c, const float *x_in, float *x_out, int max_keys) {
       cur = dst;
       continue;
     }
-    TRY(launch_gemm(m.precision, gemm_args(A, d, m.out_proj_w[l], m.out_proj_b[l], d, Tm, d, M, d, d,
-                                           false), 1, c.st));
+    TRY(launch_gemm_fwd(c, gemm_args(A, d, m.out_proj_w[l], m.out_proj_b[l], d, Tm, d, M, d, d,
+                                           false), 1));
     CHECK_LAUNCH();
     TRY(launch_add_layernorm(c.st, cur, Tm, m.norm1_w[l], m.norm1_b[l], X1, (long)M, d, nullptr));
-    TRY(launch_gemm(m.precision, gemm_args(X1, d, m.lin1_w[l], m.lin1_b[l], d, Hid, F, M, F, d, true),
-                    1, c.st));
+    TRY(launch_gemm_fwd(c, gemm_args(X1, d, m.lin1_w[l], m.lin1_b[l], d, Hid, F, M, F, d, true), 1));
     CHECK_LAUNCH();
-    TRY(launch_gemm(m.precision, gemm_args(Hid, F, m.lin2_w[l], m.lin2_b[l], F, Tm, d, M, d, F, false),
-                    1, c.st));
+    TRY(launch_gemm_fwd(c, gemm_args(Hid, F, m.lin2_w[l], m.lin2_b[l], F, Tm, d, M, d, F, false), 1));
     CHECK_LAUNCH();
     float *dst = (l == m.L - 1 && x_out) ? x_out : X;
     TRY(launch_add_layernorm(c.st, X1, Tm, m.norm2_w[l], m.norm2_b[l], dst, (long)M, d, nullptr));
@@ -350,7 +377,7 @@ struct HeadIO {
 static int gmm_heads(const Ctx &c, GemmArgs a, int rows, float *mean, float *sd, float *wgt, const float *value,
                      float *ll, long value_row0, long value_mod) {
   const aline_model &m = *c.m;
-  if ((m.precision == ALINE_PREC_F32 || m.precision == ALINE_PREC_F16X3) && m.d == fused::D && m.F == fused::F && !getenv("ALINE_NO_LAYER_TAIL")) {
+  if ((m.precision == ALINE_PREC_F32 || m.precision == ALINE_PREC_F16X3) && m.d == fused::D && m.F == fused::F && !dbg(ALINE_DBG_NO_LAYER_TAIL)) {
     // small-width model: all C heads, the parameter maps and compute_ll in one kernel on the transposed register
     // scheme of the fused path (fused_side.h), first layers as packed split-bf16 fragments
     float *side = c.at(c.pl.Wpack) + (size_t)ALINE_MAX_LAYERS * fused::LAYER_FLOATS + fused::HEAD_FLOATS;
@@ -375,9 +402,10 @@ static int gmm_heads(const Ctx &c, GemmArgs a, int rows, float *mean, float *sd,
   a.col_per_group = 0;
   for (int k = 0; k < m.C; ++k) { a.W[k] = m.gmm_w1[k]; a.bias[k] = m.gmm_b1[k]; a.red_w[k] = m.gmm_w2[k]; a.red_b[k] = m.gmm_b2[k]; }
   a.red_nout = 3; a.red_out = raw; a.red_stride = stride; a.red_block_stride = (long)rows * stride;
-  TRY(launch_gemm(m.precision, a, m.C, c.st));
+  TRY(launch_gemm_fwd(c, a, m.C));
   CHECK_LAUNCH();
   wide::GmmRawArgs f{};
+  f.range_flag = c.flag();
   f.raw = raw; f.raw_stride = stride; f.rows = rows; f.C = m.C; f.std_min = m.std_min;
   f.nblk = gemm_col_blocks(m.F); f.blk_stride = (long)rows * stride;
   f.mean = mean; f.sd = sd; f.wgt = wgt;
@@ -426,13 +454,12 @@ int do_acquisition(const Ctx &c, const float *Z, HeadIO io) {
   if (m.time_token) { a.tscalar = io.time_t; a.tcol = m.acq_w1 + m.d; a.tcol_stride = m.d + 1; }
   a.red_w[0] = m.acq_w2; a.red_b[0] = m.acq_b2; a.red_nout = 1; a.red_out = logits; a.red_stride = 1;
   a.red_block_stride = (long)g.B * g.P;
-  TRY(launch_gemm(m.precision, a, 1, c.st));
+  TRY(launch_gemm_fwd(c, a, 1));
   CHECK_LAUNCH();
   io.sel.g = g; io.sel.F = m.F; io.sel.hid = nullptr; io.sel.w2 = m.acq_w2; io.sel.b2 = m.acq_b2;
   io.sel.logits = logits; io.sel.logit_stride = g.P;
   io.sel.logit_nblk = gemm_col_blocks(m.F); io.sel.logit_blk_stride = (long)g.B * g.P;
-  if (g.P > 1024) return ALINE_EUNSUPPORTED;
-  hipLaunchKernelGGL(acq_select_kernel, dim3(g.B), dim3(256), (size_t)g.P * 8, c.st, io.sel);
+  TRY(launch_acq_select(c, io.sel));
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -536,18 +563,20 @@ static int launch_wide_block(const Ctx &c, wide::BlockArgs a) {
 }
 
 
-static int device_cus() {
-  static int n = 0;
+static int device_cus() {      // compute units of the CURRENT device (cached per device: a process may drive several)
+  static std::atomic<int> cache[64] = {};
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
   if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
+    n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    cache[dev].store(n, std::memory_order_relaxed);
   }
   return n;
 }
 
 // Launch shape of the s3 step kernel: 12 waves per workgroup (3 per SIMD, 170 registers: no spills; 16 waves at 128
-// registers measured 1.5 % slower, ALINE_S3_WAVES=16) while an episode never holds more than 64 keys, 8 waves (256
+// registers measured 1.5 % slower, ALINE_DBG_S3_WAVES = 16) while an episode never holds more than 64 keys, 8 waves (256
 // registers: all scores of a head pair over 160 keys) otherwise; as many episodes per
 // workgroup as keeps every CU busy and the token tiles spread evenly over the waves.
 struct S3Shape { int nw, nkp, epw; unsigned nwg; size_t lds; };     // nkp: key-tile pairs an episode's LDS slot holds
@@ -557,7 +586,7 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
   const int nkeys = r.n_ctx0 + r.T - 1 + n_t;
   const int need = std::max(1, (nkeys + 31) / 32);
   s.nw = need <= 2 ? 12 : 8;
-  if (const char *e = getenv("ALINE_S3_WAVES")) s.nw = (atoi(e) == 16 || atoi(e) == 12) && need <= 2 ? atoi(e) : 8;
+  if (const int w = dbg_param(ALINE_DBG_S3_WAVES)) s.nw = (w == 16 || w == 12) && need <= 2 ? w : 8;
   s.nkp = s.nw >= 12 ? 2 : s3::NKP_MAX;
   const int per_ep = s3::kv_ep_bytes(s.nkp) + 32 * s.nkp * 4;
   const int epw_max = std::max(1, std::min(s3::EPW_MAX, (s3::LDS_LIMIT - s3::KV_OFF - s3::MISC_INTS * 4) / per_ep));
@@ -570,7 +599,7 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
     const double cost = rounds * slots;
     if (cost < best - 1e-9) { best = cost; s.epw = e; }
   }
-  if (const char *e = getenv("ALINE_S3_EPW")) s.epw = std::max(1, std::min(epw_max, atoi(e)));
+  if (const int e = dbg_param(ALINE_DBG_S3_EPW)) s.epw = std::max(1, std::min(epw_max, e));
   s.nwg = (unsigned)((r.B + s.epw - 1) / s.epw);
   s.lds = (size_t)s3::step_lds_bytes(s.epw, s.nkp);
   return s;
@@ -583,11 +612,8 @@ static int launch_s3_step_v(const Ctx &c, const S3Shape &sh, const s3::StepArgs 
 #else
   constexpr bool PF = false;
 #endif
-  static size_t attr = 0;
-  if (sh.lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F, NW, MAXNKP, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
-    attr = sh.lds;
-  }
+  // (set at every launch: the attribute is per device, and a process may drive several)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F, NW, MAXNKP, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
   hipLaunchKernelGGL((s3::step_kernel<F, NW, MAXNKP, PF>), dim3(sh.nwg), dim3(NW * 64), sh.lds, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;
@@ -626,11 +652,7 @@ static int launch_s3_embed(const Ctx &c, int F, const s3::EmbArgs &a) {
 template <int F>
 static int launch_s3_gmm_f(const Ctx &c, const s3::GmmArgs &a) {
   const size_t smem = (size_t)s3::head_bytes(F) + (size_t)3 * a.C * s3::GROWS * sizeof(float);
-  static size_t attr = 0;
-  if (smem > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::gmm_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = smem;
-  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::gmm_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const long per_wg = (long)s3::WAVES * s3::GT;
   hipLaunchKernelGGL(s3::gmm_kernel<F>, dim3((unsigned)((a.ntiles + per_wg - 1) / per_wg)), dim3(s3::THREADS), smem, c.st, a);
   CHECK_LAUNCH();
@@ -668,6 +690,7 @@ const char *aline_error_string(int code) {
     case ALINE_EUNSUPPORTED: return "unsupported shape/configuration";
     case ALINE_EWORKSPACE: return "workspace too small";
     case ALINE_ELAUNCH: return "kernel launch failed";
+    case ALINE_ERANGE: return "an F16X3 operand left f16's range (non-finite or >= 65504)";
   }
   return "unknown error";
 }
@@ -684,6 +707,7 @@ int aline_embed_forward(const aline_model *m, const aline_step *s, void *ws, siz
   Ctx c;
   TRY(step_ctx(m, s, ws, ws_bytes, stream, c, ST_EMBED));
   if (!s->embedding) return ALINE_EINVAL;
+  TRY(c.clear_flag());
   return step_embed(c, *s, s->embedding);
 }
 
@@ -709,6 +733,7 @@ int aline_step_forward(const aline_model *m, const aline_step *s, void *ws, size
   Ctx c;
   TRY(step_ctx(m, s, ws, ws_bytes, stream, c, ST_ALL));
   TRY(check_select(s->select_mode, s->uniform, s->forced_idx));
+  TRY(c.clear_flag());
   float *X0 = s->embedding ? s->embedding : c.at(c.pl.X);
   TRY(step_embed(c, *s, X0));
   TRY(do_encoder(c, X0, s->encoding, c.g.n_ctx + c.g.n_td + c.g.n_th));
@@ -749,6 +774,7 @@ int aline_rollout_init(const aline_model *m, const aline_rollout *r, void *ws, s
                        void *stream) {
   Ctx c;
   TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
+  TRY(c.clear_flag());
   hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B,
                      r->P, r->n_ctx0);
   CHECK_LAUNCH();
@@ -812,7 +838,7 @@ int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void
 // The fused per-episode kernel (fused_rollout.h) covers the small-width theta-mode models.
 static bool fused_eligible(const aline_model &m, const aline_rollout &r) {
   if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
-  if (getenv("ALINE_DISABLE_FUSED")) return false;
+  if (dbg(ALINE_DBG_DISABLE_FUSED)) return false;
   if (m.precision != ALINE_PREC_F32) return false;
   if (m.d != fused::D || m.F != fused::F || m.H != fused::H || m.time_token) return false;
   if (m.embedding_type != ALINE_EMB_THETA || r.n_target_data != 0) return false;
@@ -826,6 +852,7 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   Ctx c;
   TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
   TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
+  TRY(c.clear_flag());
   fused::PackArgs pa{};
   pa.L = m->L;
   for (int l = 0; l < m->L; ++l) {
@@ -869,7 +896,7 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   // ALINE_FUSED_STAMPS=1 selects the diagnostic (s_memtime-stamped) instantiation; the stamps land
   // in the tail of the workspace scalar block and are never read by product code.
   if (r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
-  if (getenv("ALINE_FUSED_STAMPS")) {
+  if (dbg(ALINE_DBG_FUSED_STAMPS)) {
     a.stamps = reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused::rollout_f32_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::LDS_BYTES);
@@ -899,7 +926,7 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
 // The wide path (wide.h) covers d = 256 / head_dim 32 in bf16: streamed-weight fused blocks.
 static bool wide_eligible(const aline_model &m, const aline_rollout &r) {
   if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
-  if (getenv("ALINE_DISABLE_WIDE")) return false;
+  if (dbg(ALINE_DBG_DISABLE_WIDE)) return false;
   if (m.precision != ALINE_PREC_BF16 || m.d != wide::D || m.H != wide::H || m.F % 64 || m.time_token) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > wide::WNK) return false;
   if (m.dim_x > 8 || m.dim_y > 8) return false;      // wide_embed_kernel keeps one input row in 8 registers
@@ -910,6 +937,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
   Ctx c;
   TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
   TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
+  TRY(c.clear_flag());
   const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, M = r->B * N, F = m->F;
   hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B, r->P, r->n_ctx0);
   CHECK_LAUNCH();
@@ -958,7 +986,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
   const long nfw = (long)wide::layer_chunks(F) * wide::CHUNK_W;
   // one fused kernel per step when an episode fits a workgroup (<= 16 token tiles, LDS for the parameters);
   // otherwise the streamed per-block kernels with activations in HBM
-  const bool fused_step = N <= 256 && wide::step_lds_bytes(F) <= 160 * 1024 && !getenv("ALINE_WIDE_BLOCKS");
+  const bool fused_step = N <= 256 && wide::step_lds_bytes(F) <= 160 * 1024 && !dbg(ALINE_DBG_WIDE_BLOCKS);
   if (fused_step) {   // the input image is assembled once (X1 is free in this mode) and patched row-wise between steps
     hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
                        c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X1);
@@ -980,7 +1008,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
       sa.zimg = want_gmm ? reinterpret_cast<u32x4 *>(c.at(c.pl.wZimg)) : nullptr;
       sa.zrow0 = (long)t * r->B * n_t;
       const size_t smem = wide::step_lds_bytes(F);
-      const bool stamped = getenv("ALINE_WIDE_STAMPS") != nullptr;
+      const bool stamped = dbg(ALINE_DBG_WIDE_STAMPS);
       sa.stamps = stamped ? reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps)) : nullptr;
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_step_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1029,7 +1057,6 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
     const int zw = r->P - r->n_ctx0;
     sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
     sel.role_out = r->role;
-    if (r->P > 1024) return ALINE_EUNSUPPORTED;
     // posterior of this step first (the selection kernel updates the roles afterwards; order is free)
     if (!fused_step && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
       const long rows = (long)r->B * n_t;
@@ -1044,7 +1071,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
                       r->post_weight ? r->post_weight + po * m->C : nullptr, r->target_all,
                       r->target_ll ? r->target_ll + po : nullptr, 0, rows));
     }
-    hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
+    TRY(launch_acq_select(c, sel));
     CHECK_LAUNCH();
     if (fused_step && t + 1 < r->T) {   // the chosen point enters the context: its input row becomes Ex + Ey
       hipLaunchKernelGGL(wide::patch_context_row_kernel, dim3(r->B), dim3(64), 0, c.st, c.g, r->n_ctx0 + t + 1,
@@ -1067,6 +1094,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
       TRY(launch_wide_block<wide::WB_GMM>(c, b));
     }
     wide::GmmRawArgs ga{};
+    ga.range_flag = c.flag();
     ga.raw = raw; ga.raw_stride = kRawStride; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
     ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
     ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
@@ -1080,7 +1108,7 @@ static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, 
 // The x3 path (x3.h): d = 256 / 8 heads at reference precision -- every product a 3-term f16 split on the matrix pipe.
 static bool x3_eligible(const aline_model &m, const aline_rollout &r) {
   if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
-  if (getenv("ALINE_DISABLE_X3")) return false;
+  if (dbg(ALINE_DBG_DISABLE_X3)) return false;
   if (m.precision != ALINE_PREC_F16X3 || m.d != x3::D || m.H != x3::H || m.F % 32 || m.time_token) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > x3::WNK) return false;
   if ((size_t)x3::NBUF * x3::CHUNK_BYTES + (size_t)std::max(x3::layer_params(m.F), x3::head_params(m.F)) * 4 > 160 * 1024) return false;
@@ -1091,7 +1119,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
   Ctx c;
   TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
   TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
-  if (r->P > 1024) return ALINE_EUNSUPPORTED;
+  TRY(c.clear_flag());
   const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, F = m->F, tpe = (N + 15) / 16, NP = 16 * tpe;
   const long tiles = (long)r->B * tpe;
   using x3::u32x4;
@@ -1111,7 +1139,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
   pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
   for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
   unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.xImg));
-  pa.out = img;
+  pa.out = img; pa.range_flag = c.flag();
   hipLaunchKernelGGL(x3::pack_kernel, dim3(2048), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
   // step-invariant point embeddings (fp32 rows; the generic GEMM runs the same 3-term f16 split)
@@ -1124,7 +1152,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
   int *keyrow = reinterpret_cast<int *>(c.at(c.pl.xKeys)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.xKcnt));
   float *logits = c.at(c.pl.xLog);
   x3::AsmArgs aa{};
-  aa.g = c.g; aa.tpe = tpe; aa.Ex = c.at(c.pl.Ex); aa.Ey = c.at(c.pl.Ey); aa.ey_rows = r->P; aa.theta_tokens = m->theta_tokens; aa.X = XIN;
+  aa.g = c.g; aa.tpe = tpe; aa.Ex = c.at(c.pl.Ex); aa.Ey = c.at(c.pl.Ey); aa.ey_rows = r->P; aa.theta_tokens = m->theta_tokens; aa.X = XIN; aa.range_flag = c.flag();
   hipLaunchKernelGGL(x3::assemble_kernel, grid1d((size_t)tiles * x3::NKS * 64), dim3(256), 0, c.st, aa);
   CHECK_LAUNCH();
   const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
@@ -1151,7 +1179,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
       CHECK_LAUNCH();
       x3::LayerArgs la{};
       la.g = c.g; la.tpe = tpe; la.ngroups = (int)((tiles + x3::WAVES - 1) / x3::WAVES);
-      la.XIN = xin; la.XOUT = xout; la.img = img + l * lw; la.F = F; la.KV = KV; la.kcnt = kcnt;
+      la.XIN = xin; la.XOUT = xout; la.img = img + l * lw; la.F = F; la.KV = KV; la.kcnt = kcnt; la.range_flag = c.flag();
       const bool last = l == m->L - 1;
       la.zimg = (last && want_gmm) ? Zimg : nullptr; la.zrow0 = (long)t * r->B * n_t;
 #ifdef X3_STAMPS
@@ -1182,7 +1210,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
     const int zw = r->P - r->n_ctx0;
     sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
     sel.role_out = r->role;
-    hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
+    TRY(launch_acq_select(c, sel));
     CHECK_LAUNCH();
     if (t + 1 < r->T) {   // the chosen point enters the context: its input row becomes Ex + Ey
       aa.g = c.g;
@@ -1200,6 +1228,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
       TRY(launch_x3_head<3>(c, ha));
     }
     wide::GmmRawArgs ga{};
+    ga.range_flag = c.flag();
     ga.raw = raw; ga.raw_stride = kRawStride; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
     ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
     ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
@@ -1212,7 +1241,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
 // The s3 path (s3.h): d = 32 / 4 heads at reference precision, any embedding mode, up to 160 keys per episode -- one
 // launch per design step, a workgroup owns two whole episodes.
 static bool s3_eligible(const aline_model &m, const aline_rollout &r) {
-  if (getenv("ALINE_DISABLE_S3")) return false;
+  if (dbg(ALINE_DBG_DISABLE_S3)) return false;
   if (m.precision != ALINE_PREC_F16X3 || m.d != s3::D || m.H != s3::H || m.F % 32 || m.F > s3::F_MAX || m.time_token) return false;
   if (r.n_ctx0 < 1 || r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > s3::NK_MAX) return false;
   return true;
@@ -1222,7 +1251,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   Ctx c;
   TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
   TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
-  if (r->P > 1024) return ALINE_EUNSUPPORTED;
+  TRY(c.clear_flag());
   const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, F = m->F, tpe = (N + 15) / 16, NP = 16 * tpe;
   const long tiles = (long)r->B * tpe;
   using s3::u32x4;
@@ -1241,19 +1270,19 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
   for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
   unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.sImg));
-  pa.out = img;
+  pa.out = img; pa.range_flag = c.flag();
   hipLaunchKernelGGL(s3::pack_kernel, dim3(256), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
   {   // step-invariant point embeddings (fp32 rows): x-embedder on the points + target-data rows, y-embedder on the points
     s3::EmbArgs ex{};
     ex.src = Src3{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};
     ex.rows_per_ep = r->P + r->n_target_data; ex.B = r->B; ex.K = m->dim_x;
-    ex.w1 = m->x_w1; ex.b1 = m->x_b1; ex.w2 = m->x_w2; ex.b2 = m->x_b2; ex.E = c.at(c.pl.Ex);
+    ex.w1 = m->x_w1; ex.b1 = m->x_b1; ex.w2 = m->x_w2; ex.b2 = m->x_b2; ex.E = c.at(c.pl.Ex); ex.range_flag = c.flag();
     s3::EmbArgs ey{};
     ey.src = Src3{{r->point_y, nullptr, nullptr}, {r->P, 0, 0}};
     ey.rows_per_ep = r->P; ey.B = r->B; ey.K = m->dim_y;
-    ey.w1 = m->y_w1; ey.b1 = m->y_b1; ey.w2 = m->y_w2; ey.b2 = m->y_b2; ey.E = c.at(c.pl.Ey);
-    if (getenv("ALINE_S3_GENERIC_EMBED")) {       // (A/B: the generic hidden-layer kernel + GEMM pair)
+    ey.w1 = m->y_w1; ey.b1 = m->y_b1; ey.w2 = m->y_w2; ey.b2 = m->y_b2; ey.E = c.at(c.pl.Ey); ey.range_flag = c.flag();
+    if (dbg(ALINE_DBG_S3_GENERIC_EMBED)) {       // (A/B: the generic hidden-layer kernel + GEMM pair)
       TRY(do_embed_points(c, ex.src, r->point_y, r->P));
     } else {
       TRY(launch_s3_embed(c, F, ex));
@@ -1264,7 +1293,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   u32x4 *Zimg = reinterpret_cast<u32x4 *>(c.at(c.pl.sZimg));
   float *logits = c.at(c.pl.sLog);
   s3::AsmArgs aa{};
-  aa.g = c.g; aa.tpe = tpe; aa.Ex = c.at(c.pl.Ex); aa.Ey = c.at(c.pl.Ey); aa.ey_rows = r->P; aa.theta_tokens = m->theta_tokens; aa.X = X0;
+  aa.g = c.g; aa.tpe = tpe; aa.Ex = c.at(c.pl.Ex); aa.Ey = c.at(c.pl.Ey); aa.ey_rows = r->P; aa.theta_tokens = m->theta_tokens; aa.X = X0; aa.range_flag = c.flag();
   hipLaunchKernelGGL(s3::assemble_kernel, grid1d((size_t)tiles * 64), dim3(256), 0, c.st, aa);
   CHECK_LAUNCH();
   const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
@@ -1298,13 +1327,13 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     const int zw = r->P - r->n_ctx0;
     sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
     sel.role_out = r->role;
-    hipLaunchKernelGGL(acq_select_kernel, dim3(r->B), dim3(256), (size_t)r->P * 8, c.st, sel);
+    TRY(launch_acq_select(c, sel));
     CHECK_LAUNCH();
   }
   if (want_gmm) {   // GMM heads of all T * B * n_t target rows, then the parameter maps + mixture log-likelihood
     const long per_step = (long)r->B * n_t, total = per_step * r->T;
     s3::GmmArgs ga{};
-    ga.Z = Zimg; ga.ntiles = (total + 15) / 16; ga.M = total; ga.C = m->C; ga.std_min = m->std_min;
+    ga.Z = Zimg; ga.ntiles = (total + 15) / 16; ga.M = total; ga.C = m->C; ga.std_min = m->std_min; ga.range_flag = c.flag();
     ga.img = img + ((long)m->L * s3::layer_bytes(F) + s3::head_bytes(F)) / 4;
     ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
     ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
@@ -1329,6 +1358,24 @@ int aline_rollout_path(const aline_model *m, const aline_rollout *r) {
   if (x3_eligible(*m, *r)) return ALINE_PATH_X3;
   if (s3_eligible(*m, *r)) return ALINE_PATH_S3;
   return ALINE_PATH_GENERIC;
+}
+
+int aline_rollout_kernel_name(const aline_model *m, const aline_rollout *r, char *buf, size_t n) {
+  if (!buf || n == 0) return ALINE_EINVAL;
+  const int path = aline_rollout_path(m, r);
+  if (path < 0) return path;
+  switch (path) {
+    case ALINE_PATH_FUSED: snprintf(buf, n, "fused::rollout_f32_kernel<%s>", dbg(ALINE_DBG_FUSED_STAMPS) ? "true" : "false"); break;
+    case ALINE_PATH_WIDE: snprintf(buf, n, "wide::wide_step_kernel<%s>", dbg(ALINE_DBG_WIDE_STAMPS) ? "true" : "false"); break;
+    case ALINE_PATH_X3: snprintf(buf, n, "x3::layer_kernel<true>"); break;      // (the launch the event pair brackets: last layer of the last step)
+    case ALINE_PATH_S3: {
+      const S3Shape sh = s3_shape(*m, *r);
+      snprintf(buf, n, "s3::step_kernel<%d, %d, %d, false>", m->F, sh.nw, sh.nw == 8 ? s3::NKP_MAX : 2);
+      break;
+    }
+    default: snprintf(buf, n, "generic pipeline (no dominant kernel)"); break;
+  }
+  return path;
 }
 
 int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes,
@@ -1384,7 +1431,7 @@ int aline_eig_ces_step(const float *theta, const float *xi, const float *y, floa
   const size_t total = (size_t)L1 * B;
   unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
   const size_t tab_bytes = (size_t)B * CES_ROW * sizeof(float);
-  if (tab_bytes <= 48 * 1024 && !getenv("ALINE_CES_GENERIC"))
+  if (tab_bytes <= 48 * 1024 && !dbg(ALINE_DBG_CES_GENERIC))
     hipLaunchKernelGGL(eig_ces_step_table_kernel, dim3(blocks), dim3(256), tab_bytes, static_cast<hipStream_t>(stream),
                        theta, xi, y, S, (long)L1, B, noise_scale, epsilon, nan_flag);
   else
@@ -1431,29 +1478,45 @@ extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_ro
   return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).Stamps * sizeof(float);
 }
 
-// Diagnostic only: byte offset of the x3 path's raw-GMM buffer (unused while no posterior output is requested: the
-// in-kernel stamps of the X3_STAMPS build land there, tools/x3_stamps.py).
+// Diagnostic only: byte offsets of the buffers the stamped diagnostic builds (X3_STAMPS / S3_STAMPS, tools/*_stamps.py) and
+// tools/probes/relu_int_repro.py read back; declared in include/aline_hip.h.
 extern "C" size_t aline_debug_xraw_offset(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return 0;
   const Plan pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T);
-  return (m->d == s3::D ? pl.sRaw : pl.xRaw) * sizeof(float);     // (s3 path: S3_STAMPS build, tools/s3_stamps.py)
+  return (m->d == s3::D ? pl.sRaw : pl.xRaw) * sizeof(float);
 }
-
-// Diagnostic only: byte offset of the wide path's acquisition-logit buffer [B * N] (tools/probes/relu_int_repro.py).
 extern "C" size_t aline_debug_wlog_offset(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return 0;
   return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).wLog * sizeof(float);
 }
 
+extern "C" uint32_t aline_debug_set_flags(uint32_t flags) { return g_debug_flags.exchange(flags); }
+extern "C" uint32_t aline_debug_get_flags(void) { return g_debug_flags.load(); }
+extern "C" int aline_debug_set_param(int key, int value) {
+  if (key < 0 || key >= ALINE_DBG_NPARAMS) return ALINE_EINVAL;
+  g_debug_params[key].store(value);
+  return ALINE_OK;
+}
+
+// f16 range guard (include/aline_hip.h): the status word is the first word of every workspace plan
+extern "C" size_t aline_f16_range_offset(void) { return 0; }
+extern "C" int aline_f16_range_status(const void *ws, void *stream) {
+  if (!ws) return ALINE_EINVAL;
+  unsigned word = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(&word, ws, sizeof(word), hipMemcpyDeviceToHost, st) != hipSuccess) return ALINE_ELAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return ALINE_ELAUNCH;
+  return (int)(word & 0xFFu);
+}
+
 // ================================= backward (training) ============================================
-// Arithmetic of the NT GEMMs of the backward pass (forward recompute and dX products): exact-fp32 MFMA.  ALINE_BWD_PREC=3
+// Arithmetic of the NT GEMMs of the backward pass (forward recompute and dX products): exact-fp32 MFMA.  ALINE_DBG_BWD_PREC = 3
 // (3-term f16 split) was measured and is NOT used: upstream gradients are ~1e-8 .. 1e-5 (1 / (T B n_t) scaling), below
 // f16's normal range, so the split loses them (tests/test_backward_gpu.py fails), and the step is bound by HBM traffic of
 // the saved activations, not by the matrix pipe (67.7 -> 66.9 ms).
 static int bwd_prec() {
-  static int p = -1;
-  if (p < 0) { const char *e = getenv("ALINE_BWD_PREC"); p = e ? atoi(e) : ALINE_PREC_F32; if (p < 0 || p > 3) p = 0; }
-  return p;
+  const int p = dbg_param(ALINE_DBG_BWD_PREC);
+  return (p < 0 || p > 3) ? ALINE_PREC_F32 : p;
 }
 
 namespace {
@@ -1466,17 +1529,16 @@ struct BwdPlan {
 // Fused token-local tail (tail_bwd.h) for the small-width model: U1 / X1 / Hid / U2 are never stored.  ALINE_BWD_TAIL=0
 // switches back to the per-op pipeline (A/B measurements).
 // (the switches are read at every call: tests compare both pipelines in one process)
-static bool env_on(const char *name) { const char *e = getenv(name); return e ? atoi(e) != 0 : true; }
-static bool bwd_fused_tail(const aline_model &m) { return m.d == tailbwd::D && m.F == tailbwd::F && env_on("ALINE_BWD_TAIL"); }
+static bool bwd_fused_tail(const aline_model &m) { return m.d == tailbwd::D && m.F == tailbwd::F && !dbg(ALINE_DBG_NO_BWD_TAIL); }
 
 // Acquisition head backward without the [I P, F] hidden activations (acq_head_bwd.h).  ALINE_BWD_ACQ=0: the per-op kernels.
-static bool fused_acq_head(const aline_model &m) { return m.d == acqb::D && m.F == acqb::F && env_on("ALINE_BWD_ACQ"); }
+static bool fused_acq_head(const aline_model &m) { return m.d == acqb::D && m.F == acqb::F && !dbg(ALINE_DBG_NO_BWD_ACQ); }
 
-static bool fused_gmm_heads(const aline_model &m) { return m.d == gmmb::D && m.F == gmmb::F && m.C <= 16 && env_on("ALINE_BWD_GMM_FUSED"); }
+static bool fused_gmm_heads(const aline_model &m) { return m.d == gmmb::D && m.F == gmmb::F && m.C <= 16 && !dbg(ALINE_DBG_NO_BWD_GMM_FUSED); }
 
 // In-projection + attention backward as one kernel (attn_bwd_mfma.h).  ALINE_BWD_ATTN_BLOCK=0: the per-op kernels.
 static bool fused_attn_block(const aline_model &m, int max_keys) {
-  return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK && env_on("ALINE_BWD_ATTN_BLOCK");
+  return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK && !dbg(ALINE_DBG_NO_BWD_ATTN_BLOCK);
 }
 
 BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
@@ -1593,7 +1655,7 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 
 template <int HD>
 int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys) {
-  const bool mfma_on = env_on("ALINE_BWD_ATTN_MFMA");      // 0: the VALU kernel (A/B measurements)
+  const bool mfma_on = !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA);      // 0: the VALU kernel (A/B measurements)
   if (mfma_on && HD == abwd::HD && c.m->d == abwd::D && max_keys <= abwd::MAXK) {
     hipLaunchKernelGGL(abwd::attention_bwd_mfma_kernel, dim3((unsigned)c.g.B), dim3(abwd::THREADS), 0, c.st, c.g, qkv, dA, dqkv);
     CHECK_LAUNCH();
@@ -1621,25 +1683,16 @@ int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, 
   a.g1 = m.norm1_w[l]; a.e1 = m.norm1_b[l]; a.g2 = m.norm2_w[l]; a.e2 = m.norm2_b[l];
   const size_t smem = (dY ? tailbwd::LDS_FLOATS : tailbwd::LDS_FLOATS_FWD) * sizeof(float);
   const long groups = ((M + 15) / 16 + tailbwd::WAVES - 1) / tailbwd::WAVES;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS * (int)sizeof(float));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_FWD * (int)sizeof(float));
-    attr = true;
-  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS * (int)sizeof(float));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_FWD * (int)sizeof(float));
   if (!dY) {
     hipLaunchKernelGGL(tailbwd::tail_kernel<false>, dim3((unsigned)std::min<long>(groups, 256 * 3)), dim3(tailbwd::THREADS), smem, c.st, a);
   } else {
     a.dwo = gr->out_proj_w[l]; a.dbo = gr->out_proj_b[l]; a.dw1 = gr->lin1_w[l]; a.db1 = gr->lin1_b[l];
     a.dw2 = gr->lin2_w[l]; a.db2 = gr->lin2_b[l]; a.dg1 = gr->norm1_w[l]; a.de1 = gr->norm1_b[l];
     a.dg2 = gr->norm2_w[l]; a.de2 = gr->norm2_b[l];
-    const char *pc = getenv("ALINE_BWD_TAIL_PC");      // opt-in: measured 3.56 ms per call against 3.65
-    if (pc && atoi(pc) != 0) {      // producer / consumer wave pairs, 8 waves of 224 registers (tail_bwd_pc_kernel)
-      static bool attr_pc = false;
-      if (!attr_pc) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_bwd_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_PC * (int)sizeof(float));
-        attr_pc = true;
-      }
+    if (dbg(ALINE_DBG_BWD_TAIL_PC)) {      // opt-in: measured 3.56 ms per call against 3.65      // producer / consumer wave pairs, 8 waves of 224 registers (tail_bwd_pc_kernel)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_bwd_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_PC * (int)sizeof(float));
       hipLaunchKernelGGL(tailbwd::tail_bwd_pc_kernel, dim3((unsigned)std::min<long>(groups, 256)), dim3(512), tailbwd::LDS_FLOATS_PC * sizeof(float), c.st, a);
     } else
     hipLaunchKernelGGL(tailbwd::tail_kernel<true>, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);   // 434 registers: one wave per SIMD
@@ -1760,20 +1813,16 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         ka.row_index = keyidx;
         TRY(launch_gemm(bwd_prec(), ka, 1, c.st));
       }
-      if (ckv && ft && env_on("ALINE_BWD_LAYER_FWD")) {      // the rest of the layer in one kernel (layer_fwd.h): Xs(l) -> Al(l), Xs(l + 1)
+      if (ckv && ft && !dbg(ALINE_DBG_NO_BWD_LAYER_FWD)) {      // the rest of the layer in one kernel (layer_fwd.h): Xs(l) -> Al(l), Xs(l + 1)
         lfwd::Args fa{};
         fa.g = g; fa.X = Xs(l); fa.A = Al(l); fa.Y = Xs(l + 1); fa.win = m->in_proj_w[l]; fa.bin = m->in_proj_b[l];
         fa.kvc = KVl(l); fa.kcnt = kcnt; fa.max_keys = max_keys;
         fa.wo = m->out_proj_w[l]; fa.bo = m->out_proj_b[l]; fa.w1 = m->lin1_w[l]; fa.b1 = m->lin1_b[l];
         fa.w2 = m->lin2_w[l]; fa.b2 = m->lin2_b[l]; fa.g1 = m->norm1_w[l]; fa.e1 = m->norm1_b[l];
         fa.g2 = m->norm2_w[l]; fa.e2 = m->norm2_b[l];
-        static bool attr = false;
-        if (!attr) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(2) * (int)sizeof(float));
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(3) * (int)sizeof(float));
-          attr = true;
-        }
-        if (env_on("ALINE_BWD_LAYER_FWD_FLAT")) {      // (instance, tile) units from one flat list, K / V fragments from L2
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(2) * (int)sizeof(float));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(3) * (int)sizeof(float));
+        if (!dbg(ALINE_DBG_NO_BWD_LAYER_FWD_FLAT)) {      // (instance, tile) units from one flat list, K / V fragments from L2
           const long units = (long)I * ((N + 15) / 16);
           const unsigned fgrid = (unsigned)std::min<long>((units + lfwd::WAVES - 1) / lfwd::WAVES, 768);      // three workgroups per CU
           const size_t fl = lfwd::LDS_FLOATS_FLAT * sizeof(float);
@@ -1838,11 +1887,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       a.Z = Z; a.logit = dTmp; a.dZ = dX; a.M = M;
       a.w1 = m->acq_w1; a.b1 = m->acq_b1; a.w2 = m->acq_w2; a.b2 = m->acq_b2;
       a.dw1 = gr->acq_w1; a.db1 = gr->acq_b1; a.dw2 = gr->acq_w2;
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&acqb::bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, acqb::LDS_FLOATS * (int)sizeof(float));
-        attr = true;
-      }
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&acqb::bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, acqb::LDS_FLOATS * (int)sizeof(float));
       const long groups = ((M + 15) / 16 + acqb::WAVES - 1) / acqb::WAVES;
       hipLaunchKernelGGL(acqb::logit_kernel, dim3((unsigned)std::min<long>(groups, 256 * 4)), dim3(acqb::THREADS), acqb::LDS_FLOATS_LOGIT * sizeof(float), c.st, a);
       CHECK_LAUNCH();
@@ -1898,15 +1943,15 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       a.g_mean = g_pm ? g_pm + (size_t)tA * B * n_t * C : nullptr;
       a.g_std = g_ps ? g_ps + (size_t)tA * B * n_t * C : nullptr;
       a.g_wgt = g_pw ? g_pw + (size_t)tA * B * n_t * C : nullptr;
-      if (F == 128 && C <= 10 && env_on("ALINE_BWD_GMM128"))
+      if (F == 128 && C <= 10 && !dbg(ALINE_DBG_NO_BWD_GMM128))
         hipLaunchKernelGGL((gmm_bwd128_kernel<10, 128>), dim3((unsigned)((a.rows + 127) / 128)), dim3(256), 0, c.st, a);
-      else if (F == 128 && env_on("ALINE_BWD_GMM128"))
+      else if (F == 128 && !dbg(ALINE_DBG_NO_BWD_GMM128))
         hipLaunchKernelGGL((gmm_bwd128_kernel<16, GMM_BWD_ROWS>), dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       else
       hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();
       float *Wt = c.at(c.pl.Wt);   // [d, C*F]: column block k = W1_k^T
-      if (F == 128 && d % 32 == 0 && env_on("ALINE_BWD_GMM_BATCHED")) {
+      if (F == 128 && d % 32 == 0 && !dbg(ALINE_DBG_NO_BWD_GMM_BATCHED)) {
         // all C components in one launch each: dW1_k / db1_k (column block k of the hidden gradients), and dz as one K = C F product
         GemmTnArgs ta{};
         ta.dY = HidG; ta.ldy = C * F; ta.Ry = 1; ta.Gy = 1; ta.offy = 0;
@@ -1972,12 +2017,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         ba.g = g; ba.X = Xs(l); ba.dA = dTmp; ba.dX = dXn; ba.win = m->in_proj_w[l]; ba.bin = m->in_proj_b[l];
         ba.dwin = gr->in_proj_w[l]; ba.dbin = gr->in_proj_b[l];
         ba.kvc = KVl(l); ba.dkvc = dKVc; ba.keyidx = keyidx; ba.kcnt = kcnt; ba.max_keys = max_keys;
-        static bool attr = false;
-        if (!attr) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(2) * (int)sizeof(float));
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(3) * (int)sizeof(float));
-          attr = true;
-        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(2) * (int)sizeof(float));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(3) * (int)sizeof(float));
         // persistent workgroups: two per CU at <= 32 keys (242 registers), one otherwise
         if (max_keys <= 32) hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<2>, dim3((unsigned)std::min(I, 512)), dim3(abwd::THREADS), abwd::block_lds_floats(2) * sizeof(float), c.st, ba);
         else hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<3>, dim3((unsigned)std::min(I, 256)), dim3(abwd::THREADS), abwd::block_lds_floats(3) * sizeof(float), c.st, ba);

@@ -26,6 +26,18 @@ __device__ __forceinline__ void split_bf16(float a, unsigned short &hi, unsigned
   lo = f2bf(a - bf2f(hi));
 }
 
+// ---- f16 range guard (include/aline_hip.h: aline_f16_range_status) -------------------------------------------------------
+// The F16X3 kernels split fp32 operands into f16 halves; an operand that is non-finite or >= 65504 in magnitude turns into
+// inf / NaN there.  Such values reach the next LayerNorm (whose statistics become NaN), the softmax of the design
+// selection or the mixture log-likelihood, so the guard costs the hot kernels one add per LayerNorm: a per-lane
+// accumulator of the reciprocal standard deviations that is NaN iff something overflowed, checked once per wave; the
+// kernels off the hot path (weight packing, input image assembly, selection, GMM finish) test their values directly.
+#define ALINE_RANGE_ACT 1u      /* an activation operand */
+#define ALINE_RANGE_WEIGHT 2u   /* a weight (after the 2^8 pre-scale) */
+__device__ __forceinline__ bool f16_out_of_range(float v) { return !(fabsf(v) < 65504.f); }    // (true for NaN)
+__device__ __forceinline__ void range_raise(unsigned *flag, unsigned bit) { if (flag) atomicOr(flag, bit); }
+__device__ __forceinline__ void range_check_nan(unsigned *flag, float chk) { if (flag && chk != chk) atomicOr(flag, ALINE_RANGE_ACT); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);

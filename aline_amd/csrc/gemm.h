@@ -35,6 +35,7 @@ struct GemmArgs {
   // and the consumer adds the blocks in order (no atomics: results stay bit-reproducible).
   const float *red_w[GEMM_MAX_GROUPS]; const float *red_b[GEMM_MAX_GROUPS]; int red_nout; float *red_out; int red_stride;
   long red_block_stride;
+  unsigned *range_flag;            // F16X3: raised when an accumulator is not finite (an operand left f16's range); may be null
 };
 
 constexpr int GEMM_BK = 32;
@@ -268,6 +269,14 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
   constexpr int RP = 32 * LDC * sizeof(float) <= sizeof(smem) ? 32 : 16;     // rows per pass
   static_assert(RP * LDC * sizeof(float) <= sizeof(smem), "epilogue tile must fit the operand buffers");
   float *Cs = reinterpret_cast<float *>(smem);
+  if constexpr (PREC == 3) {   // f16 range guard: an out-of-range operand shows as inf / NaN accumulators (0 * inf = NaN, 0 * NaN = NaN)
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) chk = fmaf(acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3], 0.f, chk);
+    range_check_nan(a.range_flag, chk);
+  }
   const float *bias = a.bias[grp];
   const float tsc = a.tscalar ? a.tscalar[0] : 0.f;
   constexpr int C4 = BN / 4, PER_T = RP * C4 / 256;       // float4 per thread and pass (BN = 32: 1, 64: 2, 128: 4)

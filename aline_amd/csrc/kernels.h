@@ -387,12 +387,14 @@ struct SelectArgs {
   float *zt; int zt_stride;      // zt[b * stride + i], zero padded up to zt_width
   int zt_width;
   int *role_out;                 // rollout: role[b, chosen] = n_ctx_now + 1
+  unsigned *range_flag;          // f16 range guard (common.h): raised when the logits are not finite (may be null)
 };
 
 __global__ __launch_bounds__(256) void acq_select_kernel(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *logit = reinterpret_cast<float *>(smem_raw);   // [P]
   int *qslot = reinterpret_cast<int *>(logit + a.g.P);  // [P] compacted -> slot
+  float *prob = logit + 2 * a.g.P;                      // [P] probabilities in compacted order
   __shared__ float red[4];
   __shared__ int wave_cnt[4];
   __shared__ int s_base, s_choice;
@@ -445,21 +447,16 @@ __global__ __launch_bounds__(256) void acq_select_kernel(SelectArgs a) {
   if (lane == 0) red[wave] = sum;
   __syncthreads();
   sum = red[0] + red[1] + red[2] + red[3];
+  if (tid == 0 && !(sum <= 3.4e38f)) range_raise(a.range_flag, ALINE_RANGE_ACT);     // a NaN / +inf logit (fmaxf drops NaNs, the sum does not)
   const float inv = 1.f / sum;
   __syncthreads();
-  // probabilities back into logit[] (compacted order) and out to zt
-  float *prob = logit;  // reuse: write compacted probs after everyone has read their logits
-  float pv[4];          // P <= 1024
-  int cnt = 0;
-  for (int i = tid; i < nq; i += 256) pv[cnt++] = __expf(logit[qslot[i]] - mx) * inv;
-  __syncthreads();
-  cnt = 0;
-  for (int i = tid; i < nq; i += 256) prob[i] = pv[cnt++];
+  // probabilities in compacted order (any P that fits LDS: the evaluation protocol runs n_query = 2000, README.md:45) and out to zt
+  for (int i = tid; i < nq; i += 256) prob[i] = __expf(logit[qslot[i]] - mx) * inv;
   __syncthreads();
   if (a.zt)
     for (int i = tid; i < a.zt_width; i += 256)
       a.zt[(long)b * a.zt_stride + i] = i < nq ? prob[i] : 0.f;
-  // selection (single wave: nq <= 1024 keeps this short and deterministic)
+  // selection (single wave: short and deterministic)
   if (wave == 0) {
     int choice = 0;
     float val = 0.f;

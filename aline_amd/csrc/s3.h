@@ -76,6 +76,7 @@ struct PackArgs {
   const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
   const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
   unsigned *out;
+  unsigned *range_flag;
 };
 
 __global__ void pack_kernel(PackArgs a) {
@@ -89,12 +90,12 @@ __global__ void pack_kernel(PackArgs a) {
       const long o = i % lw, nfw = (long)layer_pairs(F) * PAIR_WORDS;
       if (o < nfw) {
         const int p = o / PAIR_WORDS, e = o % PAIR_WORDS;
-        if (p < 6) v = x3::pair_word(a.in_proj_w[l] + (long)(p >> 1) * D * D, D, 16 * (p & 1), 0, e, (p < 2 ? qscale : 1.f) * WSCALE);
-        else if (p < 8) v = x3::pair_word(a.out_proj_w[l], D, 16 * (p & 1), 0, e, WSCALE);
-        else if (p < 8 + F / 16) v = x3::pair_word(a.lin1_w[l], D, 16 * (p - 8), 0, e, WSCALE);
+        if (p < 6) v = x3::pair_word(a.in_proj_w[l] + (long)(p >> 1) * D * D, D, 16 * (p & 1), 0, e, (p < 2 ? qscale : 1.f) * WSCALE, a.range_flag);
+        else if (p < 8) v = x3::pair_word(a.out_proj_w[l], D, 16 * (p & 1), 0, e, WSCALE, a.range_flag);
+        else if (p < 8 + F / 16) v = x3::pair_word(a.lin1_w[l], D, 16 * (p - 8), 0, e, WSCALE, a.range_flag);
         else {
           const int q = p - 8 - F / 16;
-          v = x3::pair_word(a.lin2_w[l], F, 16 * (q & 1), q >> 1, e, WSCALE);
+          v = x3::pair_word(a.lin2_w[l], F, 16 * (q & 1), q >> 1, e, WSCALE, a.range_flag);
         }
       } else {
         const int p = o - nfw;
@@ -117,7 +118,7 @@ __global__ void pack_kernel(PackArgs a) {
       const float *w2 = k == 0 ? a.acq_w2 : a.gmm_w2[k - 1], *b2 = k == 0 ? a.acq_b2 : a.gmm_b2[k - 1];
       const int nout = k == 0 ? 1 : 3;
       if (o < nfw) {
-        v = x3::pair_word(w1, D, 16 * (int)(o / PAIR_WORDS), 0, (int)(o % PAIR_WORDS), WSCALE);
+        v = x3::pair_word(w1, D, 16 * (int)(o / PAIR_WORDS), 0, (int)(o % PAIR_WORDS), WSCALE, a.range_flag);
       } else {
         const int p = o - nfw;
         const float f = p < F ? b1[p] : p < (1 + nout) * F ? w2[p - F] : (p >= 4 * F && p < 4 * F + nout) ? b2[p - 4 * F] : 0.f;
@@ -133,6 +134,7 @@ struct AsmArgs {
   Geo g; int tpe;
   const float *Ex, *Ey; int ey_rows; const float *theta_tokens;
   u32x4 *X;
+  unsigned *range_flag;            // f16 range guard (common.h): the layer-0 input is checked where it is assembled
 };
 __device__ __forceinline__ void embed_row8(const AsmArgs &a, int b, int row, int c, f32x4 &lo, f32x4 &hi) {
   const Geo &g = a.g;
@@ -163,6 +165,7 @@ __global__ void assemble_kernel(AsmArgs a) {
   const int b = tile / a.tpe, row = (int)(tile % a.tpe) * 16 + (lane & 15);
   f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
   if (row < a.g.N) embed_row8(a, b, row, 4 * gq, lo, hi);
+  x3::range_check8(a.range_flag, lo, hi);
   store_split8(a.X, tile, lane, lo, hi);
 }
 
@@ -187,6 +190,7 @@ struct EmbArgs {
   Src3 src; int rows_per_ep, B, K;
   const float *w1, *b1, *w2, *b2;       // [F, K], [F], [D, F], [D]
   float *E;                             // [B * rows_per_ep, D] fp32 rows
+  unsigned *range_flag;                 // f16 range guard: W2, and (through the assembled input image) the hidden units
 };
 template <int F>
 __global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4, wave = tid >> 6;
   for (int e = tid; e < PAIRS * PAIR_WORDS; e += 256) {      // pair (c, m) = k-step c of output tile m
     const int p = e / PAIR_WORDS;
-    wimg[e] = x3::pair_word(a.w2, F, 16 * (p & 1), p >> 1, e % PAIR_WORDS, WSCALE);
+    wimg[e] = x3::pair_word(a.w2, F, 16 * (p & 1), p >> 1, e % PAIR_WORDS, WSCALE, blockIdx.x == 0 ? a.range_flag : nullptr);
   }
   for (int i = tid; i < D; i += 256) prm[i] = a.b2[i];
   for (int i = tid; i < F; i += 256) prm[D + i] = a.b1[i];
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
 }
 
 // (a, b) = LayerNorm over the 32 features of each token: 8 values per lane x 4 lane groups, fp32, two passes
-__device__ __forceinline__ void layer_norm32(f32x4 &a, f32x4 &b, const float *w, const float *bb, int g) {
+__device__ __forceinline__ float layer_norm32(f32x4 &a, f32x4 &b, const float *w, const float *bb, int g) {
   const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
   const float mean = group_sum4(s) * (1.f / D);
   float q = 0.f;
@@ -256,6 +260,7 @@ __device__ __forceinline__ void layer_norm32(f32x4 &a, f32x4 &b, const float *w,
   const f32x4 w0 = ld4(w + 4 * g), w1 = ld4(w + 16 + 4 * g), b0 = ld4(bb + 4 * g), b1 = ld4(bb + 16 + 4 * g);
 #pragma unroll
   for (int r = 0; r < 4; ++r) { a[r] = fmaf(a[r] * rstd, w0[r], b0[r]); b[r] = fmaf(b[r] * rstd, w1[r], b1[r]); }
+  return rstd;      // NaN iff an input was NaN / inf (the f16 range guard accumulates it)
 }
 
 // softmax numerators of one head over NKT key tiles (exp2 domain), in place; returns 1 / denominator
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       if (slot >= 0 && lane < 4) {
         f32x4 lo, hi;
         embed_row8(a.emb, bh, slot, 4 * lane, lo, hi);
+        x3::range_check8(a.emb.range_flag, lo, hi);
         store_split8(a.X0, (long)bh * tpe + (slot >> 4), lane * 16 + (slot & 15), lo, hi);
       }
     }
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   wait_vmcnt<0>();
   __syncthreads();
   S3_LAP(0);
+  float range_chk = 0.f;
 
   for (int l = 0; l < a.L; ++l) {
     const bool last = l == a.L - 1;
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         mfma3(y1, w1.hi, w1.lo, ah, al);
         x1a = y0 * WINV + ld4(bo + 4 * g) + frag_value(xh, xl, 0);
         x1b = y1 * WINV + ld4(bo + 16 + 4 * g) + frag_value(xh, xl, 1);
-        layer_norm32(x1a, x1b, ln1w, ln1b, g);
+        range_chk += layer_norm32(x1a, x1b, ln1w, ln1b, g);
         split_frag(x1a, x1b, x1h, x1l);
       }
       // X2 = LN2(X1 + b2 + W2 relu(W1 X1 + b1)): the hidden units of the tile in registers, GH tiles of 16 at a time (all of them
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         }
       }
       f32x4 x2a = y0 * WINV + ld4(b2 + 4 * g) + x1a, x2b = y1 * WINV + ld4(b2 + 16 + 4 * g) + x1b;
-      layer_norm32(x2a, x2b, ln2w, ln2b, g);
+      range_chk += layer_norm32(x2a, x2b, ln2w, ln2b, g);
       f16x8 oh, ol;
       split_frag(x2a, x2b, oh, ol);
       if (!last) {
@@ -684,6 +691,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       S3_LAP(7);
     }
   }
+  range_check_nan(a.emb.range_flag, range_chk);
 #ifdef S3_STAMPS
   if (a.stamps && blockIdx.x == 0 && lane == 0) {
     stamps.acc[8] = stamps.t_prev - t_begin;
@@ -704,6 +712,7 @@ struct GmmArgs {
   float *mean, *sd, *wgt;                         // [M, C] or null
   const float *value; long value_mod;             // value[row % value_mod] or null
   float *ll;                                      // [M] or null
+  unsigned *range_flag;                           // f16 range guard: raised when a log-likelihood is not finite
 };
 template <int F>
 __global__ __launch_bounds__(THREADS) void gmm_kernel(GmmArgs a) {
@@ -779,7 +788,9 @@ __global__ __launch_bounds__(THREADS) void gmm_kernel(GmmArgs a) {
   if (want_ll) {
     float se = 0.f;
     for (int c = 0; c < a.C; ++c) se += __expf(rr[(3 * c) * GROWS] - mx2);
-    a.ll[row] = mx2 + logf(se);
+    const float ll = mx2 + logf(se);
+    a.ll[row] = ll;
+    if (!(fabsf(ll) <= 3.4e38f)) range_raise(a.range_flag, ALINE_RANGE_ACT);
   }
 }
 

@@ -570,6 +570,7 @@ struct GmmRawArgs {
   const float *value; long value_mod;            // value[(value_row0 + row) % value_mod] or null
   long value_row0;
   float *ll;                                     // [rows] or null
+  unsigned *range_flag;                          // f16 range guard (common.h): raised when a log-likelihood is not finite; may be null
 };
 __global__ void gmm_raw_finish_kernel(GmmRawArgs a) {
   const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -598,7 +599,9 @@ __global__ void gmm_raw_finish_kernel(GmmRawArgs a) {
   if (a.ll && a.value) {
     float se = 0.f;
     for (int c = 0; c < a.C; ++c) se += __expf(lps[c] - mx2);
-    a.ll[row] = mx2 + logf(se);
+    const float ll = mx2 + logf(se);
+    a.ll[row] = ll;
+    if (!(fabsf(ll) <= 3.4e38f)) range_raise(a.range_flag, ALINE_RANGE_ACT);
   }
 }
 

@@ -118,14 +118,16 @@ struct PackArgs {
   const float *acq_w1, *acq_b1, *acq_w2, *acq_b2;
   const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
   unsigned *out;
+  unsigned *range_flag;
 };
 
 // word e (0..511) of the pair (rows row0.., k-step ks) of the row-major weight W [*, K]: hi fragment, lo fragment
-__device__ __forceinline__ unsigned pair_word(const float *W, int K, int row0, int ks, int e, float scale) {
+__device__ __forceinline__ unsigned pair_word(const float *W, int K, int row0, int ks, int e, float scale, unsigned *range_flag = nullptr) {
   const int hl = e >> 8, lane = (e & 255) >> 2, w = e & 3, g = lane >> 4, j0 = 2 * w;
   const int k0 = 32 * ks + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
   const float *p = W + (long)(row0 + (lane & 15)) * K + k0;
   unsigned hi, lo;
+  if (f16_out_of_range(p[0] * scale) || f16_out_of_range(p[1] * scale)) range_raise(range_flag, ALINE_RANGE_WEIGHT);
   split2(p[0] * scale, p[1] * scale, hi, lo);
   return hl ? lo : hi;
 }
@@ -140,12 +142,12 @@ __global__ void pack_kernel(PackArgs a) {
       const long o = i % lw, nfw = (long)layer_chunks(a.F) * CHUNK_WORDS;
       if (o < nfw) {
         const int ch = o / CHUNK_WORDS, cw = o % CHUNK_WORDS, p = cw >> 9, e = cw & 511;
-        if (ch < 24) v = pair_word(a.in_proj_w[l] + (long)(ch >> 3) * D * D, D, 16 * p, ch & 7, e, (ch < 8 ? qscale : 1.f) * WSCALE);
-        else if (ch < 32) v = pair_word(a.out_proj_w[l], D, 16 * p, ch & 7, e, WSCALE);
+        if (ch < 24) v = pair_word(a.in_proj_w[l] + (long)(ch >> 3) * D * D, D, 16 * p, ch & 7, e, (ch < 8 ? qscale : 1.f) * WSCALE, a.range_flag);
+        else if (ch < 32) v = pair_word(a.out_proj_w[l], D, 16 * p, ch & 7, e, WSCALE, a.range_flag);
         else {
           const int c = (ch - 32) >> 1;
-          if (((ch - 32) & 1) == 0) v = pair_word(a.lin1_w[l], D, 32 * c + 16 * (p & 1), p >> 1, e, WSCALE);
-          else v = pair_word(a.lin2_w[l], a.F, 16 * p, c, e, WSCALE);
+          if (((ch - 32) & 1) == 0) v = pair_word(a.lin1_w[l], D, 32 * c + 16 * (p & 1), p >> 1, e, WSCALE, a.range_flag);
+          else v = pair_word(a.lin2_w[l], a.F, 16 * p, c, e, WSCALE, a.range_flag);
         }
       } else {
         const int p = o - nfw;
@@ -169,7 +171,7 @@ __global__ void pack_kernel(PackArgs a) {
       const int nout = k == 0 ? 1 : 3;
       if (o < nfw) {
         const int ch = o / CHUNK_WORDS, cw = o % CHUNK_WORDS, p = cw >> 9, e = cw & 511;
-        v = pair_word(w1, D, 32 * ch + 16 * (p & 1), p >> 1, e, WSCALE);
+        v = pair_word(w1, D, 32 * ch + 16 * (p & 1), p >> 1, e, WSCALE, a.range_flag);
       } else {
         const int p = o - nfw;
         const float f = p < a.F ? b1[p] : p < (1 + nout) * a.F ? w2[p - a.F] : (p >= 4 * a.F && p < 4 * a.F + nout) ? b2[p - 4 * a.F] : 0.f;
@@ -186,7 +188,15 @@ struct AsmArgs {
   Geo g; int tpe;
   const float *Ex, *Ey; int ey_rows; const float *theta_tokens;
   u32x4 *X;
+  unsigned *range_flag;
 };
+// the layer-0 input is the one split operand no LayerNorm has bounded: checked where it is assembled (off the hot path)
+__device__ __forceinline__ void range_check8(unsigned *flag, const f32x4 &a, const f32x4 &b) {
+  float m = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+  m = fmaxf(m, fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
+  const float nanp = (a[0] + a[1] + a[2] + a[3] + b[0] + b[1] + b[2] + b[3]) * 0.f;     // NaN iff any is NaN / inf
+  if (!(m < 65504.f) || nanp != nanp) range_raise(flag, ALINE_RANGE_ACT);
+}
 __device__ __forceinline__ void store_split8(u32x4 *X, long tile, int ks, int lane, const f32x4 &lo4, const f32x4 &hi4) {
   f16x8 h, l;
   split_frag(lo4, hi4, h, l);
@@ -216,6 +226,7 @@ __global__ void assemble_kernel(AsmArgs a) {
   const int b = tile / a.tpe, row = (int)(tile % a.tpe) * 16 + (lane & 15);
   f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
   if (row < a.g.N) embed_row8(a, b, row, 32 * ks + 4 * gq, lo, hi);
+  range_check8(a.range_flag, lo, hi);
   store_split8(a.X, tile, ks, lane, lo, hi);
 }
 // between steps the input image changes in ONE row per episode: the point chosen at the previous step (role ==
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(64) void patch_row_kernel(AsmArgs a, int order) {
   const int ks = lane >> 2, gq = lane & 3;
   f32x4 lo, hi;
   embed_row8(a, b, slot, 32 * ks + 4 * gq, lo, hi);
+  range_check8(a.range_flag, lo, hi);
   store_split8(a.X, (long)b * a.tpe + (slot >> 4), ks, gq * 16 + (slot & 15), lo, hi);
 }
 
@@ -465,7 +477,8 @@ __device__ __forceinline__ void load_tile(const u32x4 *X, long tile, int lane_id
 }
 
 // v = LayerNorm(v) over the 256 features of each token (16 tiles x 4 registers x 4 lane groups), fp32, two passes
-__device__ __forceinline__ void layer_norm(f32x4 (&v)[NMT], const float *lw, const float *lb, int g) {
+// returns the reciprocal standard deviation (NaN iff an input was NaN / inf: the f16 range guard accumulates it)
+__device__ __forceinline__ float layer_norm(f32x4 (&v)[NMT], const float *lw, const float *lb, int g) {
   float s = 0.f;
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
@@ -482,6 +495,7 @@ __device__ __forceinline__ void layer_norm(f32x4 (&v)[NMT], const float *lw, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[mt][r] = fmaf(v[mt][r] * rstd, wv[r], bv[r]);
   }
+  return rstd;
 }
 
 // ---- K / V of the key rows ----------------------------------------------------------------------------------------
@@ -566,6 +580,7 @@ struct LayerArgs {
   const unsigned *img; int F;
   const u32x4 *KV; const int *kcnt;
   u32x4 *zimg; long zrow0;        // last layer: the rows of the target tokens also go to this (dense-row) image
+  unsigned *range_flag;           // f16 range guard (common.h)
 #ifdef X3_STAMPS
   unsigned long long *stamps;     // [8 waves][X3_NSTAMP] of workgroup 0
 #endif
@@ -645,6 +660,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #endif
   st.sync();
   FragRing ring;
+  float range_chk = 0.f;
   const long ntiles = (long)G.B * a.tpe;
   for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
     const long tile = (long)grp * WAVES + wave;
@@ -690,7 +706,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(bo + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
-    layer_norm(y, ln1w, ln1b, g);
+    range_chk += layer_norm(y, ln1w, ln1b, g);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) split_frag(y[2 * ks], y[2 * ks + 1], xh[ks], xl[ks]);
     X3_LAP(st, 7);
@@ -713,7 +729,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(b2 + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
-    layer_norm(y, ln2w, ln2b, g);
+    range_chk += layer_norm(y, ln2w, ln2b, g);
     const bool ztgt = LAST && a.zimg && rowok && r >= G.P;
     const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
 #pragma unroll
@@ -732,6 +748,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     X3_LAP(st, 7);
   }
   st.finish();
+  range_check_nan(a.range_flag, range_chk);
 #ifdef X3_STAMPS
   if (a.stamps && blockIdx.x == 0 && lane == 0) {
     unsigned long long t_end;

@@ -25,7 +25,7 @@ import torch
 from torch import optim
 from torch.optim import lr_scheduler
 
-from .train import train_step
+from .train import optimizer_step, train_step
 from .utils.target_mask import create_target_mask
 
 
@@ -124,16 +124,42 @@ def epoch_target_mask(task_cfg):
     return mask_type, mask
 
 
-def offset_rank_rng(rank, world):
-    """Episode data parallelism: every rank must draw its OWN episodes but the SAME per-epoch T and target
-    mask.  T / mask come from python's `random` (train_aline.py:59,62), the episodes from torch (and numpy): those two are
-    re-seeded per rank, `random` is left alone.  Called at start-up and after load_checkpoint (which restores identical
-    generator states on every rank)."""
-    if world <= 1:
-        return
-    base = int(torch.initial_seed()) % (2 ** 31)
-    torch.manual_seed(base + 1000003 * (rank + 1))              # CPU and CUDA generators
-    np.random.seed((base + 7919 * (rank + 1)) % (2 ** 32))
+class RankRng:
+    """Episode data parallelism: every rank draws its OWN episodes but the SAME per-epoch T and target mask.
+
+    T and the mask type come from python's `random` (train_aline.py:59,62), which stays identical on all ranks.  The mask
+    itself may consume torch's generator (`partial`: torch.randperm, weighted `predefined`: torch.multinomial,
+    utils/target_mask.py:18,24), and the episodes consume torch / numpy: so the torch stream that was common to all ranks at
+    start-up (same seed, or the state load_checkpoint restored) is kept aside as the SHARED stream for mask draws, and the
+    global torch / numpy generators are re-seeded per rank for the episodes -- with the start epoch folded in, so that a
+    resumed multi-rank run does not replay the episode stream of epochs 0..N of the original run.  world == 1: nothing is
+    touched (the single-process run consumes the generators exactly like the reference)."""
+
+    def __init__(self, rank, world, start_epoch=0):
+        self.shared = None
+        if world <= 1:
+            return
+        self.shared = torch.get_rng_state()
+        base = int(torch.initial_seed()) % (2 ** 31)
+        torch.manual_seed(base + 1000003 * (rank + 1) + 7907 * start_epoch)              # CPU and CUDA generators
+        np.random.seed((base + 7919 * (rank + 1) + 104729 * start_epoch) % (2 ** 32))
+
+    def shared_draw(self, fn):
+        """fn() with torch's global CPU generator switched to the stream all ranks share."""
+        if self.shared is None:
+            return fn()
+        mine = torch.get_rng_state()
+        torch.set_rng_state(self.shared)
+        try:
+            return fn()
+        finally:
+            self.shared = torch.get_rng_state()
+            torch.set_rng_state(mine)
+
+
+def offset_rank_rng(rank, world, start_epoch=0):
+    """(kept for callers of round 2) re-seeds the per-rank generators; see RankRng."""
+    return RankRng(rank, world, start_epoch)
 
 
 def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_epoch=None, verbose=None,
@@ -157,7 +183,7 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
     start_epoch = 0
     if _get(cfg, "load_checkpoint", False):
         start_epoch, optimizer, scheduler = load_checkpoint(cfg, model, optimizer, scheduler, _get(cfg, "load_path"))
-    offset_rank_rng(rank, world)
+    rng = RankRng(rank, world, start_epoch)
 
     def barrier():
         if dist is not None and world > 1:
@@ -171,7 +197,7 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
         tic = time.time()
         T = random.randint(min_T, max_T)
         batch = experiment.sample_batch(batch_size)
-        mask_type, batch["target_mask"] = epoch_target_mask(task_cfg)
+        mask_type, batch["target_mask"] = rng.shared_draw(lambda: epoch_target_mask(task_cfg))
         terms, _ = train_step(model, batch, T, optimizer=None, embedding_type=_get(task_cfg, "embedding_type", "theta"),
                               mask_type=mask_type, gamma=_get(cfg, "gamma", 1.0), alpha=_get(cfg, "alpha", 1.0),
                               burn_in=epoch < burn, clip_grads=_get(cfg, "clip_grads", True), dist=dist, world=world)
@@ -183,7 +209,7 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
             if rank == 0:
                 say(f"burn-in finished; model saved at {save_state_dict(model, _get(cfg, 'output_dir', '.'), stem + '_burning.pth')}")
             barrier()
-        optimizer.step()
+        optimizer_step(model, optimizer, burn_in=epoch < burn)
         scheduler.step()
         rec = dict(epoch=epoch, T=T, mask_type=mask_type, loss=float(terms["loss"]),
                    design_loss=float(terms["design_loss"]), predict_loss=float(terms["predict_loss"]),

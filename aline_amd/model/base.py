@@ -42,6 +42,7 @@ class Aline(nn.Module):
                  precision: str = None) -> None:
         super().__init__()
         self.embedder, self.encoder, self.head = embedder, encoder, head
+        self.range_check = True       # f16x3: read the range status back after every step-API forward (automatic f32 re-run)
         if precision is not None:
             self.set_precision(precision)
 
@@ -97,6 +98,18 @@ class Aline(nn.Module):
         ws, nb = call.workspace(m)
         _lib.check(_lib.lib.aline_step_forward(C.byref(m), C.byref(call.s), ws, nb,
                                                _lib.stream_ptr(call.device)), "step_forward")
+        if m.precision == _lib.PREC["f16x3"] and self.range_check and not torch.cuda.is_current_stream_capturing():
+            # f16 range guard: one 4-byte read-back per step (the reference's own step synchronises too, encoder.py:17)
+            rc = _lib.lib.aline_f16_range_status(ws, _lib.stream_ptr(call.device))
+            if rc < 0:
+                _lib.check(rc, "f16_range_status")
+            if rc > 0:
+                import warnings
+                warnings.warn("aline_amd: an F16X3 operand left f16's range (|x| >= 65504 or non-finite); re-running this step in f32")
+                m.precision = _lib.PREC["f32"]
+                ws, nb = call.workspace(m)
+                _lib.check(_lib.lib.aline_step_forward(C.byref(m), C.byref(call.s), ws, nb,
+                                                       _lib.stream_ptr(call.device)), "step_forward")
         frozen = {k: _native._get(batch, k) for k in ("context_x", "query_x", "target_all", "target_mask")}
         out = self.head._package(outs, lambda: self.head._query_posterior(frozen, z))
         if return_hidden:

@@ -1,6 +1,8 @@
 """Episode-level data parallelism: episodes are independent through the whole
-rollout, so ranks shard the batch and never exchange data on the forward path.  One process per
-GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests)."""
+rollout, so every rank rolls out its own episodes and never exchanges data on the forward path.  One process per
+GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests).  bench.py times every leg
+through `aggregate_throughput` (the whole-job rate of the bench contract).  The gradient all-reduce of the training step is
+`aline_amd.train.all_reduce_grads`; the evaluation shards its outer batches in `aline_amd.utils.eval.eval_boed`."""
 import os
 
 import torch
@@ -9,13 +11,6 @@ import torch
 def world_info():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
-
-
-def shard_range(total: int, rank: int, world: int):
-    """Contiguous, balanced shard [lo, hi) of `total` episodes for `rank` (sizes differ by <= 1)."""
-    base, rem = divmod(total, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
 
 
 def aggregate_throughput(local_units: float, local_seconds: float, dist=None, device="cpu"):

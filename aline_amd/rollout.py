@@ -91,6 +91,7 @@ class Rollout:
             raise RuntimeError("aline_amd: unsupported model/batch configuration")
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._graph = None
+        self.fell_back = False          # run_checked() re-ran the rollout in f32 after an f16 range overflow
 
     PATHS = {0: "generic pipeline", 1: "fused::rollout_f32_kernel", 2: "wide::wide_step_kernel",
              3: "x3::layer_kernel", 4: "s3::step_kernel"}
@@ -102,6 +103,15 @@ class Rollout:
         if rc < 0:
             _lib.check(rc, "rollout_path")
         return self.PATHS[rc]
+
+    @property
+    def kernel_name(self):
+        """The dominant kernel of that path as rocprofv3 names it (template arguments of the launch shape included)."""
+        buf = C.create_string_buffer(128)
+        rc = _lib.lib.aline_rollout_kernel_name(C.byref(self.m), C.byref(self.r), buf, 128)
+        if rc < 0:
+            _lib.check(rc, "rollout_kernel_name")
+        return buf.value.decode()
 
     # ------------------------------------------------------------------------------------------
     def refresh_uniform(self):
@@ -117,6 +127,37 @@ class Rollout:
         """init + T steps enqueued on the current stream (no host synchronisation)."""
         self._enqueue()
         return self
+
+    # ---- f16 range guard (include/aline_hip.h: aline_f16_range_status) -----------------------------------------------
+    def range_status(self):
+        """0 = clean; bit 0 / bit 1: an activation / a weight left f16's range in an F16X3 kernel of the last run (the
+        results then hold inf / NaN).  Host-synchronising: call it where the caller synchronises anyway."""
+        return _lib.f16_range_status(self.ws, self.device)
+
+    def check_range(self):
+        st = self.range_status()
+        if st:
+            raise RuntimeError(f"aline_amd: F16X3 operand out of f16 range (status {st}: "
+                               f"{'activation ' if st & 1 else ''}{'weight' if st & 2 else ''}); use precision 'f32'")
+        return self
+
+    def run_checked(self):
+        """run(), then the range status (one host synchronisation); an F16X3 rollout whose operands left f16's range is
+        re-run in exact fp32 (same designs when they were forced; a warning is issued)."""
+        self.run()
+        if self.m.precision != _lib.PREC["f16x3"] or not self.range_status():
+            return self
+        import warnings
+        warnings.warn("aline_amd: an F16X3 operand left f16's range (|x| >= 65504 or non-finite); re-running this rollout in f32")
+        self.m.precision = _lib.PREC["f32"]
+        nbytes = _lib.lib.aline_rollout_workspace_bytes(C.byref(self.m), C.byref(self.r))
+        if nbytes == 0:
+            raise RuntimeError("aline_amd: unsupported model/batch configuration")
+        if nbytes > self.ws.numel():
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._graph = None
+        self.fell_back = True
+        return self.run()
 
     def capture(self):
         """Capture init + T steps into one HIP graph (hipGraph through torch's stream capture:

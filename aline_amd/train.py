@@ -88,9 +88,14 @@ def _discounts(gamma, T, dev):
     return _DISC[key]
 
 
-def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, burn_in=False):
+def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, burn_in=False, dist=None, world=1):
     """train_aline.py:97-132 on the rollout's per-step log-likelihoods.  Returns the losses and the two
-    upstream gradients of `aline_rollout_backward` (dLoss/dlog_prob [B,T], dLoss/dtarget_ll [T,B,n_t])."""
+    upstream gradients of `aline_rollout_backward` (dLoss/dlog_prob [B,T], dLoss/dtarget_ll [T,B,n_t]).
+
+    dist / world (data parallel): the reward z-score of train_aline.py:122 uses the mean and the unbiased std over dim 0 of
+    the GLOBAL batch (world * B episodes): one all-reduce of the per-rank sums [3, T - 1] (count, sum, sum of squares), so an
+    N-rank step equals the single-process step on the concatenated batch; the design loss / its gradient are then scaled for
+    the global batch (the gradient all-reduce averages over ranks).  dist=None: rank-local moments."""
     B, T, n_t = ro.B, ro.T, ro.n_t
     nll_q, nll = ro.nlls(embedding_type, mask_type)                      # [B, T]
     predict_loss = nll.mean()
@@ -101,7 +106,14 @@ def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, b
     if T > 1:
         disc = _discounts(gamma, T, dev)
         R = disc * torch.clamp(nll_q[:, :-1] - nll_q[:, 1:], min=0.0)    # [B, T-1], detached by construction
-        R = (R - R.mean(dim=0, keepdim=True)) / (R.std(dim=0, keepdim=True) + 1e-9)
+        if dist is not None and world > 1:
+            mom = torch.stack([torch.full_like(R[0], float(B)), R.sum(0), (R * R).sum(0)])     # [3, T-1]
+            dist.all_reduce(mom)
+            n, mean = mom[0], mom[1] / mom[0]
+            var = (mom[2] - n * mean * mean).clamp(min=0.0) / (n - 1.0)                         # unbiased, as Tensor.std
+            R = (R - mean) / (var.sqrt() + 1e-9)
+        else:
+            R = (R - R.mean(dim=0, keepdim=True)) / (R.std(dim=0, keepdim=True) + 1e-9)
         design_loss = -(ro.log_prob[:, :-1] * R).mean()
         if not burn_in:
             g_logp[:, :-1] = -alpha * R / (B * (T - 1))
@@ -160,17 +172,55 @@ def all_reduce_grads(model, dist, world, flat=None):
         off += n
 
 
-_ROLLOUT_GRAPHS = {}          # (model, shapes, T) -> captured Rollout; at most _MAX_GRAPHS of them
+_ROLLOUT_GRAPHS = {}          # (model, shapes, T) -> captured Rollout, most recently used last; at most _MAX_GRAPHS of them
 _MAX_GRAPHS = 8
 _GRAPH_OK = True
+_GRAPH_MISSES = 0             # consecutive cache misses: a driver that draws T from a wide range would capture every step
+_RANGE_PENDING = []           # (pinned status word, event) of training rollouts whose f16 range status has not been looked at
+
+
+def _own(t):
+    """A private fp32 copy: the graph's input buffers must not alias the caller's first batch (`_lib.f32` returns the same
+    storage for an fp32-contiguous tensor, and the buffers are overwritten at every later step)."""
+    return None if t is None else t.detach().to(torch.float32).clone()
+
+
+def check_range_async(block=False):
+    """Training rollouts in f16x3 post their range status (include/aline_hip.h) to pinned memory without stalling the step;
+    this looks at the ones that have arrived (all of them with block=True) and raises if an operand left f16's range -- the
+    update of that step was computed from inf / NaN, so the run must stop (use precision 'f32')."""
+    keep = []
+    for word, ev in _RANGE_PENDING:
+        if block:
+            ev.synchronize()
+        if ev.query():
+            if int(word.item()) & 0xFF:
+                _RANGE_PENDING.clear()
+                raise RuntimeError("aline_amd: an F16X3 operand left f16's range during a training rollout (status "
+                                   f"{int(word.item()) & 0xFF}); train with precision 'f32'")
+        else:
+            keep.append((word, ev))
+    _RANGE_PENDING[:] = keep
+
+
+def _post_range_status(ro):
+    if ro.m.precision != _lib.PREC["f16x3"]:
+        return
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    word.copy_(ro.ws[:4].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _RANGE_PENDING.append((word, ev))
 
 
 def _sampled_rollout(model, batch, T):
     """The forward rollout of a training step (designs sampled, train_aline.py:80-110) replayed from a HIP graph that is kept
-    per (model, batch shapes, T): the step's data is copied into the graph's input buffers, the uniform numbers are redrawn
-    and the graph is replayed (3.2 ms of eager launches -> 2.9 ms at the headline shape).  ALINE_TRAIN_GRAPH=0: eager."""
+    per (model, batch shapes, T): the step's data is copied into the graph's own input buffers, the uniform numbers are redrawn
+    and the graph is replayed (3.2 ms of eager launches -> 2.9 ms at the headline shape).  ALINE_TRAIN_GRAPH=0: eager.  The
+    cache is LRU; after _MAX_GRAPHS consecutive misses (T drawn from a range wider than the cache, train_aline.py:59-62) the
+    step runs eagerly instead of capturing a graph it will not see again."""
     import os
-    global _GRAPH_OK
+    global _GRAPH_OK, _GRAPH_MISSES
     if os.environ.get("ALINE_TRAIN_GRAPH", "1") == "0" or not _GRAPH_OK:
         return Rollout(model, batch, T, select="sample").run()
     g = lambda k: batch.get(k) if isinstance(batch, dict) else getattr(batch, k, None)    # noqa: E731
@@ -178,20 +228,29 @@ def _sampled_rollout(model, batch, T):
     prm = list(model.parameters())
     key = (id(model), prm[0].data_ptr(), prm[-1].data_ptr(), T, model.precision if hasattr(model, "precision") else None,
            tuple((k, tuple(v.shape), v.dtype) for k, v in tens.items() if torch.is_tensor(v)))
-    ro = _ROLLOUT_GRAPHS.get(key)
+    ro = _ROLLOUT_GRAPHS.pop(key, None)
     if ro is None:
+        _GRAPH_MISSES += 1
+        if _GRAPH_MISSES > _MAX_GRAPHS:          # thrashing: eager launches (+0.3 ms) beat a warm-up run + a capture per step
+            return Rollout(model, batch, T, select="sample").run()
         if len(_ROLLOUT_GRAPHS) >= _MAX_GRAPHS:
-            _ROLLOUT_GRAPHS.pop(next(iter(_ROLLOUT_GRAPHS)))
+            _ROLLOUT_GRAPHS.pop(next(iter(_ROLLOUT_GRAPHS)))         # least recently used
         try:
-            ro = Rollout(model, batch, T, select="sample").capture()
+            own = dict(batch) if isinstance(batch, dict) else {k: v for k, v in vars(batch).items()}
+            for k in ("target_all", "target_x"):
+                if torch.is_tensor(own.get(k)):
+                    own[k] = _own(own[k])
+            if torch.is_tensor(own.get("target_mask")):
+                own["target_mask"] = own["target_mask"].clone()
+            ro = Rollout(model, own, T, select="sample").capture()
         except RuntimeError as e:                   # a runtime that refuses the capture: eager launches from now on
             import warnings
             warnings.warn(f"aline_amd: HIP-graph capture of the training rollout failed ({e}); using eager launches")
             _GRAPH_OK = False
             torch.cuda.synchronize()
             return Rollout(model, batch, T, select="sample").run()
-        _ROLLOUT_GRAPHS[key] = ro
     else:
+        _GRAPH_MISSES = 0
         torch.cat([_lib.f32(tens["context_x"]), _lib.f32(tens["query_x"])], dim=1, out=ro.px)
         torch.cat([_lib.f32(tens["context_y"]), _lib.f32(tens["query_y"])], dim=1, out=ro.py)
         ro.target_all.copy_(tens["target_all"].reshape(ro.target_all.shape))
@@ -199,14 +258,39 @@ def _sampled_rollout(model, batch, T):
             ro.tx.copy_(tens["target_x"])
         if ro.tmask is not None:
             ro.tmask.copy_(tens["target_mask"])
+    _ROLLOUT_GRAPHS[key] = ro                        # (re-)inserted last = most recently used
     ro.refresh_uniform()
     return ro.replay()
 
 
+def optimizer_step(model, optimizer, burn_in=False):
+    """optimizer.step() as the reference sees it: during burn-in (train_aline.py:126-128: loss = predict_loss) no loss term
+    reaches the acquisition head, its .grad stays None there and AdamW skips those parameters -- no weight decay, no moment
+    updates.  The flat gradient buffer gives every parameter a (zero) .grad, so they are hidden for the step."""
+    if not burn_in:
+        optimizer.step()
+        return
+    frozen = list(model.head.acquisition_head.parameters())
+    views = [p.grad for p in frozen]
+    for p in frozen:
+        p.grad = None
+    try:
+        optimizer.step()
+    finally:
+        for p, v in zip(frozen, views):
+            p.grad = v
+
+
 def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_type="all", gamma=1.0, alpha=1.0,
-               burn_in=False, forced_idx=None, clip_grads=True, dist=None, world=1, t_chunk=None):
-    """One epoch body of train_aline.py:55-152 (without the hydra / logging shell)."""
+               burn_in=False, forced_idx=None, clip_grads=True, dist=None, world=1, t_chunk=None, global_reward_moments=False):
+    """One epoch body of train_aline.py:55-152 (without the hydra / logging shell).
+
+    The returned `ro` is the step's rollout; when it came from the graph cache its outputs (log_prob, target_ll, idx, ...) are
+    the cache entry's buffers and are overwritten by the next step with the same shapes -- clone what must outlive the step.
+    global_reward_moments (N > 1): z-score the rewards with the moments of the WHOLE data-parallel batch (one extra all-reduce
+    of [3, T - 1] floats before the backward; SURVEY 8-e option ii) instead of the rank-local moments (option i)."""
     model.train()
+    check_range_async()                   # (f16x3 rollouts of earlier steps: raises if an operand left f16's range)
     with torch.no_grad():
         flat, gstruct = flat_grads(model)
         flat.zero_()
@@ -214,7 +298,9 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
             ro = Rollout(model, batch, T, select="forced", forced_idx=forced_idx).run()
         else:
             ro = _sampled_rollout(model, batch, T)
-        terms = reinforce_terms(ro, embedding_type, mask_type, gamma, alpha, burn_in)
+        _post_range_status(ro)
+        terms = reinforce_terms(ro, embedding_type, mask_type, gamma, alpha, burn_in,
+                                dist=dist if (global_reward_moments and world > 1) else None, world=world)
         backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=t_chunk, grads=gstruct)
         if dist is not None and world > 1:
             all_reduce_grads(model, dist, world, flat=flat)
@@ -223,7 +309,7 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
             # total norm = max |g| over all tensors, coefficient = min(1, max_norm / (total + 1e-6))
             flat.mul_((1.0 / (flat.abs().max() + 1e-6)).clamp(max=1.0))
         if optimizer is not None:
-            optimizer.step()
+            optimizer_step(model, optimizer, burn_in)
     return terms, ro
 
 

@@ -37,7 +37,7 @@ def get_traces(model, experiment, T=30, batch_size=40, time_token=False):
     batch = experiment.sample_batch(batch_size)
     # the reference's eval loop feeds batch.t = (T - t) / T (eval.py:24), not the t / T of training
     ro = Rollout(model, batch, T, select="argmax", time_token_T=T if time_token else 0, time_token_reverse=bool(time_token))
-    ro.run()
+    ro.run_checked()        # (f16x3: falls back to f32 if an operand left f16's range)
     cx, cy = ro.export_context()
     theta_0 = batch.target_theta.reshape(*theta_shape)
     return theta_0, experiment.unnormalise_design(cx), cy

@@ -12,7 +12,9 @@
  *     call is legal inside hipGraph capture;
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work, never synchronise;
  *   - return 0 on success, a negative ALINE_E* code otherwise; nothing throws across the ABI;
- *   - re-entrant, no mutable global state.
+ *   - re-entrant; the library never reads the environment.  The only mutable process-wide state is the diagnostic
+ *     word of aline_debug_set_flags (0 = normal operation, which nothing but tests / A-B measurements changes) and its
+ *     two integer knobs, plus a sticky f16-range status word that aline_f16_range_status reads and clears.
  */
 #ifndef ALINE_HIP_H
 #define ALINE_HIP_H
@@ -23,13 +25,17 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
+#pragma GCC visibility push(default)
 
-#define ALINE_ABI_VERSION 2
+#define ALINE_ABI_VERSION 3
 #define ALINE_MAX_LAYERS 8
 #define ALINE_MAX_COMPONENTS 16
+#define ALINE_MAX_POINTS 4096     /* P = n_ctx0 + n_query0 of a rollout / n_ctx + n_query of a step (README.md:45,50 evaluate at n_query = 2000) */
 
 enum { ALINE_OK = 0, ALINE_EINVAL = -1, ALINE_EUNSUPPORTED = -2, ALINE_EWORKSPACE = -3,
-       ALINE_ELAUNCH = -4 };
+       ALINE_ELAUNCH = -4,
+       ALINE_ERANGE = -5 };  /* an F16X3 operand left f16's range (see aline_f16_range_status) */
 
 /* embedding_type of model/embedder.py:24 */
 enum { ALINE_EMB_DATA = 0, ALINE_EMB_THETA = 1, ALINE_EMB_MIX = 2 };
@@ -40,7 +46,10 @@ enum { ALINE_EMB_DATA = 0, ALINE_EMB_THETA = 1, ALINE_EMB_MIX = 2 };
  * 3 bf16 MFMA passes; F16X3 = the same 3-term split in f16 (11 + 11 significant bits, dropped term
  * <= 2^-24): reference-grade results (posterior log-likelihood within 1e-4 of the fp32 reference on
  * every fixture, like F32) at 3 passes of the f16/bf16 matrix pipe -- the parity mode of the wide
- * (d = 256) path and of the generic GEMMs.  Inputs to F16X3 products must be below 65504 in magnitude. */
+ * (d = 256) path and of the generic GEMMs.  Operands of F16X3 products must be below 65504 in magnitude (weights are
+ * pre-scaled by 2^8: |w| < 255): every F16X3 kernel checks the operands it splits and raises a sticky device flag in the
+ * workspace when one is non-finite or out of range -- aline_f16_range_status() reads it (a host-synchronising call made by
+ * the caller after the work, never by the library); the Python mirror re-runs such a call in F32 and warns. */
 enum { ALINE_PREC_F32 = 0, ALINE_PREC_BF16 = 1, ALINE_PREC_BF16X3 = 2, ALINE_PREC_F16X3 = 3 };
 
 /* design selection of model/head.py:350-358 */
@@ -170,6 +179,9 @@ enum { ALINE_PATH_GENERIC = 0,   /* stage kernels + GEMMs, any configuration */
        ALINE_PATH_X3 = 3,        /* x3.h: d = 256, F16X3 (reference precision on the f16 matrix pipe) */
        ALINE_PATH_S3 = 4 };      /* s3.h: d = 32, F16X3, any embedding mode, one launch per design step */
 int aline_rollout_path(const aline_model *m, const aline_rollout *r);
+/* Name (as rocprofv3 prints it, template arguments included) of the dominant kernel of that path for (m, r) -- the launch
+ * the ev_kernel_start / ev_kernel_stop pair brackets -- written to buf; returns the ALINE_PATH_* value or a negative code. */
+int aline_rollout_kernel_name(const aline_model *m, const aline_rollout *r, char *buf, size_t n);
 /* Task.update_batch equivalent for callers that want the reference layout back
  * (tasks/base_task.py:133-154): context_x/y [B,n_ctx0+T,*] in order of entry, query remainder. */
 int aline_rollout_export(const aline_rollout *r, int n_ctx, float *context_x, float *context_y,
@@ -260,11 +272,51 @@ int aline_encoder_backward(const aline_model *m, const aline_rollout *r, const f
 int aline_embed_backward(const aline_model *m, const aline_rollout *r, const float *dx, const aline_grads *grads,
                          void *ws, size_t ws_bytes, void *stream);
 
-/* --- diagnostics ----------------------------------------------------------------------------- */
-/* Byte offset, inside a rollout workspace, of the per-phase cycle stamps the fused rollout kernel
- * writes when the process runs with ALINE_FUSED_STAMPS=1 (diagnostic instantiation only). */
-size_t aline_debug_stamps_offset(const aline_model *m, const aline_rollout *r);
+/* --- F16X3 operand range guard ------------------------------------------------------------------ */
+/* Byte offset, inside any step / rollout workspace of this library, of a 32-bit status word the F16X3 kernels OR into:
+ * bit 0 = an activation operand was non-finite or >= 65504 in magnitude when it was split into f16 halves, bit 1 = a weight
+ * (after the 2^8 pre-scale).  aline_*_forward clear it when they start.  aline_f16_range_status copies it to the host
+ * (hipMemcpyAsync + stream synchronise: call it after the work, outside graph capture) and returns the word (>= 0) or a
+ * negative error code. */
+size_t aline_f16_range_offset(void);
+int aline_f16_range_status(const void *ws, void *stream);
 
+/* --- diagnostics ----------------------------------------------------------------------------- */
+/* Process-wide diagnostic word, 0 in normal operation.  Tests and A/B measurements use it to force the path a fused kernel
+ * replaces (every fused kernel is cross-checked against that path) or to opt into an experiment.  Returns the old word. */
+enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off -> generic pipeline */
+       ALINE_DBG_DISABLE_WIDE = 1u << 1,       /* wide path off */
+       ALINE_DBG_DISABLE_X3 = 1u << 2,         /* x3 path off -> generic pipeline on the F16X3 GEMM policy */
+       ALINE_DBG_DISABLE_S3 = 1u << 3,         /* s3 path off */
+       ALINE_DBG_WIDE_BLOCKS = 1u << 4,        /* wide path on per-block kernels */
+       ALINE_DBG_NO_LAYER_TAIL = 1u << 5,      /* generic d = 32 pipeline on per-op kernels */
+       ALINE_DBG_FULL_QKV = 1u << 6,           /* generic pipeline: K / V of every row (as the reference) */
+       ALINE_DBG_VALU_ATTENTION = 1u << 7,     /* generic pipeline: fp32 VALU attention instead of attn3 */
+       ALINE_DBG_S3_GENERIC_EMBED = 1u << 8,   /* s3: point embedders on the generic kernels */
+       ALINE_DBG_CES_GENERIC = 1u << 9,        /* CES likelihood: powf formulation */
+       ALINE_DBG_FUSED_STAMPS = 1u << 10,      /* in-kernel phase stamps (diagnostic instantiations) */
+       ALINE_DBG_WIDE_STAMPS = 1u << 11,
+       ALINE_DBG_BWD_TAIL_PC = 1u << 12,       /* producer / consumer tail backward */
+       /* backward: switch ONE fused kernel back to the per-op pipeline it replaces */
+       ALINE_DBG_NO_BWD_TAIL = 1u << 16, ALINE_DBG_NO_BWD_ATTN_BLOCK = 1u << 17, ALINE_DBG_NO_BWD_ACQ = 1u << 18,
+       ALINE_DBG_NO_BWD_LAYER_FWD = 1u << 19, ALINE_DBG_NO_BWD_LAYER_FWD_FLAT = 1u << 20,
+       ALINE_DBG_NO_BWD_GMM_FUSED = 1u << 21, ALINE_DBG_NO_BWD_GMM128 = 1u << 22, ALINE_DBG_NO_BWD_GMM_BATCHED = 1u << 23,
+       ALINE_DBG_NO_BWD_ATTN_MFMA = 1u << 24,
+       ALINE_DBG_X3_LEGACY_HEAD = 1u << 25 };  /* x3: acquisition logits by the stand-alone head kernel */
+uint32_t aline_debug_set_flags(uint32_t flags);
+uint32_t aline_debug_get_flags(void);
+/* Integer knobs of the same kind (0 = automatic): launch shape of the s3 step kernel, precision of the backward GEMMs. */
+enum { ALINE_DBG_S3_WAVES = 0, ALINE_DBG_S3_EPW = 1, ALINE_DBG_BWD_PREC = 2, ALINE_DBG_NPARAMS = 3 };
+int aline_debug_set_param(int key, int value);
+/* Byte offset, inside a rollout workspace, of the per-phase cycle stamps the fused rollout kernel
+ * writes under ALINE_DBG_FUSED_STAMPS (diagnostic instantiation only). */
+size_t aline_debug_stamps_offset(const aline_model *m, const aline_rollout *r);
+/* Same for the buffers the stamped diagnostic builds of the x3 / s3 kernels (tools/x3_stamps.py, tools/s3_stamps.py) and
+ * tools/probes/relu_int_repro.py (acquisition logits of the wide path) read back. */
+size_t aline_debug_xraw_offset(const aline_model *m, const aline_rollout *r);
+size_t aline_debug_wlog_offset(const aline_model *m, const aline_rollout *r);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -35,9 +35,21 @@ def _lin(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     return y if b is None else y + b
 
 
+# Test probe: when set to a list, every ReLU appends (key prefix of its first Linear, pre-activation tensor).  The backward
+# parity test uses it to find the hidden units whose pre-activation sits on the ReLU's knife edge (|h| < 1e-6), where two
+# correct fp32 forwards may take different sides.
+RELU_PROBE: Optional[list] = None
+
+
+def _relu(h: Tensor, tag: str) -> Tensor:
+    if RELU_PROBE is not None:
+        RELU_PROBE.append((tag, h.detach()))
+    return torch.relu(h)
+
+
 def _mlp(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
     """nn.Sequential(Linear, ReLU, Linear) with keys `{prefix}.0.*`, `{prefix}.2.*`."""
-    h = torch.relu(_lin(x, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"]))
+    h = _relu(_lin(x, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"]), f"{prefix}.0")
     return _lin(h, sd[f"{prefix}.2.weight"], sd[f"{prefix}.2.bias"])
 
 
@@ -111,7 +123,7 @@ def encoder(sd, x: Tensor, allowed: Tensor, n_head: int, num_layers: int,
         a = a.transpose(1, 2).reshape(B, N, d)
         sa = _lin(a, sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"])
         x = _layer_norm(x + sa, sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"])
-        ff = _lin(torch.relu(_lin(x, sd[f"{p}.linear1.weight"], sd[f"{p}.linear1.bias"])),
+        ff = _lin(_relu(_lin(x, sd[f"{p}.linear1.weight"], sd[f"{p}.linear1.bias"]), f"{p}.linear1"),
                   sd[f"{p}.linear2.weight"], sd[f"{p}.linear2.bias"])
         x = _layer_norm(x + ff, sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"])
         outs.append(x)

@@ -37,10 +37,58 @@ def test_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_errors(lib):
     lib.aline_abi_version.restype = ctypes.c_int
-    assert lib.aline_abi_version() == 2
+    assert lib.aline_abi_version() == 3
     lib.aline_error_string.restype = ctypes.c_char_p
     assert lib.aline_error_string(0) == b"ok"
     assert b"workspace" in lib.aline_error_string(-3)
+
+
+def test_only_the_c_abi_is_exported_and_the_library_ignores_the_environment():
+    """-fvisibility=hidden: the dynamic symbol table holds the functions of include/aline_hip.h and nothing else of the
+    library's code (the C++ device stubs of round 2 are gone; what remains besides them are hipcc's kernel HANDLE objects,
+    data symbols the HIP runtime registers kernels by).  And the library has no environment switches: `getenv` is not among
+    its imports (diagnostics go through aline_debug_set_flags)."""
+    out = subprocess.check_output(["nm", "-D", LIB]).decode().splitlines()
+    funcs = [l.split()[-1] for l in out if len(l.split()) == 3 and l.split()[1] in "Tt"]
+    assert sorted(funcs) == declared_functions(), sorted(set(funcs) ^ set(declared_functions()))
+    undefined = [l.split()[-1].split("@")[0] for l in out if len(l.split()) == 2 and l.split()[0] == "U"]
+    assert "getenv" not in undefined and "secure_getenv" not in undefined
+
+
+def test_debug_word_and_kernel_name(lib):
+    """The diagnostic word (0 by default) steers the path selection; aline_rollout_kernel_name reports the dominant kernel
+    with the template arguments of the launch shape -- host logic only."""
+    from aline_amd import _lib
+    L = _lib.lib
+    assert L.aline_debug_get_flags() == 0
+    m = _small_model()
+    m.precision = _lib.PREC["f16x3"]
+    r = _lib.AlineRollout()
+    r.B, r.P, r.n_ctx0, r.n_target_data, r.T = 1000, 201, 1, 0, 30
+    buf = ctypes.create_string_buffer(128)
+    assert L.aline_rollout_kernel_name(ctypes.byref(m), ctypes.byref(r), buf, 128) == 4
+    assert buf.value == b"s3::step_kernel<128, 12, 2, false>"
+    with _lib.debug("DISABLE_S3"):
+        assert L.aline_rollout_path(ctypes.byref(m), ctypes.byref(r)) == 0
+    with _lib.debug(S3_WAVES=16):
+        L.aline_rollout_kernel_name(ctypes.byref(m), ctypes.byref(r), buf, 128)
+        assert buf.value == b"s3::step_kernel<128, 16, 2, false>"
+    with _lib.debug_env({"ALINE_DISABLE_S3": "1", "ALINE_BWD_TAIL": "0"}):
+        assert L.aline_debug_get_flags() == _lib.DBG["DISABLE_S3"] | _lib.DBG["NO_BWD_TAIL"]
+    assert L.aline_debug_get_flags() == 0
+    assert L.aline_rollout_path(ctypes.byref(m), ctypes.byref(r)) == 4
+    r.T, r.n_target_data = 50, 100                       # cfg3: up to 153 keys -> the 8-wave variant
+    m.n_theta, m.embedding_type = 3, 2
+    r.B = 512
+    L.aline_rollout_kernel_name(ctypes.byref(m), ctypes.byref(r), buf, 128)
+    assert buf.value == b"s3::step_kernel<128, 8, 5, false>"
+    assert L.aline_debug_set_param(99, 1) == -1
+    assert L.aline_f16_range_offset() == 0
+    # every enumerator of the header's ALINE_DBG_* list has the value the Python mirror uses
+    hdr = open(HEADER).read()
+    for name, bit in _lib.DBG.items():
+        mo = re.search(rf"ALINE_DBG_{name} = 1u << (\d+)", hdr)
+        assert mo and (1 << int(mo.group(1))) == bit, name
 
 
 def test_struct_layout_matches_c(tmp_path):
@@ -170,6 +218,7 @@ def test_rollout_path_selection_is_pure_host(lib):
     m.precision = _lib.PREC["f16x3"]
     assert L.aline_rollout_path(byref(m), byref(rollout())) == S3             # the benchmarked path
     assert L.aline_rollout_path(byref(m), byref(rollout(T=160))) == GENERIC   # 1 + 159 + 2 keys > 160
+    assert L.aline_rollout_path(byref(m), byref(rollout(B=2, P=2001, T=35))) == S3   # the evaluation protocol's n_query = 2000 (README.md:45)
     m.n_theta, m.embedding_type = 3, 2                                       # mix mode (cfg3): 1 + 49 + 103 keys
     assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == S3
     m.precision = _lib.PREC["f32"]

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from aline_amd.parallel import aggregate_throughput, shard_range
+from aline_amd.parallel import aggregate_throughput
 
 
 def _free_port():
@@ -20,7 +20,7 @@ def _free_port():
 def _worker(rank, world, port, total, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = shard_range(total, rank, world)
+    lo, hi = rank * (total // world), (rank + 1) * (total // world) if rank + 1 < world else total
     # every rank "rolls out" its own episodes; rank 1 is slower
     rate, tmax, units = aggregate_throughput(float(hi - lo) * 6000.0, 1.0 + rank, dist)
     covered = torch.zeros(total)
@@ -44,14 +44,96 @@ def test_shards_cover_batch_once_and_rate_uses_max_time():
     assert abs(rate - total * 6000.0 / 2.0) < 1e-6
 
 
-def test_shard_range_properties():
-    for total in (0, 1, 7, 1000, 4096):
-        for world in (1, 2, 3, 8):
-            spans = [shard_range(total, r, world) for r in range(world)]
-            assert spans[0][0] == 0 and spans[-1][1] == total
-            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-            sizes = [hi - lo for lo, hi in spans]
-            assert max(sizes) - min(sizes) <= 1
+class _FakeRollout:
+    """What aline_amd.train.reinforce_terms reads of a finished rollout, on the CPU."""
+
+    def __init__(self, target_ll, log_prob, n_theta):
+        import types
+        self.target_ll, self.log_prob = target_ll, log_prob
+        self.T, self.B, self.n_t = target_ll.shape
+        self.m = types.SimpleNamespace(n_theta=n_theta)
+        self.tmask = None
+
+    def nlls(self, embedding_type, mask_type="all"):
+        nll = -self.target_ll.mean(-1)
+        return nll.t(), nll.t()
+
+
+def _moments_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aline_amd.train import reinforce_terms
+    g = torch.Generator().manual_seed(5)
+    T, B, n_t = 7, 6, 2
+    ll, lp = torch.randn(T, world * B, n_t, generator=g), torch.randn(world * B, T, generator=g)
+    mine = _FakeRollout(ll[:, rank * B:(rank + 1) * B].contiguous(), lp[rank * B:(rank + 1) * B].contiguous(), 2)
+    glob = reinforce_terms(mine, "theta", dist=dist, world=world)              # option (ii): global moments
+    loc = reinforce_terms(mine, "theta")                                        # option (i): rank-local moments
+    # what the gradient all-reduce does to per-rank quantities: average over ranks
+    dl = glob["design_loss"].clone()
+    dist.all_reduce(dl)
+    dl /= world
+    if rank == 0:
+        whole = reinforce_terms(_FakeRollout(ll, lp, 2), "theta")              # the single-process step on the concatenated batch
+        out.put(dict(R_glob=glob["R"], R_loc=loc["R"], R_whole=whole["R"][:B], g_glob=glob["g_logp"], g_whole=whole["g_logp"][:B],
+                     dl=float(dl), dl_whole=float(whole["design_loss"])))
+    dist.destroy_process_group()
+
+
+def test_global_reward_moments_equal_the_single_process_batch():
+    """SURVEY 8-e option (ii): with the [3, T - 1] moment all-reduce the z-scored rewards of an N-rank step are those of the
+    single-process step on the concatenated batch (train_aline.py:122), and so are the design loss and -- after the gradient
+    all-reduce's average over ranks -- its gradient; the rank-local z-score (option i) is not."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_moments_worker, args=(r, world, port, out)) for r in range(world)]
+    [p.start() for p in procs]
+    res = out.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert torch.allclose(res["R_glob"], res["R_whole"], atol=1e-5)
+    assert not torch.allclose(res["R_loc"], res["R_whole"], atol=1e-3)
+    # g_logp = -alpha R / (B_local (T - 1)) per rank; averaged over `world` ranks it is the whole batch's -alpha R / (B (T - 1))
+    assert torch.allclose(res["g_glob"] / world, res["g_whole"], atol=1e-6)
+    assert abs(res["dl"] - res["dl_whole"]) < 1e-5
+
+
+def _rng_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import random
+    import numpy as np
+    from aline_amd.driver import RankRng, epoch_target_mask
+    rec = {}
+    for start_epoch in (0, 40):                          # a fresh run, and a run resumed at epoch 40 (same restored generator states)
+        torch.manual_seed(123); np.random.seed(123); random.seed(123)
+        rng = RankRng(rank, world, start_epoch)
+        masks, eps = [], []
+        for cfg in (dict(mask_type=["partial"], embedding_type="data", n_target_data=12, n_target_theta=0, n_selected_targets=4),
+                    dict(mask_type=["predefined"], embedding_type="theta", n_target_data=0, n_target_theta=4,
+                         predefined_masks=[[False, False, True, True], [True, True, False, False]], predefined_mask_weights=[1.0, 1.0])):
+            for _ in range(4):
+                masks.append(rng.shared_draw(lambda: epoch_target_mask(cfg))[1].tolist())
+                eps.append(torch.rand(3).tolist())       # "episodes": the rank's own torch stream
+        rec[start_epoch] = (masks, eps)
+    out.put((rank, rec))
+
+
+def test_ranks_draw_the_same_masks_and_their_own_episodes_also_after_resume():
+    """`partial` / weighted `predefined` masks consume torch's generator (utils/target_mask.py:18,24), which is
+    re-seeded per rank for the episodes -- the driver draws them from the stream all ranks share; a resumed run must not
+    replay the episode stream of the original run's first epochs."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_rng_worker, args=(r, world, port, out)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(out.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    for start in (0, 40):
+        assert got[0][start][0] == got[1][start][0]                     # same masks on both ranks
+        assert got[0][start][1] != got[1][start][1]                     # different episodes
+    assert len({tuple(map(tuple, got[0][0][0]))}) == 1 and any(m != got[0][0][0][0] for m in got[0][0][0])   # the draws vary
+    assert got[0][0][1] != got[0][40][1] and got[1][0][1] != got[1][40][1]      # resumed: a new episode stream per rank
 
 
 def _grad_worker(rank, world, port, out):

@@ -38,13 +38,10 @@ def test_exhausted_queries_masks_and_small_batches(B, n_c, n_q, T, mask, fused):
     batch, g = _batch(B, n_c, n_q, 11 * B + n_q, mask)
     forced = torch.stack([torch.randint(0, n_q - t, (B,), generator=g) for t in range(T)], 1)
     ref = orc.rollout(sd, batch, CFG, T, forced_idx=forced, mask_type="all" if mask is None else "partial")
-    if not fused:
-        os.environ["ALINE_DISABLE_FUSED"] = "1"
-    try:
+    from aline_amd import _lib
+    with _lib.debug(*([] if fused else ["DISABLE_FUSED"])):
         ro = Rollout(model, to_dev(batch), T, select="forced", forced_idx=forced, keep_zt=True).run()
         torch.cuda.synchronize()
-    finally:
-        os.environ.pop("ALINE_DISABLE_FUSED", None)
     assert maxdiff(ro.target_ll, torch.stack(ref["target_ll"])) < 1e-4
     assert maxdiff(ro.log_prob, torch.stack(ref["log_prob"], 1)) < 1e-4
     zt = ro.zt.cpu()                                     # [T, B, n_q] zero padded

@@ -207,7 +207,7 @@ def test_no_cpu_fallback():
 
 def test_layer_tail_and_gmm_kernels_match_the_per_op_pipeline(golden):
     """d=32 / F=128 generic pipeline: `fused::layer_tail_kernel` (out-proj + LN1 + FFN + LN2 in one kernel) and the
-    row-mapped `fused::gmm_rows_kernel` against the per-op kernels they replace (ALINE_NO_LAYER_TAIL=1), mix mode
+    row-mapped `fused::gmm_rows_kernel` against the per-op kernels they replace (ALINE_DBG_NO_LAYER_TAIL), mix mode
     with a split mask, teacher-forced with the same designs."""
     import os
     from aline_amd.rollout import Rollout
@@ -216,14 +216,11 @@ def test_layer_tail_and_gmm_kernels_match_the_per_op_pipeline(golden):
     model, _ = native_model(dims, fx.meta["wseed"])
     batch, forced = to_dev(fx.batch()), fx.forced_idx("train")
     outs = []
-    for env in (None, "1"):
-        if env:
-            os.environ["ALINE_NO_LAYER_TAIL"] = env
-        try:
+    from aline_amd import _lib
+    for flags in ([], ["NO_LAYER_TAIL"]):
+        with _lib.debug(*flags):
             ro = Rollout(model, batch, T, select="forced", forced_idx=forced, keep_zt=True).run()
             torch.cuda.synchronize()
-        finally:
-            os.environ.pop("ALINE_NO_LAYER_TAIL", None)
         outs.append((ro.target_ll.cpu().clone(), ro.log_prob.cpu().clone(), ro.post_std.cpu().clone()))
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-4
     assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-4

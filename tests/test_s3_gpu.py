@@ -44,10 +44,8 @@ def make_batch(emb, B, n_query, seed, dx=2, n_td=20, n_ctx=1):
 
 def run(prec, env, emb, B, n_query, T, seed=5, select="forced", target_mask=None, want_path=None, postq=False, **kw):
     from aline_amd.rollout import Rollout
-    for k in ENV_KEYS:
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
+    from aline_amd import _lib
+    with _lib.debug_env(env):
         bkw = {k: kw[k] for k in ("dx", "n_td", "n_ctx") if k in kw}
         dkw = {k: kw[k] for k in ("dx", "F", "L", "C") if k in kw}
         model, _ = native_model(dims_of(emb, **dkw), 11, prec)
@@ -75,9 +73,6 @@ def run(prec, env, emb, B, n_query, T, seed=5, select="forced", target_mask=None
                 "idx": ro.idx.cpu().clone(), "zt": ro.zt.float().cpu().clone(),
                 "mean": ro.post_mean.float().cpu().clone(), "std": ro.post_std.float().cpu().clone(),
                 "w": ro.post_weight.float().cpu().clone()}
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 def close(a, b):
@@ -156,11 +151,7 @@ def test_s3_fallbacks():
     d8 = dict(dims_of("theta"), n_head=8)
     model8, _ = native_model(d8, 11, "f16x3")
     assert Rollout(model8, make_batch("theta", 2, 60, 1), 5, select="argmax").path == "generic pipeline"
-    os.environ["ALINE_DISABLE_S3"] = "1"
-    try:
-        a = run("f16x3", {"ALINE_DISABLE_S3": "1"}, "mix", 3, 50, 5, want_path="generic pipeline")
-    finally:
-        os.environ.pop("ALINE_DISABLE_S3", None)
+    a = run("f16x3", {"ALINE_DISABLE_S3": "1"}, "mix", 3, 50, 5, want_path="generic pipeline")
     b = run("f16x3", {}, "mix", 3, 50, 5, want_path="s3::step_kernel")
     close(a, b)
 

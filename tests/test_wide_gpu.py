@@ -21,10 +21,8 @@ DIMS = {"dim_x": 2, "dim_y": 1, "d": 256, "F": 1024, "n_head": 8, "L": 2, "C": 1
 def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, dims=None, full=False):
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
-    for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
+    from aline_amd import _lib
+    with _lib.debug_env(env):
         model, _ = native_model(dims or DIMS, 11, prec)
         torch.manual_seed(seed)
         task = HiddenLocation(device=torch.device("cuda"), n_query_init=n_query)
@@ -39,9 +37,6 @@ def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, di
         if full:
             return {k: getattr(ro, k).float().cpu().clone() for k in ("target_ll", "log_prob", "post_mean", "post_std", "post_weight")}
         return ro.target_ll.float().cpu().clone(), ro.log_prob.float().cpu().clone(), ro.idx.cpu().clone()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize("B,n_query,T", [(3, 200, 6), (5, 37, 4), (2, 250, 3), (4, 16, 5)])

@@ -14,10 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def _run(fxname, prec, env, fill):
     from aline_amd.rollout import Rollout
-    for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS", "ALINE_DISABLE_FUSED"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
+    from aline_amd import _lib
+    with _lib.debug_env(env):
         fx = Fixture(fxname)
         model, _ = native_model(fx.meta["dims"], fx.meta["wseed"], prec)
         ro = Rollout(model, to_dev(fx.batch()), fx.meta["T"], select="forced", forced_idx=fx.forced_idx("train"))
@@ -25,9 +23,6 @@ def _run(fxname, prec, env, fill):
         ro.run()
         torch.cuda.synchronize()
         return ro.target_ll.cpu().clone(), ro.log_prob.cpu().clone()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize("name,fxname,prec,env", [

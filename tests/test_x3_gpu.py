@@ -19,10 +19,8 @@ LL_TOL, LP_TOL = 1e-4, 1e-4
 def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, dims=DIMS):
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
-    for k in ("ALINE_DISABLE_X3", "ALINE_VALU_ATTENTION"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
+    from aline_amd import _lib
+    with _lib.debug_env(env):
         model, _ = native_model(dims, 11, prec)
         torch.manual_seed(seed)
         task = HiddenLocation(device=torch.device("cuda"), n_query_init=n_query)
@@ -35,9 +33,6 @@ def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, di
         ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None).run()
         torch.cuda.synchronize()
         return ro.target_ll.float().cpu().clone(), ro.log_prob.float().cpu().clone(), ro.idx.cpu().clone()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize("B,n_query,T", [(3, 200, 6), (5, 37, 4), (2, 250, 3), (4, 16, 5), (9, 200, 20), (2, 90, 40)])

@@ -24,5 +24,5 @@ for t in range(x.shape[1]):
     d = (ll[fin] - ref[t][fin]).abs()
     worst_abs = max(worst_abs, float(d.max()))
     worst_rel = max(worst_rel, float((d / (ref[t][fin].abs() + 1.0)).max()))
-print(f"kernel={'generic' if os.environ.get('ALINE_CES_GENERIC') else 'table'} max|d|={worst_abs:.4g} "
+print(f"kernel={'generic' if 'CES_GENERIC' in os.environ.get('ALINE_DBG', '') else 'table'} max|d|={worst_abs:.4g} "
       f"max|d|/(|ref|+1)={worst_rel:.3g}  (|ref| max {float(ref[torch.isfinite(ref)].abs().max()):.3g})")

@@ -30,7 +30,7 @@ def wait_states(line):
 
 def main():
     src = os.path.join(ROOT, "aline_amd", "csrc", "aline_hip.hip")
-    asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+    asm = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-S", "--cuda-device-only",
                           "-o", "-", src], capture_output=True, text=True, check=True).stdout
     lines = asm.splitlines()
     INF = 10 ** 6

@@ -1,14 +1,15 @@
 """Randomized cross-check of the fused d=32 rollout kernel against the generic fp32 pipeline (same C ABI, env
-ALINE_DISABLE_FUSED=1): shapes, step counts, target masks, sampling; plus run-to-run reproducibility.
+ALINE_DBG_DISABLE_FUSED): shapes, step counts, target masks, sampling; plus run-to-run reproducibility.
 Run on the GPU box:  python tools/fused_sweep.py"""
 import sys, os, torch, random
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/oracle")
 from helpers import native_model
+from aline_amd import _lib
 from aline_amd.rollout import Rollout
 from aline_amd.tasks import HiddenLocation
 DIMS = {"dim_x": 2, "dim_y": 1, "d": 32, "F": 128, "n_head": 4, "L": 3, "C": 10, "n_theta": 2, "embedding_type": "theta", "time_token": False}
 def run(env, B, nq, T, seed, mask):
-    os.environ.pop("ALINE_DISABLE_FUSED", None); os.environ.update(env)
+    _lib.lib.aline_debug_set_flags(0); ctx = _lib.debug_env(env); ctx.__enter__()
     model, _ = native_model(DIMS, 3 + seed, "f32")
     torch.manual_seed(seed)
     batch = HiddenLocation(device=torch.device("cuda"), n_query_init=nq).sample_batch(B)

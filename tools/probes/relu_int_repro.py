@@ -1,12 +1,13 @@
-"""Probe for DESIGN 4.3's note: does the streamed block-kernel path (ALINE_WIDE_BLOCKS=1) give bit-identical results run
+"""Probe for DESIGN 4.3's note: does the streamed block-kernel path (ALINE_DBG_WIDE_BLOCKS) give bit-identical results run
 to run with the library given in ALINE_HIP_LIB (built with / without -DALINE_RELU_INT)?  Prints the number of runs whose
 log-probabilities / log-likelihoods differ from the first run, and which steps / episodes differ."""
 import os, sys, torch
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.path.join(R, "oracle"))
-os.environ["ALINE_WIDE_BLOCKS"] = "1"
 from helpers import native_model
+from aline_amd import _lib
 from aline_amd.rollout import Rollout
+_lib.lib.aline_debug_set_flags(_lib.DBG["WIDE_BLOCKS"])
 from aline_amd.tasks import HiddenLocation
 DIMS = {"dim_x": 2, "dim_y": 1, "d": 256, "F": 1024, "n_head": 8, "L": 2, "C": 10, "n_theta": 2, "embedding_type": "theta", "time_token": False}
 model, _ = native_model(DIMS, 11, "bf16")

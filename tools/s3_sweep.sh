@@ -2,8 +2,6 @@
 run() { python tools/config_bench.py --configs $1 --precs f16x3 2>/dev/null | grep '"d": 32' | head -1 | python -c 'import json,sys; d=json.loads(sys.stdin.readline()); print(round(d["ms_per_rollout"],3), d["path"])'; }
 for spec in ${SWEEP:-16:0 16:4 16:5 8:0 8:4}; do
   w=${spec%%:*}; e=${spec#*:}
-  if [ $e = 0 ]; then unset ALINE_S3_EPW; else export ALINE_S3_EPW=$e; fi
-  echo "cfg2 waves=$w epw=$e: $(ALINE_S3_WAVES=$w run 2)"
+  echo "cfg2 waves=$w epw=$e: $(ALINE_DBG=S3_WAVES=$w,S3_EPW=$e run 2)"
 done
-unset ALINE_S3_EPW
 echo "cfg3: $(run 3)"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase cycle shares of the fused rollout kernel (s_memtime stamps, workgroup 0).
-Run on the GPU box:  ALINE_FUSED_STAMPS=1 python tools/stamps.py [--batch 1000]"""
+Run on the GPU box:  python tools/stamps.py [--batch 1000]"""
 import argparse
 import ctypes as C
 import os
@@ -9,10 +9,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ALINE_FUSED_STAMPS"] = "1"
 from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib  # noqa: E402
 from aline_amd.rollout import Rollout  # noqa: E402
 from aline_amd.tasks import HiddenLocation  # noqa: E402
+_lib.lib.aline_debug_set_flags(_lib.DBG["FUSED_STAMPS"])
 
 PH = ["key list", "x0 load", "weight stream+bar", "pre-pass+bar", "main pass", "wait slowest",
       "head stream", "acq MLP", "bar after acq", "select / GMM", "bar after sel", "GMM epilogue+bar"]

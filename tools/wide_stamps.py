@@ -4,10 +4,10 @@ Run on the GPU box:  python tools/wide_stamps.py [--batch 1000]"""
 import argparse, ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ALINE_WIDE_STAMPS"] = "1"
 from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib  # noqa: E402
 from aline_amd.rollout import Rollout  # noqa: E402
 from aline_amd.tasks import HiddenLocation  # noqa: E402
+_lib.lib.aline_debug_set_flags(_lib.DBG["WIDE_STAMPS"])
 
 PH = ["setup", "key rows->LDS", "K proj", "V proj", "Q proj", "Q frags+resid", "attention", "OUT proj", "LN1", "FFN",
       "LN2", "acq head"]

@@ -1,11 +1,11 @@
 import sys, os, torch, random
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/oracle")
 from helpers import native_model
+from aline_amd import _lib
 from aline_amd.rollout import Rollout
 from aline_amd.tasks import HiddenLocation
 def run(env, dims, B, nq, T, seed, mask):
-    for k in ("ALINE_DISABLE_WIDE", "ALINE_WIDE_BLOCKS"): os.environ.pop(k, None)
-    os.environ.update(env)
+    _lib.lib.aline_debug_set_flags(0); ctx = _lib.debug_env(env); ctx.__enter__()
     model, _ = native_model(dims, 11 + seed, "bf16")
     torch.manual_seed(seed)
     batch = HiddenLocation(device=torch.device("cuda"), n_query_init=nq).sample_batch(B)
