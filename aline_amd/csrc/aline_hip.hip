@@ -51,7 +51,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Flag, Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
+  size_t Flag, xKX, xKpos, Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -106,6 +106,8 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
     p.xIn = take(img); p.xA = take(img); p.xB = take(img);
     p.xKV = take((size_t)B * x3::KV_EP * 4);
     p.xKeys = take((size_t)B * x3::WNK); p.xKcnt = take((size_t)B * 2);
+    p.xKX = take((size_t)x3::img_pieces((long)B * (x3::WNK / 16)) * 4);      // key image (key rows of the layer input, key-list order)
+    p.xKpos = take((size_t)B * tpe * 16 / 2 + 1);                             // short [B][16 tpe]
     p.xLog = take((size_t)B * tpe * 16);
     p.xZimg = take((size_t)x3::img_pieces(((long)T * B * n_t + 15) / 16) * 4);
     p.xRaw = take((size_t)T * B * n_t * kRawStride);
@@ -171,6 +173,11 @@ GemmArgs gemm_args(const float *X, int ldx, const float *W, const float *bias, i
   return a;
 }
 
+// the f16 range status word is cleared by a KERNEL node: a hipMemsetAsync captured into a HIP graph was observed (ROCm 7.2, MI355X)
+// to fill the 64 bytes with the kernel arguments of an eager launch enqueued right behind the replay (tools/ws_debug.py: seed and
+// offset of torch's uniform_ kernel appeared in the words after 200 back-to-back refresh + replay pairs)
+__global__ void clear_words_kernel(unsigned *p) { p[threadIdx.x] = 0u; }
+
 struct Ctx {
   const aline_model *m;
   Geo g;
@@ -179,7 +186,10 @@ struct Ctx {
   hipStream_t st;
   float *at(size_t off) const { return ws + off; }
   unsigned *flag() const { return reinterpret_cast<unsigned *>(ws + pl.Flag); }     // f16 range guard (common.h)
-  int clear_flag() const { return hipMemsetAsync(ws + pl.Flag, 0, 64, st) == hipSuccess ? ALINE_OK : ALINE_ELAUNCH; }
+  int clear_flag() const {
+    hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(16), 0, st, flag());
+    return hipGetLastError() == hipSuccess ? ALINE_OK : ALINE_ELAUNCH;
+  }
 };
 
 inline dim3 grid1d(size_t total, int block = 256) { return dim3((unsigned)((total + block - 1) / block)); }
@@ -1150,6 +1160,8 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
   u32x4 *XIN = reinterpret_cast<u32x4 *>(c.at(c.pl.xIn)), *XA = reinterpret_cast<u32x4 *>(c.at(c.pl.xA)), *XB = reinterpret_cast<u32x4 *>(c.at(c.pl.xB));
   u32x4 *KV = reinterpret_cast<u32x4 *>(c.at(c.pl.xKV)), *Zimg = reinterpret_cast<u32x4 *>(c.at(c.pl.xZimg));
   int *keyrow = reinterpret_cast<int *>(c.at(c.pl.xKeys)), *kcnt = reinterpret_cast<int *>(c.at(c.pl.xKcnt));
+  short *keypos = reinterpret_cast<short *>(c.at(c.pl.xKpos));
+  u32x4 *KX = reinterpret_cast<u32x4 *>(c.at(c.pl.xKX));
   float *logits = c.at(c.pl.xLog);
   x3::AsmArgs aa{};
   aa.g = c.g; aa.tpe = tpe; aa.Ex = c.at(c.pl.Ex); aa.Ey = c.at(c.pl.Ey); aa.ey_rows = r->P; aa.theta_tokens = m->theta_tokens; aa.X = XIN; aa.range_flag = c.flag();
@@ -1165,7 +1177,7 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
   const int cus = device_cus();
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
-    hipLaunchKernelGGL(x3::keys_kernel, dim3(r->B), dim3(256), 0, c.st, c.g, keyrow, kcnt);
+    hipLaunchKernelGGL(x3::keys_kernel, dim3(r->B), dim3(256), 0, c.st, c.g, tpe, keyrow, kcnt, keypos, XIN, KX);
     CHECK_LAUNCH();
     const int nkeys = r->n_ctx0 + t + n_t;                      // upper bound of an episode's key count at this step
     const int nkt2 = 2 * ((std::min(nkeys, x3::WNK) + 31) / 32);
@@ -1173,13 +1185,13 @@ static int rollout_x3(const aline_model *m, const aline_rollout *r, void *ws, si
     for (int l = 0; l < m->L; ++l) {
       u32x4 *xout = (l & 1) ? XB : XA;
       x3::KvArgs ka{};
-      ka.g = c.g; ka.tpe = tpe; ka.nkt2 = nkt2; ka.X = xin; ka.img = img + l * lw; ka.F = F; ka.keyrow = keyrow; ka.kcnt = kcnt; ka.KV = KV;
+      ka.g = c.g; ka.tpe = tpe; ka.nkt2 = nkt2; ka.X = KX; ka.img = img + l * lw; ka.F = F; ka.keyrow = keyrow; ka.kcnt = kcnt; ka.KV = KV;
       ka.ngroups = (int)(((long)r->B * nkt2 + x3::WAVES - 1) / x3::WAVES);
       hipLaunchKernelGGL(x3::kv_kernel, dim3((unsigned)std::min(ka.ngroups, cus)), dim3(x3::THREADS), smem_kv, c.st, ka);
       CHECK_LAUNCH();
       x3::LayerArgs la{};
       la.g = c.g; la.tpe = tpe; la.ngroups = (int)((tiles + x3::WAVES - 1) / x3::WAVES);
-      la.XIN = xin; la.XOUT = xout; la.img = img + l * lw; la.F = F; la.KV = KV; la.kcnt = kcnt; la.range_flag = c.flag();
+      la.XIN = xin; la.XOUT = xout; la.img = img + l * lw; la.F = F; la.KV = KV; la.kcnt = kcnt; la.range_flag = c.flag(); la.keypos = keypos; la.KXout = KX;
       const bool last = l == m->L - 1;
       la.zimg = (last && want_gmm) ? Zimg : nullptr; la.zrow0 = (long)t * r->B * n_t;
 #ifdef X3_STAMPS
@@ -1807,7 +1819,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       CHECK_LAUNCH();
     }
     for (int l = 0; l < L && do_enc; ++l) {
-      Ctx fc; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
+      Ctx fc{}; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
       if (ckv) {      // K / V of the key rows: row-gather GEMM on the key list
         GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, KVl(l), 2 * d, I * max_keys, 2 * d, d, false);
         ka.row_index = keyidx;

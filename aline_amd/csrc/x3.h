@@ -246,11 +246,18 @@ __global__ __launch_bounds__(64) void patch_row_kernel(AsmArgs a, int order) {
 }
 
 // ---- key list of every episode (model/encoder.py:83-126): context rows in slot order, then the visible targets --
-__global__ __launch_bounds__(256) void keys_kernel(Geo g, int *__restrict__ keyrow, int *__restrict__ kcnt) {
+// Also, for the K / V kernel: keypos [B][16 tpe] = position of a token row in its episode's key list (-1: not a key) -- the
+// layer kernel files the output rows that are keys into the KEY IMAGE of the next layer with it --, and the key image of
+// layer 0 itself: the key rows of the input image gathered into [B][WNK / 16 key tiles] tiles of the usual piece layout, so
+// that kv_kernel reads whole KBs instead of 64 scattered 16-byte pieces per key row (a row of the token image shares each
+// of its 64-byte lines with three other rows: 4x read amplification; the gather was most of kv_kernel's time in round 2).
+__global__ __launch_bounds__(256) void keys_kernel(Geo g, int tpe, int *__restrict__ keyrow, int *__restrict__ kcnt,
+                                                   short *__restrict__ keypos, const u32x4 *__restrict__ X0, u32x4 *__restrict__ KX) {
   __shared__ int wave_cnt[4];
-  __shared__ int s_base;
+  __shared__ int s_base, s_n;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_base = 0;
+  for (int i = tid; i < 16 * tpe; i += 256) keypos[(long)b * 16 * tpe + i] = -1;
   __syncthreads();
   for (int c0 = 0; c0 < g.P; c0 += 256) {
     const int row = c0 + tid;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256) void keys_kernel(Geo g, int *__restrict__ keyr
     int off = s_base;
     for (int w = 0; w < wave; ++w) off += wave_cnt[w];
     const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
-    if (key && k < WNK) keyrow[b * WNK + k] = row;
+    if (key && k < WNK) { keyrow[b * WNK + k] = row; keypos[(long)b * 16 * tpe + row] = (short)k; }
     __syncthreads();
     if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
@@ -271,8 +278,17 @@ __global__ __launch_bounds__(256) void keys_kernel(Geo g, int *__restrict__ keyr
     kcnt[2 * b] = n;
     const int n_t = g.n_td + g.n_th;
     for (int j = 0; j < n_t; ++j)
-      if ((!g.tmask || g.tmask[j]) && n < WNK) keyrow[b * WNK + n++] = g.P + j;
+      if ((!g.tmask || g.tmask[j]) && n < WNK) { keyrow[b * WNK + n] = g.P + j; keypos[(long)b * 16 * tpe + g.P + j] = (short)n; ++n; }
     kcnt[2 * b + 1] = n;
+    s_n = n;
+  }
+  __syncthreads();
+  // layer 0's key image: key k -> tile b * (WNK / 16) + k / 16, row k % 16; 64 pieces (ks, hi | lo, g) of 16 bytes per key row
+  const int n = s_n;
+  for (int i = tid; i < n * 64; i += 256) {
+    const int k = i >> 6, e = i & 63, ks = e >> 3, hl = (e >> 2) & 1, gq = e & 3;
+    const int row = keyrow[b * WNK + k];
+    KX[xpiece((long)b * (WNK / 16) + (k >> 4), ks, hl, 16 * gq + (k & 15))] = X0[xpiece((long)b * tpe + (row >> 4), ks, hl, 16 * gq + (row & 15))];
   }
 }
 
@@ -441,6 +457,30 @@ __device__ __forceinline__ void chunk_run(St &st, FragRing &r, Body body) {
     else chunk_pipe<false>(st, r, cur, nx, [&](int p, const f16x8 &ah, const f16x8 &al) { body(i, p, ah, al); });
   }
 }
+// The same with hook(i) behind chunk i (global loads that should be in flight while the following chunks compute)
+template <int N, class St, class Body, class Hook>
+__device__ __forceinline__ void chunk_run_hook(St &st, FragRing &r, Body body, Hook hook) {
+  prime(r, st.cur());
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const f16x8 *cur = st.cur(), *nx = st.nxt();
+    st.advance();
+    if (i + 1 < N) chunk_pipe<true>(st, r, cur, nx, [&](int p, const f16x8 &ah, const f16x8 &al) { body(i, p, ah, al); });
+    else chunk_pipe<false>(st, r, cur, nx, [&](int p, const f16x8 &ah, const f16x8 &al) { body(i, p, ah, al); });
+    hook(i);
+  }
+}
+// A wave without a tile in this round: it computes nothing and reads no fragments (its SIMD partner then has the matrix pipe
+// to itself), but keeps its share of the weight stream and the chunk barriers going -- exactly one issue / sync / advance per chunk.
+template <class St>
+__device__ __forceinline__ void idle_chunks(St &st, int nchunks) {
+#pragma unroll 1
+  for (int i = 0; i < nchunks; ++i) {
+    st.advance();
+    st.issue();
+    st.sync();
+  }
+}
 // FFN-shaped run over F/32 groups of 32 hidden units: chunk A = the group's W1 pairs (k-step p >> 1, hidden tile
 // p & 1) -> hidden units in registers; chunk B = the group's W2 pairs -> consume(c, p, A_hi, A_lo) with the hidden
 // fragment pair made by `hidden(c, h0, h1)`.  Fragment prefetch runs across all chunk boundaries of the run.
@@ -501,7 +541,7 @@ __device__ __forceinline__ float layer_norm(f32x4 (&v)[NMT], const float *lw, co
 // ---- K / V of the key rows ----------------------------------------------------------------------------------------
 struct KvArgs {
   Geo g; int tpe, nkt2, ngroups;
-  const u32x4 *X;                 // layer input image
+  const u32x4 *X;                 // KEY IMAGE of this layer: [B][WNK / 16] tiles of the key rows in key-list order (keys_kernel / the previous layer)
   const unsigned *img;            // this layer's weight image
   int F;
   const int *keyrow, *kcnt;
@@ -527,11 +567,10 @@ __global__ __launch_bounds__(THREADS) void kv_kernel(KvArgs a) {
     const bool valid = tile < ntiles;
     const long tl = valid ? tile : ntiles - 1;
     const int b = tl / a.nkt2, kt = tl % a.nkt2, key = 16 * kt + tok;
-    const int row = key < a.kcnt[2 * b + 1] ? a.keyrow[b * WNK + key] : -1;
+    const bool live = key < a.kcnt[2 * b + 1];          // (slots behind the key count hold stale rows: zeroed, the attention masks them)
     f16x8 xh[NKS], xl[NKS];
-    if (row >= 0) {
-      load_tile(a.X, (long)b * a.tpe + (row >> 4), 16 * g + (row & 15), xh, xl);
-    } else {
+    load_tile(a.X, (long)b * (WNK / 16) + kt, lane, xh, xl);
+    if (!live) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) { xh[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; xl[ks] = xh[ks]; }
     }
@@ -581,6 +620,7 @@ struct LayerArgs {
   const u32x4 *KV; const int *kcnt;
   u32x4 *zimg; long zrow0;        // last layer: the rows of the target tokens also go to this (dense-row) image
   unsigned *range_flag;           // f16 range guard (common.h)
+  const short *keypos; u32x4 *KXout;   // not the last layer: output rows that are keys also go to the next layer's key image
 #ifdef X3_STAMPS
   unsigned long long *stamps;     // [8 waves][X3_NSTAMP] of workgroup 0
 #endif
@@ -590,22 +630,54 @@ struct LayerArgs {
 // the exp2 domain (scale folded into Wq), softmax over the keys of a token (4 NKT values per lane x 4 lane groups),
 // O^T = V^T P.  qh / ql [h] go in as the Q^T fragment pair of head h and come out as the pair of the normalised head
 // output (= k-step h of the out-projection).
+// The K / V fragment pairs of one head come from L2 (KV buffer of the episode, 2 NKT + 4 NS pieces of 16 bytes per lane): the
+// pairs of head h + 1 are requested before head h is computed (a dependent L2 round trip per head was 11 % of the kernel:
+// profiles/r02_x3_layer_kernel_stamps.txt), those of head 0 by the caller before the Q projection's epilogue.
 template <int NKT>
-__device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], const u32x4 *kv, int nv) {
+struct HeadKV {
+  static constexpr int NS = NKT > 2 ? 2 : 1;
+  u32x4 k[2 * NKT], v[4 * NS];          // K pairs (kt: hi, lo); V^T pairs ((i, si): hi, lo), i = 2 h, 2 h + 1
+  __device__ __forceinline__ void load(const u32x4 *kv, int h) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) { k[2 * kt] = kv[((h * 4 + kt) * 2) * 64]; k[2 * kt + 1] = kv[((h * 4 + kt) * 2 + 1) * 64]; }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int si = 0; si < NS; ++si) {
+        const u32x4 *vp = kv + KV_VOFF + (((2 * h + ii) * 2 + si) * 2) * 64;
+        v[(ii * NS + si) * 2] = vp[0]; v[(ii * NS + si) * 2 + 1] = vp[64];
+      }
+  }
+};
+template <int NKT>
+__device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], const u32x4 *kv, int nv, HeadKV<NKT> &first) {
   constexpr int NS = NKT > 2 ? 2 : 1;
   f32x4 mb[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) mb[kt][r] = (16 * kt + r) < nv ? 0.f : -INFINITY;
+#ifdef X3_KV_DEPTH2       // (experiment: two heads ahead; NKT <= 2 only -- 3 x 64 registers at four key tiles do not fit)
+  constexpr int NB = NKT <= 2 ? 3 : 2;
+#else
+  constexpr int NB = 2;
+#endif
+  HeadKV<NKT> buf[NB];
+  buf[0] = first;
+  if (NB == 3) buf[1].load(kv, 1);
 #pragma unroll
   for (int h = 0; h < H; ++h) {
+    HeadKV<NKT> &c = buf[h % NB];
+#ifndef X3_NO_KV_PREFETCH
+    if (h + NB - 1 < H) buf[(h + NB - 1) % NB].load(kv, h + NB - 1);
+#else
+    if (h > 0) c.load(kv, h);
+#endif
     f32x4 s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const f16x8 kh = __builtin_bit_cast(f16x8, kv[((h * 4 + kt) * 2) * 64]), kl = __builtin_bit_cast(f16x8, kv[((h * 4 + kt) * 2 + 1) * 64]);
       s[kt] = mb[kt];
-      mfma3(s[kt], kh, kl, qh[h], ql[h]);
+      mfma3(s[kt], __builtin_bit_cast(f16x8, c.k[2 * kt]), __builtin_bit_cast(f16x8, c.k[2 * kt + 1]), qh[h], ql[h]);
     }
     float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
@@ -626,9 +698,8 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], c
     for (int si = 0; si < NS; ++si) {
       f16x8 ph, pl;
       split_frag(s[2 * si], (2 * si + 1 < NKT) ? s[(2 * si + 1 < NKT) ? 2 * si + 1 : 0] : z4, ph, pl);
-      const u32x4 *v0 = kv + KV_VOFF + (((2 * h) * 2 + si) * 2) * 64, *v1 = kv + KV_VOFF + (((2 * h + 1) * 2 + si) * 2) * 64;
-      mfma3(o0, __builtin_bit_cast(f16x8, v0[0]), __builtin_bit_cast(f16x8, v0[64]), ph, pl);
-      mfma3(o1, __builtin_bit_cast(f16x8, v1[0]), __builtin_bit_cast(f16x8, v1[64]), ph, pl);
+      mfma3(o0, __builtin_bit_cast(f16x8, c.v[si * 2]), __builtin_bit_cast(f16x8, c.v[si * 2 + 1]), ph, pl);
+      mfma3(o1, __builtin_bit_cast(f16x8, c.v[(NS + si) * 2]), __builtin_bit_cast(f16x8, c.v[(NS + si) * 2 + 1]), ph, pl);
     }
     split_frag(o0 * inv, o1 * inv, qh[h], ql[h]);
   }
@@ -659,21 +730,45 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
   st.stamps.start();
 #endif
   st.sync();
+#ifdef X3_SETPRIO      // (experiment: static priority for the second-dispatched half, MI355X_MICROARCH.md 'two waves per SIMD' item 4)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   FragRing ring;
   float range_chk = 0.f;
+  // Tile rounds.  Full rounds: workgroup b takes the 8 consecutive tiles of group rd * G + b, one per wave (two waves per
+  // SIMD).  What is left after the full rounds (712 of 13 000 tiles at the headline shape: 0.35 of a round) is spread over ALL
+  // workgroups, `ktail` waves each -- waves 0 .. ktail - 1 sit on different SIMDs while ktail <= 4, so a tail tile has the
+  // matrix pipe of its SIMD to itself instead of sharing it in a few fully occupied workgroups while the other CUs idle.
   const long ntiles = (long)G.B * a.tpe;
-  for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
-    const long tile = (long)grp * WAVES + wave;
-    const bool valid = tile < ntiles;
-    const long tl = valid ? tile : ntiles - 1;
-    const int b = tl / a.tpe, j = tl % a.tpe;
-    const int r = 16 * j + tok, rc = min(r, G.N - 1);
-    const bool rowok = valid && r < G.N;
-    const int lidx = 16 * g + (rc & 15);
-    f16x8 xh[NKS], xl[NKS];
-    load_tile(a.XIN, tl, lidx, xh, xl);
+  const int NG = gridDim.x;
+  const long per_round = (long)NG * WAVES;
+  const int full = (int)(ntiles / per_round);
+  const long rem = ntiles - (long)full * per_round;
+  const int ktail = (int)((rem + NG - 1) / NG), rounds = full + (rem > 0 ? 1 : 0);
+  const bool wg_tail = rem > 0 && (long)blockIdx.x * ktail < rem;              // (workgroup-uniform) a tail round for this workgroup
+  const long tail_tile = (long)full * per_round + (long)blockIdx.x * ktail + wave;
+  const bool my_tail = wg_tail && wave < ktail && tail_tile < ntiles;
+  const int my_rounds = full + (my_tail ? 1 : 0);                              // rounds in which this wave computes a tile
+  auto tile_of = [&](int rd) -> long {                                         // (rd < my_rounds)
+    return rd < full ? ((long)rd * NG + blockIdx.x) * WAVES + wave : tail_tile;
+  };
+  auto rows_of = [&](long tile, int &b, int &r, int &lidx) {
+    b = (int)(tile / a.tpe);
+    r = 16 * (int)(tile % a.tpe) + tok;
+    lidx = 16 * g + (min(r, G.N - 1) & 15);
+  };
+  f16x8 xh[NKS], xl[NKS];
+  if (my_rounds > 0) { int b0, r0, l0; rows_of(tile_of(0), b0, r0, l0); load_tile(a.XIN, tile_of(0), l0, xh, xl); }
+  for (int rd = 0; rd < my_rounds; ++rd) {
+    const long tl = tile_of(rd);
+    int b, r, lidx;
+    rows_of(tl, b, r, lidx);
+    const int rc = min(r, G.N - 1);
+    const bool rowok = r < G.N;
     const int n_ck = a.kcnt[2 * b], n_ak = a.kcnt[2 * b + 1];
     const bool isq = rc < G.P && !is_ctx(G, b, rc);
+    const u32x4 *kv = a.KV + (long)b * KV_EP + lane;
+    const int nkt = __builtin_amdgcn_readfirstlane((n_ak + 15) >> 4);     // (uniform per wave: one episode per tile)
     X3_LAP(st, 7);
 
     f32x4 y[NMT];
@@ -681,28 +776,38 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     chunk_run<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, xh[cc], xl[cc]); });
-    f16x8 qh[H], ql[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 16 + 4 * g);
-      split_frag(y[2 * h] * WINV + c0, y[2 * h + 1] * WINV + c1, qh[h], ql[h]);
-    }
     // ---- attention: context and target rows see the context keys, query rows also the visible targets -------------
-    {
-      const u32x4 *kv = a.KV + (long)b * KV_EP + lane;
-      const int nv = (isq ? n_ak : n_ck) - 4 * g;          // key 16 kt + 4 g + r is visible iff 16 kt + r < nv
-      const int nkt = __builtin_amdgcn_readfirstlane((n_ak + 15) >> 4);     // (uniform per wave: one episode per tile)
+    f16x8 qh[H], ql[H];
+    auto q_epilogue = [&]() {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 16 + 4 * g);
+        split_frag(y[2 * h] * WINV + c0, y[2 * h + 1] * WINV + c1, qh[h], ql[h]);
+      }
       X3_LAP(st, 5);
-      if (nkt <= 1) attention_tile<1>(qh, ql, kv, nv);
-      else if (nkt == 2) attention_tile<2>(qh, ql, kv, nv);
-      else attention_tile<4>(qh, ql, kv, nv);
+    };
+    {
+      const int nv = (isq ? n_ak : n_ck) - 4 * g;          // key 16 kt + 4 g + r is visible iff 16 kt + r < nv
+      // (head 0's K / V pairs are requested before the epilogue of the Q projection and land while it runs)
+      if (nkt <= 1) { HeadKV<1> k0; k0.load(kv, 0); q_epilogue(); attention_tile<1>(qh, ql, kv, nv, k0); }
+      else if (nkt == 2) { HeadKV<2> k0; k0.load(kv, 0); q_epilogue(); attention_tile<2>(qh, ql, kv, nv, k0); }
+      else { HeadKV<4> k0; k0.load(kv, 0); q_epilogue(); attention_tile<4>(qh, ql, kv, nv, k0); }
       X3_LAP(st, 6);
     }
-    // ---- X1 = LN1(X + bo + Wo A) -------------------------------------------------------------------------------------
+    // ---- X1 = LN1(X + bo + Wo A): the residual X comes back from L2 a k-step per chunk, into the registers the consumed
+    // fragments of the attention output free (it was not kept through the attention: registers) -------------------------
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef X3_NO_RESID_HOOK
+    chunk_run_hook<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, qh[cc], ql[cc]); },
+                        [&](int cc) {
+                          xh[cc] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tl, cc, 0, lidx)]);
+                          xl[cc] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tl, cc, 1, lidx)]);
+                        });
+#else
     chunk_run<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, qh[cc], ql[cc]); });
-    load_tile(a.XIN, tl, lidx, xh, xl);      // the residual (not kept through the out-projection: registers)
+    load_tile(a.XIN, tl, lidx, xh, xl);
+#endif
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(bo + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
@@ -726,12 +831,27 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
               },
               [&](int, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, hbh, hbl); });
     }
+    // The next round's tile.  Requesting ALL of it here (behind LN2 + the stores) was measured 2 % SLOWER than loading it at the
+    // top of the round (64 more live registers through LN2: X3_NEXT_PREFETCH); the Q projection consumes a k-step per chunk, so at
+    // the top only the first k-step's latency is exposed -- X3_NEXT_KS0 requests just that one here.
+    // (unconditional: after the last round the same tile is read once more, from L2, and dropped)
+    f16x8 nxh[NKS], nxl[NKS];
+    const long tn = tile_of(rd + 1 < my_rounds ? rd + 1 : rd);
+    int bn, rn, ln;
+    rows_of(tn, bn, rn, ln);
+#if defined(X3_NEXT_PREFETCH)
+    load_tile(a.XIN, tn, ln, nxh, nxl);
+#elif defined(X3_NEXT_KS0)
+    nxh[0] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, 0, 0, ln)]);
+    nxl[0] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, 0, 1, ln)]);
+#endif
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(b2 + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
     range_chk += layer_norm(y, ln2w, ln2b, g);
     const bool ztgt = LAST && a.zimg && rowok && r >= G.P;
     const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
+    const int kp = (!LAST && rowok) ? a.keypos[(long)b * 16 * a.tpe + r] : -1;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       f16x8 oh, ol;
@@ -744,9 +864,27 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
         a.zimg[xpiece(zr >> 4, ks, 0, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, oh);
         a.zimg[xpiece(zr >> 4, ks, 1, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, ol);
       }
+      if (!LAST && kp >= 0) {
+        a.KXout[xpiece((long)b * (WNK / 16) + (kp >> 4), ks, 0, 16 * g + (kp & 15))] = __builtin_bit_cast(u32x4, oh);
+        a.KXout[xpiece((long)b * (WNK / 16) + (kp >> 4), ks, 1, 16 * g + (kp & 15))] = __builtin_bit_cast(u32x4, ol);
+      }
     }
+#if defined(X3_NEXT_PREFETCH)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { xh[ks] = nxh[ks]; xl[ks] = nxl[ks]; }
+#elif defined(X3_NEXT_KS0)
+    xh[0] = nxh[0]; xl[0] = nxl[0];
+#pragma unroll
+    for (int ks = 1; ks < NKS; ++ks) {
+      xh[ks] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, ks, 0, ln)]);
+      xl[ks] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, ks, 1, ln)]);
+    }
+#else
+    load_tile(a.XIN, tn, ln, xh, xl);
+#endif
     X3_LAP(st, 7);
   }
+  if (wg_tail && !my_tail) idle_chunks(st, seq);       // the tail round of a wave without a tile: stream + barriers only
   st.finish();
   range_check_nan(a.range_flag, range_chk);
 #ifdef X3_STAMPS

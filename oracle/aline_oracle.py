@@ -35,15 +35,31 @@ def _lin(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     return y if b is None else y + b
 
 
-# Test probe: when set to a list, every ReLU appends (key prefix of its first Linear, pre-activation tensor).  The backward
-# parity test uses it to find the hidden units whose pre-activation sits on the ReLU's knife edge (|h| < 1e-6), where two
-# correct fp32 forwards may take different sides.
+# Test probes of the ReLUs (tests/test_backward_gpu.py).  Two correct fp32 forwards may take different sides of a ReLU whose
+# pre-activation is within rounding of zero, and ONE flipped gate changes every gradient upstream of it (the row's whole
+# contribution through that unit).  RELU_PROBE (a list): every ReLU appends (call index, key prefix of its Linear,
+# pre-activation).  RELU_FLIP ({call index: bool mask}): the gates under the mask are inverted (forward h * gate, so the value
+# stays continuous) -- the test differentiates the oracle under the flips of the knife-edge gates to span what a correct
+# kernel may return.  reset_relu_calls() restarts the call numbering before a rollout.
 RELU_PROBE: Optional[list] = None
+RELU_FLIP: Optional[dict] = None
+_relu_calls = 0
+
+
+def reset_relu_calls() -> None:
+    global _relu_calls
+    _relu_calls = 0
 
 
 def _relu(h: Tensor, tag: str) -> Tensor:
+    global _relu_calls
+    i = _relu_calls
+    _relu_calls += 1
     if RELU_PROBE is not None:
-        RELU_PROBE.append((tag, h.detach()))
+        RELU_PROBE.append((i, tag, h.detach()))
+    if RELU_FLIP is not None and i in RELU_FLIP:
+        gate = (h.detach() > 0) ^ RELU_FLIP[i]
+        return h * gate.to(h.dtype)
     return torch.relu(h)
 
 
