@@ -1534,7 +1534,7 @@ static int bwd_prec() {
 namespace {
 
 struct BwdPlan {
-  size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt, KeyIdx, Kcnt,
+  size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt, KeyIdx, Kcnt, Tvec,
       total;
 };
 
@@ -1544,7 +1544,7 @@ struct BwdPlan {
 static bool bwd_fused_tail(const aline_model &m) { return m.d == tailbwd::D && m.F == tailbwd::F && !dbg(ALINE_DBG_NO_BWD_TAIL); }
 
 // Acquisition head backward without the [I P, F] hidden activations (acq_head_bwd.h).  ALINE_BWD_ACQ=0: the per-op kernels.
-static bool fused_acq_head(const aline_model &m) { return m.d == acqb::D && m.F == acqb::F && !dbg(ALINE_DBG_NO_BWD_ACQ); }
+static bool fused_acq_head(const aline_model &m) { return m.d == acqb::D && m.F == acqb::F && !m.time_token && !dbg(ALINE_DBG_NO_BWD_ACQ); }
 
 static bool fused_gmm_heads(const aline_model &m) { return m.d == gmmb::D && m.F == gmmb::F && m.C <= 16 && !dbg(ALINE_DBG_NO_BWD_GMM_FUSED); }
 
@@ -1568,6 +1568,7 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   p.Hid = take(ft ? 0 : L * M * F);
   p.U2 = take(ft ? 0 : L * M * d);
   p.HidA = take(fused_acq_head(m) ? 0 : I * P * F);
+  p.Tvec = take(I);
   // (fused GMM kernels: raw / draw [rows, C, 4] each + dz per component [C, rows, 32] instead of the hidden units [rows, C F])
   p.HidG = take(I * n_t * m.C * (fused_gmm_heads(m) ? 40 : F));
   p.dXa = take(M * d);
@@ -1597,8 +1598,8 @@ struct BCtx {
   float *at(size_t off) const { return ws + off; }
 };
 
-int transpose_to(const BCtx &c, const float *W, int rows, int cols, float *dst) {
-  hipLaunchKernelGGL(transpose_kernel, grid1d((size_t)rows * cols), dim3(256), 0, c.st, W, rows, cols, cols, dst);
+int transpose_to(const BCtx &c, const float *W, int rows, int cols, float *dst, int ld = 0) {
+  hipLaunchKernelGGL(transpose_kernel, grid1d((size_t)rows * cols), dim3(256), 0, c.st, W, rows, cols, ld > 0 ? ld : cols, dst);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -1618,12 +1619,12 @@ int gemm_dx(const BCtx &c, const float *dY, int ldy, const float *W, int N, int 
 
 // dW[N, K] += dY^T X, db[N] += colsum(dY)
 int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, long M,
-            int N, int K, int Ry = 1, int Gy = 1, int offy = 0, int Rx = 1, int Gx = 1, int offx = 0) {
+            int N, int K, int Ry = 1, int Gy = 1, int offy = 0, int Rx = 1, int Gx = 1, int offx = 0, int ldw = 0) {
   if (N % 32 || K % 32) return ALINE_EUNSUPPORTED;
   GemmTnArgs a{};
   a.dY = dY; a.ldy = ldy; a.Ry = Ry; a.Gy = Gy; a.offy = offy;
   a.X = X; a.ldx = ldx; a.Rx = Rx; a.Gx = Gx; a.offx = offx;
-  a.dW = dW; a.ldw = K; a.db = db; a.M = M; a.N = N; a.K = K;
+  a.dW = dW; a.ldw = ldw > 0 ? ldw : K; a.db = db; a.M = M; a.N = N; a.K = K;
   a.mchunk = 4096;
   // short products (the GMM heads see n_t target rows per instance: 60 000 rows at the headline shape) would run on M / 4096
   // = 15 workgroups (0.21 ms each, ten of them per step): shrink the chunk until ~512 workgroups exist
@@ -1743,7 +1744,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
   if (do_head && (!g_logp || (!g_ll && !g_pm && !g_ps && !g_pw))) return ALINE_EINVAL;
   TRY(validate_model(*m, io.stages));
   // (the forward activations are recomputed here in exact fp32 whichever reference-precision mode rolled the episodes out)
-  if ((m->precision != ALINE_PREC_F32 && m->precision != ALINE_PREC_F16X3) || m->time_token) return ALINE_EUNSUPPORTED;
+  if (m->precision != ALINE_PREC_F32 && m->precision != ALINE_PREC_F16X3) return ALINE_EUNSUPPORTED;
   if (!r->role || (do_head && (!r->slot || !r->target_all)) || (do_emb && (!r->point_x || !r->point_y))) return ALINE_EINVAL;
   if (io.stages != ST_ALL && r->T != 1) return ALINE_EINVAL;
   if ((do_enc && !do_emb && !io.x_in) || (do_head && !do_enc && !io.z_in) || (!do_head && !io.d_in) ||
@@ -1872,13 +1873,21 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     }
     const float *Z = do_enc ? Xs(L) : io.z_in;
     float *HidA = c.at(c.pl.HidA), *HidG = c.at(c.pl.HidG);
+    float *tvec = c.at(c.pl.Tvec);                               // time token: t of every instance of this chunk
     const bool facq = do_head && fused_acq_head(*m);
     // GMM heads without the [rows, C F] hidden activations (acq_head_bwd.h, gmmb).  ALINE_BWD_GMM_FUSED=0: the per-op kernels.
     const bool fgmm = do_head && n_t > 0 && fused_gmm_heads(*m);
     if (do_head) {
       if (!facq) {
-      GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, d, HidA, F, I * P, F, d, true);
+      const int ldw1 = m->time_token ? d + 1 : d;                // head.py:24-25: [F, d + 1] with a time token
+      GemmArgs a = gemm_args(Z, d, m->acq_w1, m->acq_b1, ldw1, HidA, F, I * P, F, d, true);
       a.R_in = P; a.G_in = N; a.off_in = 0;
+      if (m->time_token) {     // + t(instance) * W1[:, d]  (model/head.py:342-345; t / T per step: train_aline.py:80-82)
+        const int TT = r->time_token_T > 0 ? r->time_token_T : r->time_token_T < 0 ? -r->time_token_T : r->T;
+        hipLaunchKernelGGL(time_vec_kernel, grid1d((size_t)I), dim3(256), 0, c.st, tvec, I, B, tA, TT, r->time_token_T < 0 ? 1 : 0);
+        CHECK_LAUNCH();
+        a.tvec = tvec; a.tvec_div = P; a.tcol = m->acq_w1 + d; a.tcol_stride = d + 1;
+      }
       TRY(launch_gemm(bwd_prec(), a, 1, c.st));
       }
       if (!fgmm) {
@@ -1915,10 +1924,17 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       a.T = r->T; a.dw2 = gr->acq_w2; a.db2 = gr->acq_b2;
       hipLaunchKernelGGL(acq_bwd_kernel, dim3(I), dim3(256), (size_t)(P + F) * sizeof(float), c.st, a);
       CHECK_LAUNCH();
-      TRY(gemm_dw(c, HidA, F, Z, d, gr->acq_w1, gr->acq_b1, (long)I * P, F, d, 1, 1, 0, P, N, 0));
-      // dZ[point rows] = dHidA . W1a
+      const int ldw1 = m->time_token ? d + 1 : d;
+      TRY(gemm_dw(c, HidA, F, Z, d, gr->acq_w1, gr->acq_b1, (long)I * P, F, d, 1, 1, 0, P, N, 0, ldw1));
+      if (m->time_token) {     // the time column: dW1[f, d] += sum_rows dHidA[row, f] t(row)
+        const long rows = (long)I * P, rpb = 512;
+        hipLaunchKernelGGL(time_col_grad_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, c.st, HidA, F, rows, P, tvec,
+                           gr->acq_w1, d + 1, d, rpb);
+        CHECK_LAUNCH();
+      }
+      // dZ[point rows] = dHidA . W1a  (the first d columns of W1)
       float *Wt = c.at(c.pl.Wt);
-      TRY(transpose_to(c, m->acq_w1, F, d, Wt));
+      TRY(transpose_to(c, m->acq_w1, F, d, Wt, ldw1));
       GemmArgs ga = gemm_args(HidA, F, Wt, nullptr, F, dX, d, I * P, d, F, false);
       ga.R_out = P; ga.G_out = N; ga.off_out = 0;
       TRY(launch_gemm(bwd_prec(), ga, 1, c.st));

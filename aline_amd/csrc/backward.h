@@ -203,6 +203,26 @@ __global__ void add_inplace_kernel(float *__restrict__ a, const float *__restric
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] += b[i];
 }
+// time token (model/head.py:342-345): the acquisition MLP sees [z | t]; t of instance i (= step t0 + i / B of the rollout) is
+// step / T, or (T - step) / T for the evaluation schedule (utils/eval.py:24)
+__global__ void time_vec_kernel(float *__restrict__ tv, int I, int B, int t0, int TT, int reverse) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I) return;
+  const int step = t0 + i / B;
+  tv[i] = reverse ? (float)(TT - step) / (float)TT : (float)step / (float)TT;
+}
+// gradient of the time column of the acquisition head's first layer: dW1[f, d] += sum_rows dHid[row, f] * t(row / rows_per_inst)
+__global__ __launch_bounds__(256) void time_col_grad_kernel(const float *__restrict__ dHid, int F, long rows, int rows_per_inst,
+                                                            const float *__restrict__ tv, float *__restrict__ dW1, int ldw, int col,
+                                                            long rows_per_block) {
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc = fmaf(dHid[r * F + f], tv[r / rows_per_inst], acc);
+    atomicAdd(dW1 + (long)f * ldw + col, acc);
+  }
+}
+
 __global__ void transpose_kernel(const float *__restrict__ src, int rows, int cols, int ld, float *__restrict__ dst) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // dst [cols, rows]
   if (i >= (long)rows * cols) return;

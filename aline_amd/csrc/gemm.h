@@ -26,7 +26,8 @@ struct GemmArgs {
   const float *W[GEMM_MAX_GROUPS]; const float *bias[GEMM_MAX_GROUPS]; int ldw;
   float *Y; int ldy; int R_out, G_out, off_out; int col_per_group;
   int M, N, K; int relu; int accum;   // accum: Y += result
-  const float *tscalar; const float *tcol; int tcol_stride;  // optional rank-1 term (time token)
+  const float *tscalar; const float *tcol; int tcol_stride;  // optional rank-1 term (time token): + t * tcol[n * tcol_stride]
+  const float *tvec; int tvec_div;                           // ... with a per-row t = tvec[m / tvec_div] instead of the scalar (backward: instances of several steps)
   const float *mask; int ldmask;   // optional ReLU gate of a backward product: Y[m, n] = 0 where mask[m, n] <= 0
   // optional fused second layer of a two-layer head: instead of storing Y, reduce it against red_w[grp] [red_nout, N]
   //   red_out[row * red_stride + grp * red_nout + j] (+)= sum_n Y[row, n] * red_w[grp][j, n]  (+ red_b[grp][j] once)
@@ -308,9 +309,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
           const int n = n0 + 16 * seg + 4 * i;
           float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 16 * seg + 4 * i);
           if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
-          if (a.tscalar) {
-            v.x += tsc * a.tcol[(long)n * a.tcol_stride]; v.y += tsc * a.tcol[(long)(n + 1) * a.tcol_stride];
-            v.z += tsc * a.tcol[(long)(n + 2) * a.tcol_stride]; v.w += tsc * a.tcol[(long)(n + 3) * a.tcol_stride];
+          if (a.tscalar || a.tvec) {
+            const float tr = a.tvec ? a.tvec[m / a.tvec_div] : tsc;
+            v.x += tr * a.tcol[(long)n * a.tcol_stride]; v.y += tr * a.tcol[(long)(n + 1) * a.tcol_stride];
+            v.z += tr * a.tcol[(long)(n + 2) * a.tcol_stride]; v.w += tr * a.tcol[(long)(n + 3) * a.tcol_stride];
           }
           if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
 #pragma unroll
@@ -339,9 +341,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
       if (m >= a.M) continue;
       float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * c4);
       if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
-      if (a.tscalar) {
-        v.x += tsc * a.tcol[(long)n * a.tcol_stride]; v.y += tsc * a.tcol[(long)(n + 1) * a.tcol_stride];
-        v.z += tsc * a.tcol[(long)(n + 2) * a.tcol_stride]; v.w += tsc * a.tcol[(long)(n + 3) * a.tcol_stride];
+      if (a.tscalar || a.tvec) {
+        const float tr = a.tvec ? a.tvec[m / a.tvec_div] : tsc;
+        v.x += tr * a.tcol[(long)n * a.tcol_stride]; v.y += tr * a.tcol[(long)(n + 1) * a.tcol_stride];
+        v.z += tr * a.tcol[(long)(n + 2) * a.tcol_stride]; v.w += tr * a.tcol[(long)(n + 3) * a.tcol_stride];
       }
       if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (a.mask) {

@@ -340,26 +340,6 @@ __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, cons
   }
 }
 
-// ordered compaction of `n` candidates into list[base ..] by a 256-thread group (4 waves) of the workgroup; every
-// thread of the WORKGROUP must call it (barriers).  cnt[0..3]: wave counts of this group, *run: running total.
-template <class Pred, class Val>
-__device__ __forceinline__ void compact_half(int n, int htid, int hwave, int lane, int *cnt, int *run, int *list, int cap, Pred pred, Val val) {
-  for (int c0 = 0; c0 < n; c0 += 256) {
-    const int i = c0 + htid;
-    const bool on = i < n && pred(i);
-    const unsigned long long bal = __ballot(on);
-    if (lane == 0) cnt[hwave] = __popcll(bal);
-    __syncthreads();
-    int off = *run;
-    for (int w = 0; w < hwave; ++w) off += cnt[w];
-    const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
-    if (on && k < cap) list[k] = val(i);
-    __syncthreads();
-    if (htid == 0) *run = min(*run + cnt[0] + cnt[1] + cnt[2] + cnt[3], cap);
-    __syncthreads();
-  }
-}
-
 // In-kernel phase stamps (S3_STAMPS diagnostic build only, tools/s3_stamps.py): s_memtime deltas accumulated per wave.
 //   0 prologue (DMA issue, patched row, key lists, first barrier)   1 K / V tiles   2 barrier behind K / V
 //   3 tile load + Q projection   4 attention   5 out-projection .. LN2, stores, logits   6 barrier behind the tiles
@@ -422,16 +402,37 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   for (int piece = wave; piece < (lbytes >> 10); piece += NW) glds16(gimg + piece * 1024 + lane * 16, wl + piece * 1024);
   for (int piece = wave; piece < (head_bytes(F) >> 10); piece += NW) glds16(gimg + (long)a.L * lbytes + piece * 1024 + lane * 16, whd + piece * 1024);
   if (tid == 0) { queue[0] = 0; queue[1] = 0; }
-  // per episode: the patched row, then the key list (context rows in slot order, then the visible targets)
-  for (int e0 = 0; e0 < epw; e0 += NGRP) {
-    const int e = e0 + grp;
+  // per episode, by ONE WAVE (ballot compaction: no workgroup barriers; the 256-thread version with three barriers per 256 slots
+  // and a second pass for the episodes beyond NW / 4 was 7 % of the step at the headline shape): the patched row, then the key
+  // list (context rows in slot order, then the visible targets)
+  for (int e = wave; e < epw; e += NW) {
     const int b_e = blockIdx.x * epw + e;
-    const bool ep_ok = e < epw && b_e < G.B;
+    const bool ep_ok = b_e < G.B;
     const int bh = min(b_e, G.B - 1);
-    if (a.order > 0 && hwave == 0 && ep_ok) {      // the point chosen at the previous step enters the context
-      int slot = -1;
-      for (int p = lane; p < G.P; p += 64)
-        if (G.role[(long)bh * G.P + p] == a.order) slot = p;
+    int *list = keyrow + e * nkcap;
+    int n = 0, slot = -1;
+    for (int c0 = 0; c0 < G.P; c0 += 64) {
+      const int p = c0 + lane;
+      const int rl = (ep_ok && p < G.P) ? (G.role ? G.role[(long)bh * G.P + p] : (p < G.n_ctx ? 1 : 0)) : 0;
+      if (a.order > 0 && rl == a.order) slot = p;
+      const bool key = rl > 0;
+      const unsigned long long bal = __ballot(key);
+      const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+      if (key && k < nkcap) list[k] = p;
+      n += __popcll(bal);
+    }
+    n = min(n, nkcap);
+    if (lane == 0) n_ck[e] = n;
+    for (int c0 = 0; c0 < n_t; c0 += 64) {
+      const int j = c0 + lane;
+      const bool key = ep_ok && j < n_t && (!G.tmask || G.tmask[j]);
+      const unsigned long long bal = __ballot(key);
+      const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+      if (key && k < nkcap) list[k] = G.P + j;
+      n += __popcll(bal);
+    }
+    if (lane == 0) n_ak[e] = min(n, nkcap);
+    if (a.order > 0 && ep_ok) {      // the point chosen at the previous step enters the context: its X0 row becomes Ex + Ey
       slot = __reduce_max_sync(~0ull, slot);
       if (slot >= 0 && lane < 4) {
         f32x4 lo, hi;
@@ -440,15 +441,6 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         store_split8(a.X0, (long)bh * tpe + (slot >> 4), lane * 16 + (slot & 15), lo, hi);
       }
     }
-    int *list = keyrow + min(e, epw - 1) * nkcap;
-    if (htid == 0) run[grp] = 0;
-    __syncthreads();
-    compact_half(G.P, htid, hwave, lane, wcnt + 4 * grp, run + grp, list, nkcap,
-                 [&](int p) { return ep_ok && is_ctx(G, bh, p); }, [](int p) { return p; });
-    if (htid == 0 && e < epw) n_ck[e] = run[grp];
-    compact_half(n_t, htid, hwave, lane, wcnt + 4 * grp, run + grp, list, nkcap,
-                 [&](int j) { return ep_ok && (!G.tmask || G.tmask[j]); }, [&](int j) { return G.P + j; });
-    if (htid == 0 && e < epw) n_ak[e] = run[grp];
   }
   wait_vmcnt<0>();
   __syncthreads();
@@ -462,13 +454,16 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
     const float *bq = prm, *bk = prm + D, *bv = prm + 2 * D, *bo = prm + 3 * D, *b1 = prm + 4 * D, *b2 = b1 + F;
     const float *ln1w = b2 + D, *ln1b = ln1w + D, *ln2w = ln1b + D, *ln2b = ln2w + D;
     // ---- K / V of the key rows -> LDS ---------------------------------------------------------------------------
+    // jobs: (episode, key tile, K | V) -- K and V of a key tile as separate jobs: twice as many, half as long (at the headline
+    // shape 16 jobs for the 12 waves instead of 8: the phase in front of the barrier is latency-bound)
     const int nk2 = a.nk2;
     for (;;) {
       int job = 0;
       if (lane == 0) job = atomicAdd(queue, 1);
       job = __builtin_amdgcn_readfirstlane(job);
-      if (job >= epw * nk2) break;
-      int e = 0, kt = job;
+      if (job >= 2 * epw * nk2) break;
+      const int want_v = job & 1;
+      int e = 0, kt = job >> 1;
       while (kt >= nk2) { kt -= nk2; ++e; }
       const int b = min(blockIdx.x * epw + e, G.B - 1);
       const int key = 16 * kt + tok;
@@ -481,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       }
       char *kv = lds + KV_OFF + e * kv_ep + lane * 16;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      {   // K^T = Wk KX^T: rows = channels, columns = keys -> the A fragment pair of key tile kt
+      if (!want_v) {   // K^T = Wk KX^T: rows = channels, columns = keys -> the A fragment pair of key tile kt
         f32x4 y0 = z4, y1 = z4;
         const Frag w0 = lds_pair(wl, 2, lane), w1 = lds_pair(wl, 3, lane);
         mfma3(y0, w0.hi, w0.lo, xh, xl);
@@ -490,21 +485,22 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         split_frag(y0 * WINV + ld4(bk + 4 * g), y1 * WINV + ld4(bk + 16 + 4 * g), fh, fl);
         *reinterpret_cast<f16x8 *>(kv + kt * PAIR_BYTES) = fh;
         *reinterpret_cast<f16x8 *>(kv + kt * PAIR_BYTES + 1024) = fl;
-      }
-      // V = KX Wv^T with the operands swapped (rows = keys, columns = channels): accumulator i holds
-      // V[key 16 kt + 4 g + r][channel 16 i + tok] = half (kt & 1) of this lane's piece of the V^T pair (i, kt / 2)
+      } else {
+        // V = KX Wv^T with the operands swapped (rows = keys, columns = channels): accumulator i holds
+        // V[key 16 kt + 4 g + r][channel 16 i + tok] = half (kt & 1) of this lane's piece of the V^T pair (i, kt / 2)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f32x4 v = z4;
-        const Frag w = lds_pair(wl, 4 + i, lane);
-        mfma3(v, xh, xl, w.hi, w.lo);
-        const float bvv = bv[16 * i + tok];
-        unsigned h0, l0, h1, l1;
-        split2(v[0] * WINV + bvv, v[1] * WINV + bvv, h0, l0);
-        split2(v[2] * WINV + bvv, v[3] * WINV + bvv, h1, l1);
-        char *vp = kv + kv_v + (i * nkp + (kt >> 1)) * PAIR_BYTES + 8 * (kt & 1);
-        *reinterpret_cast<u32x2 *>(vp) = (u32x2){h0, h1};
-        *reinterpret_cast<u32x2 *>(vp + 1024) = (u32x2){l0, l1};
+        for (int i = 0; i < 2; ++i) {
+          f32x4 v = z4;
+          const Frag w = lds_pair(wl, 4 + i, lane);
+          mfma3(v, xh, xl, w.hi, w.lo);
+          const float bvv = bv[16 * i + tok];
+          unsigned h0, l0, h1, l1;
+          split2(v[0] * WINV + bvv, v[1] * WINV + bvv, h0, l0);
+          split2(v[2] * WINV + bvv, v[3] * WINV + bvv, h1, l1);
+          char *vp = kv + kv_v + (i * nkp + (kt >> 1)) * PAIR_BYTES + 8 * (kt & 1);
+          *reinterpret_cast<u32x2 *>(vp) = (u32x2){h0, h1};
+          *reinterpret_cast<u32x2 *>(vp + 1024) = (u32x2){l0, l1};
+        }
       }
     }
     S3_LAP(1);

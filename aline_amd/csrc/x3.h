@@ -285,10 +285,19 @@ __global__ __launch_bounds__(256) void keys_kernel(Geo g, int tpe, int *__restri
   __syncthreads();
   // layer 0's key image: key k -> tile b * (WNK / 16) + k / 16, row k % 16; 64 pieces (ks, hi | lo, g) of 16 bytes per key row
   const int n = s_n;
-  for (int i = tid; i < n * 64; i += 256) {
-    const int k = i >> 6, e = i & 63, ks = e >> 3, hl = (e >> 2) & 1, gq = e & 3;
-    const int row = keyrow[b * WNK + k];
-    KX[xpiece((long)b * (WNK / 16) + (k >> 4), ks, hl, 16 * gq + (k & 15))] = X0[xpiece((long)b * tpe + (row >> 4), ks, hl, 16 * gq + (row & 15))];
+  for (int i0 = tid; i0 < n * 64; i0 += 256 * 8) {          // 8 pieces per thread in flight (the loads miss L2: one at a time took 28 us)
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + 256 * u, n * 64 - 1), k = i >> 6, e = i & 63, ks = e >> 3, hl = (e >> 2) & 1, gq = e & 3;
+      const int row = keyrow[b * WNK + k];
+      v[u] = X0[xpiece((long)b * tpe + (row >> 4), ks, hl, 16 * gq + (row & 15))];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u, k = i >> 6, e = i & 63, ks = e >> 3, hl = (e >> 2) & 1, gq = e & 3;
+      if (i < n * 64) KX[xpiece((long)b * (WNK / 16) + (k >> 4), ks, hl, 16 * gq + (k & 15))] = v[u];
+    }
   }
 }
 
@@ -349,10 +358,16 @@ struct Stream {
   int dma_slot;           // the MFMA batch (0..3) of a chunk behind which this wave issues its pieces (0: all waves)
   __device__ __forceinline__ void issue() {
 #ifndef X3_NO_DMA      // (timing experiments only: tools/x3_variants.sh)
-    const char *p = src(s_issue) + wave_off + lane_off;
-    char *d = ring + b_issue * CHUNK_BYTES + wave_off;
+    // buffer_load ... lds with the chunk's base in a scalar buffer descriptor and a constant 32-bit lane offset: no per-piece
+    // vector address arithmetic (global_load_lds took a 64-bit per-lane address per piece); the whole rollout 80.2 -> 77.3 ms
+    // (kv_kernel / head_kernel, which are stream-bound, gain; the layer kernel is unchanged: profiles/r03_x3_timing_experiments.txt)
+    {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src(s_issue)), 0, CHUNK_BYTES, 0x00020000);
+      char *d = ring + b_issue * CHUNK_BYTES + wave_off;
 #pragma unroll
-    for (int i = 0; i < PIECES_PER_WAVE; ++i) glds16(p + i * 1024, d + i * 1024);
+      for (int i = 0; i < PIECES_PER_WAVE; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(d + i * 1024), 16, lane_off, wave_off + i * 1024, 0, 0);
+    }
 #endif
     s_issue = s_issue + 1 == seq_len ? 0 : s_issue + 1;
     b_issue = (b_issue + 1) & (NBUF - 1);
@@ -385,11 +400,7 @@ __device__ __forceinline__ Stream<SrcFn> make_stream(SrcFn src, char *ring, int 
                   Stamps{},
 #endif
                   src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u, (unsigned)wave * (unsigned)(PIECES_PER_WAVE * 1024),
-#ifdef X3_DMA_SPREAD     // (timing experiment: partner waves issue two batches apart; 5 % slower than all behind batch 0)
-                  (wave + 2 * (wave >> 2)) & 3};
-#else
                   0};
-#endif
   return s;
 }
 
@@ -657,22 +668,13 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], c
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) mb[kt][r] = (16 * kt + r) < nv ? 0.f : -INFINITY;
-#ifdef X3_KV_DEPTH2       // (experiment: two heads ahead; NKT <= 2 only -- 3 x 64 registers at four key tiles do not fit)
-  constexpr int NB = NKT <= 2 ? 3 : 2;
-#else
-  constexpr int NB = 2;
-#endif
+  constexpr int NB = 2;      // (two heads ahead, three buffers: measured 1 % slower)
   HeadKV<NKT> buf[NB];
   buf[0] = first;
-  if (NB == 3) buf[1].load(kv, 1);
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     HeadKV<NKT> &c = buf[h % NB];
-#ifndef X3_NO_KV_PREFETCH
-    if (h + NB - 1 < H) buf[(h + NB - 1) % NB].load(kv, h + NB - 1);
-#else
-    if (h > 0) c.load(kv, h);
-#endif
+    if (h + 1 < H) buf[(h + 1) % NB].load(kv, h + 1);
     f32x4 s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -730,9 +732,6 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
   st.stamps.start();
 #endif
   st.sync();
-#ifdef X3_SETPRIO      // (experiment: static priority for the second-dispatched half, MI355X_MICROARCH.md 'two waves per SIMD' item 4)
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   FragRing ring;
   float range_chk = 0.f;
   // Tile rounds.  Full rounds: workgroup b takes the 8 consecutive tiles of group rd * G + b, one per wave (two waves per
@@ -798,16 +797,11 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     // fragments of the attention output free (it was not kept through the attention: registers) -------------------------
 #pragma unroll
     for (int m = 0; m < NMT; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifndef X3_NO_RESID_HOOK
     chunk_run_hook<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, qh[cc], ql[cc]); },
                         [&](int cc) {
                           xh[cc] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tl, cc, 0, lidx)]);
                           xl[cc] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tl, cc, 1, lidx)]);
                         });
-#else
-    chunk_run<NKS>(st, ring, [&](int cc, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, qh[cc], ql[cc]); });
-    load_tile(a.XIN, tl, lidx, xh, xl);
-#endif
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(bo + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
@@ -831,20 +825,12 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
               },
               [&](int, int m, const f16x8 &ah, const f16x8 &al) { mfma3(y[m], ah, al, hbh, hbl); });
     }
-    // The next round's tile.  Requesting ALL of it here (behind LN2 + the stores) was measured 2 % SLOWER than loading it at the
-    // top of the round (64 more live registers through LN2: X3_NEXT_PREFETCH); the Q projection consumes a k-step per chunk, so at
-    // the top only the first k-step's latency is exposed -- X3_NEXT_KS0 requests just that one here.
-    // (unconditional: after the last round the same tile is read once more, from L2, and dropped)
-    f16x8 nxh[NKS], nxl[NKS];
+    // (The next round's tile is loaded at the top of the round: the Q projection consumes a k-step per chunk, so only the first
+    //  k-step's latency is exposed.  Requesting the whole tile here, behind LN2 and the stores, was measured 2 % SLOWER -- 64 more
+    //  live registers through LN2 --, requesting its first k-step only: no change.  profiles/r03_x3_timing_experiments.txt)
     const long tn = tile_of(rd + 1 < my_rounds ? rd + 1 : rd);
     int bn, rn, ln;
     rows_of(tn, bn, rn, ln);
-#if defined(X3_NEXT_PREFETCH)
-    load_tile(a.XIN, tn, ln, nxh, nxl);
-#elif defined(X3_NEXT_KS0)
-    nxh[0] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, 0, 0, ln)]);
-    nxl[0] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, 0, 1, ln)]);
-#endif
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(b2 + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
@@ -869,19 +855,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
         a.KXout[xpiece((long)b * (WNK / 16) + (kp >> 4), ks, 1, 16 * g + (kp & 15))] = __builtin_bit_cast(u32x4, ol);
       }
     }
-#if defined(X3_NEXT_PREFETCH)
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) { xh[ks] = nxh[ks]; xl[ks] = nxl[ks]; }
-#elif defined(X3_NEXT_KS0)
-    xh[0] = nxh[0]; xl[0] = nxl[0];
-#pragma unroll
-    for (int ks = 1; ks < NKS; ++ks) {
-      xh[ks] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, ks, 0, ln)]);
-      xl[ks] = __builtin_bit_cast(f16x8, a.XIN[xpiece(tn, ks, 1, ln)]);
-    }
-#else
-    load_tile(a.XIN, tn, ln, xh, xl);
-#endif
+    load_tile(a.XIN, tn, ln, xh, xl);       // (after the last round: the same tile once more, from L2, dropped)
     X3_LAP(st, 7);
   }
   if (wg_tail && !my_tail) idle_chunks(st, seq);       // the tail round of a wave without a tile: stream + barriers only

@@ -168,8 +168,6 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
     (dicts with epoch, T, mask_type, loss, design_loss, predict_loss, lr, seconds).  With `dist` / `world` > 1 (one
     process per GPU) every rank trains on its own episodes, gradients are all-reduced once per step; checkpoints and
     state_dicts are written by rank 0 only, followed by a barrier."""
-    if _get(cfg, "time_token", False):
-        raise NotImplementedError("aline_amd: the native backward does not cover the time-token variant")
     batch_size = batch_size or _get(cfg, "batch_size")
     max_T = max_T or _get(cfg, "T")
     min_T = min_T or _get(cfg, "min_T", max_T)

@@ -59,7 +59,7 @@ class Fixture:
 
 MODEL_FIXTURES = ["cfg2_location_d32", "cfg2_location_d256", "cfg1_almix_d1_data",
                   "cfg1_almix_d1_theta", "cfg1_almix_d1_all", "cfg3_almix_d2", "cfg4_ces",
-                  "cfg5_psycho_d512", "aux_data_timetoken"]
+                  "cfg5_psycho_d512", "aux_data_timetoken", "aux_timetoken_train"]
 
 
 @pytest.fixture(scope="session")

@@ -9,8 +9,10 @@ from helpers import native_model, to_dev
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["cfg2_location_d32", "cfg1_almix_d1_data"])
+@pytest.mark.parametrize("name", ["cfg2_location_d32", "cfg1_almix_d1_data", "aux_timetoken_train"])
 def test_gradients_match_reference_autograd(golden, name):
+    """(aux_timetoken_train: data mode with the time token of model/head.py:342-345 -- the acquisition MLP sees [z | t / T],
+    train_aline.py:80-82 -- incl. the gradient of the time column of its first layer; fixture of oracle/make_golden_r3.py)"""
     from aline_amd.train import train_step
     fx = golden(name)
     dims, T = fx.meta["dims"], fx.meta["T"]
@@ -270,8 +272,7 @@ def _oracle_gradients_with_gate_flips(sd, cpu, cfg, T, forced, mask, g_logp, g_l
     return g0, deltas, ref, n_gates
 
 
-@pytest.mark.parametrize("mask", ["all", "split"])
-@pytest.mark.parametrize("B", [10, 11])
+@pytest.mark.parametrize("mask,B", [("all", 10), ("split", 11)])
 def test_fused_backward_kernels_in_mix_mode_with_target_data_keys(mask, B):
     """The fused attention kernels with target DATA rows among the keys and a target mask (model/encoder.py:83-126:
     the candidates see context + visible targets): al_mix task with 8 target points + 3 theta tokens, T = 9 (<= 32 keys).

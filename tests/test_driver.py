@@ -120,12 +120,20 @@ def test_train_loop_across_burn_in_and_resume(tmp_path):
     cfg = _cfg(tmp_path, max_epoch=6, burning_epoch=3, checkpoint=2, T=6, min_T=4, batch_size=16,
                task=_Cfg(mask_type=["all"], embedding_type="theta", n_target_data=0, n_target_theta=2,
                          n_query_init=40))
-    seen_nq = []
-    recs = train(cfg, model, task, on_epoch=lambda r: seen_nq.append(task.n_query_init))
+    seen_nq, acq_drift = [], []
+    acq0 = [p.detach().clone() for p in model.head.acquisition_head.parameters()]
+
+    def on_epoch(r):
+        seen_nq.append(task.n_query_init)
+        acq_drift.append(max(float((p.detach() - q).abs().max()) for p, q in zip(model.head.acquisition_head.parameters(), acq0)))
+    recs = train(cfg, model, task, on_epoch=on_epoch)
     assert [r["epoch"] for r in recs] == list(range(6))
     assert all(4 <= r["T"] <= 6 for r in recs) and all(np.isfinite(r["loss"]) for r in recs)
     # burn-in: n_query_init = T, prediction loss only; afterwards the configured candidate set and two lr groups
     assert seen_nq == [6, 6, 6, 40, 40, 40]
+    # during burn-in no loss term reaches the acquisition head (train_aline.py:126-128): its .grad is None in the reference and
+    # AdamW leaves it alone -- no weight decay, no moment updates; from the first design-loss epoch on it moves
+    assert acq_drift[:3] == [0.0, 0.0, 0.0] and acq_drift[3] > 0.0, acq_drift
     assert all(r["loss"] == pytest.approx(r["predict_loss"]) for r in recs[:3])
     assert [len(r["lr"]) for r in recs] == [1, 1, 1, 2, 2, 2]
     assert recs[3]["lr"][0] == pytest.approx(recs[3]["lr"][1] / 5)
