@@ -1550,7 +1550,7 @@ static bool fused_gmm_heads(const aline_model &m) { return m.d == gmmb::D && m.F
 
 // In-projection + attention backward as one kernel (attn_bwd_mfma.h).  ALINE_BWD_ATTN_BLOCK=0: the per-op kernels.
 static bool fused_attn_block(const aline_model &m, int max_keys) {
-  return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK && !dbg(ALINE_DBG_NO_BWD_ATTN_BLOCK);
+  return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK_BLOCK && !dbg(ALINE_DBG_NO_BWD_ATTN_BLOCK);
 }
 
 BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
@@ -1734,6 +1734,43 @@ extern "C" int aline_rollout_backward(const aline_model *m, const aline_rollout 
 //   x_in   input of the encoder (ST_ENC without ST_EMBED)        z_in   encoder output (ST_HEAD without ST_ENC)
 //   d_in   upstream gradient wrt the stage's output (ST_ENC without ST_HEAD: dz; ST_EMBED alone: dx)
 //   d_out  gradient wrt the stage's input (ST_HEAD alone: dz; ST_ENC without ST_EMBED: dx)
+// per-instance attention kernels of the training backward, by the number of key tiles an instance may hold (<= 160 keys):
+// two persistent workgroups per CU while the LDS / register budget allows, one otherwise
+template <int KT>
+static int launch_layer_fwd_kt(hipStream_t st, const lfwd::Args &fa, int I) {
+  const size_t lds = (size_t)lfwd::lds_floats(KT) * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(lfwd::layer_fwd_kernel<KT>, dim3((unsigned)std::min(I, KT <= 3 ? 512 : 256)), dim3(lfwd::THREADS), lds, st, fa);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+static int launch_layer_fwd(hipStream_t st, const lfwd::Args &fa, int I, int max_keys) {
+  const int kt = (max_keys + 15) / 16;
+  if (kt <= 2) return launch_layer_fwd_kt<2>(st, fa, I);
+  if (kt <= 3) return launch_layer_fwd_kt<3>(st, fa, I);
+  if (kt <= 4) return launch_layer_fwd_kt<4>(st, fa, I);
+  if (kt <= 6) return launch_layer_fwd_kt<6>(st, fa, I);
+  if (kt <= 8) return launch_layer_fwd_kt<8>(st, fa, I);
+  return kt <= 10 ? launch_layer_fwd_kt<10>(st, fa, I) : ALINE_EUNSUPPORTED;
+}
+template <int KT>
+static int launch_attn_block_bwd_kt(hipStream_t st, const abwd::BlockArgs &ba, int I) {
+  const size_t lds = (size_t)abwd::block_lds_floats(KT) * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<KT>, dim3((unsigned)std::min(I, KT <= 2 ? 512 : 256)), dim3(abwd::THREADS), lds, st, ba);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+static int launch_attn_block_bwd(hipStream_t st, const abwd::BlockArgs &ba, int I, int max_keys) {
+  const int kt = (max_keys + 15) / 16;
+  if (kt <= 2) return launch_attn_block_bwd_kt<2>(st, ba, I);
+  if (kt <= 3) return launch_attn_block_bwd_kt<3>(st, ba, I);
+  if (kt <= 4) return launch_attn_block_bwd_kt<4>(st, ba, I);
+  if (kt <= 6) return launch_attn_block_bwd_kt<6>(st, ba, I);
+  if (kt <= 8) return launch_attn_block_bwd_kt<8>(st, ba, I);
+  return kt <= 10 ? launch_attn_block_bwd_kt<10>(st, ba, I) : ALINE_EUNSUPPORTED;
+}
+
 struct StageIO { int stages; const float *x_in, *z_in, *d_in; float *d_out; };
 
 static int backward_impl(const aline_model *m, const aline_rollout *r, const float *g_logp, const float *g_ll,
@@ -1833,9 +1870,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         fa.wo = m->out_proj_w[l]; fa.bo = m->out_proj_b[l]; fa.w1 = m->lin1_w[l]; fa.b1 = m->lin1_b[l];
         fa.w2 = m->lin2_w[l]; fa.b2 = m->lin2_b[l]; fa.g1 = m->norm1_w[l]; fa.e1 = m->norm1_b[l];
         fa.g2 = m->norm2_w[l]; fa.e2 = m->norm2_b[l];
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(2) * (int)sizeof(float));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lfwd::lds_floats(3) * (int)sizeof(float));
-        if (!dbg(ALINE_DBG_NO_BWD_LAYER_FWD_FLAT)) {      // (instance, tile) units from one flat list, K / V fragments from L2
+        if (max_keys <= 48 && !dbg(ALINE_DBG_NO_BWD_LAYER_FWD_FLAT)) {      // (instance, tile) units from one flat list, K / V fragments from L2
           const long units = (long)I * ((N + 15) / 16);
           const unsigned fgrid = (unsigned)std::min<long>((units + lfwd::WAVES - 1) / lfwd::WAVES, 768);      // three workgroups per CU
           const size_t fl = lfwd::LDS_FLOATS_FLAT * sizeof(float);
@@ -1844,10 +1879,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
           CHECK_LAUNCH();
           continue;
         }
-        const unsigned grid = (unsigned)std::min(I, 512);      // two persistent workgroups per CU
-        if (max_keys <= 32) hipLaunchKernelGGL(lfwd::layer_fwd_kernel<2>, dim3(grid), dim3(lfwd::THREADS), lfwd::lds_floats(2) * sizeof(float), c.st, fa);
-        else hipLaunchKernelGGL(lfwd::layer_fwd_kernel<3>, dim3(grid), dim3(lfwd::THREADS), lfwd::lds_floats(3) * sizeof(float), c.st, fa);
-        CHECK_LAUNCH();
+        TRY(launch_layer_fwd(c.st, fa, I, max_keys));
         continue;
       }
       if (ckv) {
@@ -2045,12 +2077,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         ba.g = g; ba.X = Xs(l); ba.dA = dTmp; ba.dX = dXn; ba.win = m->in_proj_w[l]; ba.bin = m->in_proj_b[l];
         ba.dwin = gr->in_proj_w[l]; ba.dbin = gr->in_proj_b[l];
         ba.kvc = KVl(l); ba.dkvc = dKVc; ba.keyidx = keyidx; ba.kcnt = kcnt; ba.max_keys = max_keys;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(2) * (int)sizeof(float));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, abwd::block_lds_floats(3) * (int)sizeof(float));
-        // persistent workgroups: two per CU at <= 32 keys (242 registers), one otherwise
-        if (max_keys <= 32) hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<2>, dim3((unsigned)std::min(I, 512)), dim3(abwd::THREADS), abwd::block_lds_floats(2) * sizeof(float), c.st, ba);
-        else hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<3>, dim3((unsigned)std::min(I, 256)), dim3(abwd::THREADS), abwd::block_lds_floats(3) * sizeof(float), c.st, ba);
-        CHECK_LAUNCH();
+        TRY(launch_attn_block_bwd(c.st, ba, I, max_keys));
         // key rows: dx += Wk^T dK + Wv^T dV, Wk / Wv gradients (one wave per (instance, key tile))
         const long units = (long)I * ((max_keys + 15) / 16);
         hipLaunchKernelGGL(abwd::kv_bwd_kernel, dim3((unsigned)std::min<long>((units + abwd::WAVES - 1) / abwd::WAVES, 1024)), dim3(abwd::THREADS), 0, c.st, ba);

@@ -425,6 +425,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    if os.environ.get("ALINE_DUMP_MAPS"):      # (diagnostic: where every library of this process is mapped, before the timed loop)
+        with open(os.environ["ALINE_DUMP_MAPS"], "w") as f:
+            f.write(open("/proc/self/maps").read())
     for _ in range(args.warmup):
         ro.refresh_uniform()
         run()
@@ -443,9 +446,6 @@ def main():
     designs_per_rollout = args.batch * args.T * args.n_query
     # whole job = the designs of all ranks / the slowest rank's time
     value, dt, _ = aggregate_throughput(float(designs_per_rollout * args.steps), dt, dist, device)
-    if os.environ.get("ALINE_DUMP_MAPS"):      # (diagnostic: where every library of this process is mapped)
-        with open(os.environ["ALINE_DUMP_MAPS"], "w") as f:
-            f.write(open("/proc/self/maps").read())
 
     # sustained leg: the same replay back to back for >= --sustain-s seconds (so that SMI sampling sees the GPU busy)
     sustained_ms = None
