@@ -1550,7 +1550,7 @@ static bool fused_gmm_heads(const aline_model &m) { return m.d == gmmb::D && m.F
 
 // In-projection + attention backward as one kernel (attn_bwd_mfma.h).  ALINE_BWD_ATTN_BLOCK=0: the per-op kernels.
 static bool fused_attn_block(const aline_model &m, int max_keys) {
-  return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK_BLOCK && !dbg(ALINE_DBG_NO_BWD_ATTN_BLOCK);
+  return m.d == abwd::D && m.H == abwd::H && max_keys <= abwd::MAXK && !dbg(ALINE_DBG_NO_BWD_ATTN_BLOCK);
 }
 
 BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
@@ -1734,41 +1734,32 @@ extern "C" int aline_rollout_backward(const aline_model *m, const aline_rollout 
 //   x_in   input of the encoder (ST_ENC without ST_EMBED)        z_in   encoder output (ST_HEAD without ST_ENC)
 //   d_in   upstream gradient wrt the stage's output (ST_ENC without ST_HEAD: dz; ST_EMBED alone: dx)
 //   d_out  gradient wrt the stage's input (ST_HEAD alone: dz; ST_ENC without ST_EMBED: dx)
-// per-instance attention kernels of the training backward, by the number of key tiles an instance may hold (<= 160 keys):
-// two persistent workgroups per CU while the LDS / register budget allows, one otherwise
+// per-instance attention kernels of the training backward (<= 48 keys: two or three key tiles).  Instantiations for 4 .. 10 key tiles (up
+// to 160 keys: cfg3) were built and measured in round 3 and are NOT kept: with all scores of a head and the dK / dV tiles of every key tile in
+// registers they run at one wave per SIMD (8 tiles: 94, 10 tiles: 281 spills) -- attn_block_bwd_kernel<10> 7.3 ms per call against 6.5 ms of the
+// fp32-VALU kernel it would replace, layer_fwd_kernel<10> 3.7 ms against 2.9 ms of the three kernels it fuses (profiles/r03_cfg3_train_*).
 template <int KT>
 static int launch_layer_fwd_kt(hipStream_t st, const lfwd::Args &fa, int I) {
   const size_t lds = (size_t)lfwd::lds_floats(KT) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lfwd::layer_fwd_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(lfwd::layer_fwd_kernel<KT>, dim3((unsigned)std::min(I, KT <= 3 ? 512 : 256)), dim3(lfwd::THREADS), lds, st, fa);
+  hipLaunchKernelGGL(lfwd::layer_fwd_kernel<KT>, dim3((unsigned)std::min(I, 512)), dim3(lfwd::THREADS), lds, st, fa);      // two persistent workgroups per CU
   CHECK_LAUNCH();
   return ALINE_OK;
 }
 static int launch_layer_fwd(hipStream_t st, const lfwd::Args &fa, int I, int max_keys) {
-  const int kt = (max_keys + 15) / 16;
-  if (kt <= 2) return launch_layer_fwd_kt<2>(st, fa, I);
-  if (kt <= 3) return launch_layer_fwd_kt<3>(st, fa, I);
-  if (kt <= 4) return launch_layer_fwd_kt<4>(st, fa, I);
-  if (kt <= 6) return launch_layer_fwd_kt<6>(st, fa, I);
-  if (kt <= 8) return launch_layer_fwd_kt<8>(st, fa, I);
-  return kt <= 10 ? launch_layer_fwd_kt<10>(st, fa, I) : ALINE_EUNSUPPORTED;
+  return max_keys <= 32 ? launch_layer_fwd_kt<2>(st, fa, I) : max_keys <= 48 ? launch_layer_fwd_kt<3>(st, fa, I) : ALINE_EUNSUPPORTED;
 }
 template <int KT>
 static int launch_attn_block_bwd_kt(hipStream_t st, const abwd::BlockArgs &ba, int I) {
   const size_t lds = (size_t)abwd::block_lds_floats(KT) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // persistent workgroups: two per CU at <= 32 keys (242 registers), one otherwise
   hipLaunchKernelGGL(abwd::attn_block_bwd_kernel<KT>, dim3((unsigned)std::min(I, KT <= 2 ? 512 : 256)), dim3(abwd::THREADS), lds, st, ba);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
 static int launch_attn_block_bwd(hipStream_t st, const abwd::BlockArgs &ba, int I, int max_keys) {
-  const int kt = (max_keys + 15) / 16;
-  if (kt <= 2) return launch_attn_block_bwd_kt<2>(st, ba, I);
-  if (kt <= 3) return launch_attn_block_bwd_kt<3>(st, ba, I);
-  if (kt <= 4) return launch_attn_block_bwd_kt<4>(st, ba, I);
-  if (kt <= 6) return launch_attn_block_bwd_kt<6>(st, ba, I);
-  if (kt <= 8) return launch_attn_block_bwd_kt<8>(st, ba, I);
-  return kt <= 10 ? launch_attn_block_bwd_kt<10>(st, ba, I) : ALINE_EUNSUPPORTED;
+  return max_keys <= 32 ? launch_attn_block_bwd_kt<2>(st, ba, I) : max_keys <= 48 ? launch_attn_block_bwd_kt<3>(st, ba, I) : ALINE_EUNSUPPORTED;
 }
 
 struct StageIO { int stages; const float *x_in, *z_in, *d_in; float *d_out; };

@@ -15,8 +15,7 @@
 
 namespace abwd {
 
-constexpr int D = 32, HD = 8, H = 4, KTMAX = 3, MAXK = 16 * KTMAX;      // (the stand-alone attention_bwd_mfma_kernel)
-constexpr int KT_BLOCK_MAX = 10, MAXK_BLOCK = 16 * KT_BLOCK_MAX;        // the attention-block kernels: up to 160 keys
+constexpr int D = 32, HD = 8, H = 4, KTMAX = 3, MAXK = 16 * KTMAX;
 constexpr int PK = 36;
 constexpr int WAVES = 4, THREADS = 64 * WAVES;
 
@@ -230,16 +229,12 @@ __device__ __forceinline__ bool role_is_ctx(const Geo &g, int b, int r) {
   return r > 0;
 }
 
-// LDS (floats): Wq image [32][36] | bq [32] | Ks, Vs, zeros [3][16 KT][36] | wave scratch [4][16][36] | dK / dV slots [NS][2][16 KT][36]
-// NS = one slot per wave up to 48 keys (KT <= 3); beyond that ONE slot the waves add to in turn (a slot per wave would not fit:
-// 184 KB at 160 keys) -- three more barriers per instance, negligible beside the 19 x 10 (tile, key tile) units of an instance.
-constexpr int block_slots(int KT) { return KT <= 3 ? WAVES : 1; }
-constexpr int block_lds_floats(int KT) { return D * PK + D + 3 * 16 * KT * PK + WAVES * 16 * PK + block_slots(KT) * 2 * 16 * KT * PK; }
+// LDS (floats): Wq image [32][36] | bq [32] | Ks, Vs, zeros [3][16 KT][36] | wave scratch [4][16][36] | dK / dV slots [4][2][16 KT][36]
+constexpr int block_lds_floats(int KT) { return D * PK + D + 3 * 16 * KT * PK + WAVES * 16 * PK + WAVES * 2 * 16 * KT * PK; }
 
 template <int KT>
 __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kernel(BlockArgs a) {
   constexpr int MK = 16 * KT;
-  constexpr int NS = block_slots(KT);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *const Wi = lds, *const bi = Wi + D * PK, *const Ks = bi + D, *const Vs = Ks + MK * PK, *const Zs = Vs + MK * PK,
                *const scrs = Zs + MK * PK, *const slots = scrs + WAVES * 16 * PK;      // slots [wave][dK | dV][MK][PK]
@@ -417,9 +412,8 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
       }
     }
     // ---- dK / dV of the key rows: every wave leaves its partial sums in its own LDS slot (plain 16-byte stores: LDS float
-    // atomics retire a few lanes per cycle), the store to the compact buffer adds the four slots; with one shared slot
-    // (KT > 3) wave 0 stores and waves 1 .. 3 add in turn -------------------------------------------------------------
-    if constexpr (NS == WAVES) {
+    // atomics retire a few lanes per cycle), the store to the compact buffer adds the four slots -------------------------
+    {
       float *my = slots + wave * 2 * MK * PK;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -429,31 +423,14 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
             *reinterpret_cast<f32x4 *>(my + (16 * kt + tok) * PK + 16 * mt + 4 * gq) = dKt[mt][kt] * ln2;
             *reinterpret_cast<f32x4 *>(my + MK * PK + (16 * kt + tok) * PK + 16 * mt + 4 * gq) = dVt[mt][kt];
           }
-      __syncthreads();
-    } else {
-#pragma unroll 1
-      for (int w = 0; w < WAVES; ++w) {
-        if (wave == w) {
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-              if (kt < nkt) {
-                f32x4 *pk = reinterpret_cast<f32x4 *>(slots + (16 * kt + tok) * PK + 16 * mt + 4 * gq);
-                f32x4 *pv = reinterpret_cast<f32x4 *>(slots + MK * PK + (16 * kt + tok) * PK + 16 * mt + 4 * gq);
-                if (w == 0) { *pk = dKt[mt][kt] * ln2; *pv = dVt[mt][kt]; }
-                else { *pk = *pk + dKt[mt][kt] * ln2; *pv = *pv + dVt[mt][kt]; }
-              }
-        }
-        __syncthreads();
-      }
     }
+    __syncthreads();
     for (int i = tid; i < n_ak * 16; i += THREADS) {
       const int j = i >> 4, c4 = (i & 15) * 4;
       const float *src = slots + (c4 < D ? 0 : MK * PK - D) + j * PK + c4;
       f32x4 v = ld4(src);
 #pragma unroll
-      for (int w = 1; w < NS; ++w) v += ld4(src + w * 2 * MK * PK);
+      for (int w = 1; w < WAVES; ++w) v += ld4(src + w * 2 * MK * PK);
       *reinterpret_cast<f32x4 *>(a.dkvc + ((long)b * a.max_keys + j) * 2 * D + c4) = v;
     }
   }

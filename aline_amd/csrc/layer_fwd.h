@@ -1,4 +1,4 @@
-// One encoder layer of the small-width model (d = 32, F = 128, 4 heads of 8, <= 160 keys per instance), forward recompute of
+// One encoder layer of the small-width model (d = 32, F = 128, 4 heads of 8, <= 48 keys per instance), forward recompute of
 // the TRAINING backward, as ONE kernel:  x -> q = Wq x + bq -> a = masked set-attention(q, K, V) -> y = tail(x, a)
 // (model/encoder.py:8-46, 83-126, 128-141).  It replaces the Q-projection GEMM, the K / V gather GEMM, the attention
 // kernel and the tail kernel of the per-op recompute (2.25 ms per layer at the headline shape): x is read once, a (the
@@ -34,10 +34,8 @@ struct Args {
 // LDS (floats): tail image [L_SCR] | Wq image [32][36] | bq [32] | Ks, Vs, zeros [3][16 KT][36]
 constexpr int lds_floats(int KT) { return L_SCR + D * PK + D + 3 * 16 * KT * PK; }
 
-// KT = key tiles held (2, 3: two workgroups per CU; 4, 6, 8, 10 -- up to 160 keys, the mix / data configurations: one workgroup
-// per CU, K / V / zero blocks of 16 KT rows in LDS, all scores of a head in 4 KT registers)
 template <int KT>
-__global__ __launch_bounds__(THREADS, KT <= 3 ? 2 : 1) void layer_fwd_kernel(Args a) {
+__global__ __launch_bounds__(THREADS, 2) void layer_fwd_kernel(Args a) {
   constexpr int MK = 16 * KT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *const Wi = lds + L_SCR, *const bi = Wi + D * PK, *const Ks = bi + D, *const Vs = Ks + MK * PK, *const Zs = Vs + MK * PK;

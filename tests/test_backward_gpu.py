@@ -209,6 +209,52 @@ def test_fused_backward_kernels_match_per_op_pipeline(T, B):
     assert worst[1] < 2e-4, worst
 
 
+@pytest.mark.parametrize("T,B,n_td", [(12, 8, 100), (50, 4, 100), (20, 6, 40)])
+def test_fused_backward_kernels_at_the_cfg3_key_counts(T, B, n_td):
+    """BASELINE configs[2] (al_mix dx = 2: 100 target points + 3 theta tokens among the keys, split mask): up to 1 + 49 + 103 = 153
+    keys per instance: beyond 48 keys the attention runs the per-op kernels (fp32 VALU attention + in-projection GEMMs) while the
+    token-local tail, the acquisition head and the GMM heads stay on their fused kernels.  That mix against the all-per-op
+    pipeline on the same rollout and upstream gradients: 115, 153 and 62 keys."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import GPTask
+    from aline_amd.train import backward, reinforce_terms
+    from aline_amd.utils import create_target_mask
+    torch.manual_seed(7)
+    dev = torch.device("cuda")
+    task = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=200, n_target_theta=3, n_target_data=n_td, device=dev)
+    batch = task.sample_batch(B)
+    batch["target_mask"] = create_target_mask("split", "mix", n_td, 3, None, None, None, None, "data")
+    model = Aline(Embedder(2, 1, 32, 128, 3, "mix"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda()
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        terms = reinforce_terms(ro, "mix", "split")
+        grads = []
+        for flags in ([], ["NO_BWD_TAIL", "NO_BWD_ATTN_BLOCK", "NO_BWD_ACQ", "NO_BWD_LAYER_FWD", "NO_BWD_GMM_FUSED", "NO_BWD_GMM128",
+                           "NO_BWD_GMM_BATCHED"]):
+            with _lib.debug(*flags):
+                for p in model.parameters():
+                    p.grad = None
+                backward(model, ro, terms["g_logp"], terms["g_ll"])
+                torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    floor = 1e-2 * max(float(g.abs().max()) for g in grads[1].values())
+    worst, errs = ("", 0.0), {}
+    for k in grads[0]:
+        ref = grads[1][k]
+        assert torch.isfinite(grads[0][k]).all(), k
+        err = errs[k] = float((grads[0][k] - ref).abs().max()) / max(float(ref.abs().max()), floor)
+        if err > worst[1]:
+            worst = (k, err)
+    # exact-fp32 products in different summation orders.  With a few hundred instances ONE knife-edge ReLU (a hidden unit whose
+    # pre-activation is within rounding of zero takes the other side in one of the two forwards: the gate-flip arbitration of
+    # test_fused_backward_kernels_in_mix_mode_with_target_data_keys) moves an element of that unit's own gradients by up to 1 % and
+    # everything upstream of it by ~1e-4: the first-layer parameters of the heads are held to 2e-2, everything else to 5e-4
+    loose = max((e for k, e in errs.items() if k.startswith("head.") and (".0.weight" in k or ".0.bias" in k)), default=0.0)
+    tight = max((e for k, e in errs.items() if not (k.startswith("head.") and (".0.weight" in k or ".0.bias" in k))), default=0.0)
+    assert tight < 5e-4 and loose < 2e-2, (worst, tight, loose)
+
+
 def test_train_step_graph_rollout_takes_the_new_batch():
     """`train_step` replays its sampled rollout from a HIP graph kept per (model, shapes, T): a second step on another batch
     must be the rollout of THAT batch -- same designs, log-probabilities and log-likelihoods as a fresh eager rollout with
