@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void attention_kernel(Geo g, int d, const floa
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < MAX_KT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
-    mx = group_max4(mx);
+    mx = group_max4(mx, x3::opaque_inf());
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < MAX_KT; ++kt)

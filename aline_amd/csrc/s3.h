@@ -28,6 +28,7 @@ using x3::frag_value;
 using x3::split_frag;
 using x3::glds16;
 using x3::group_max4;
+using x3::vmax;
 using x3::mfma3;
 using x3::split2;
 using x3::wait_vmcnt;
@@ -265,19 +266,22 @@ __device__ __forceinline__ float layer_norm32(f32x4 &a, f32x4 &b, const float *w
 
 // softmax numerators of one head over NKT key tiles (exp2 domain), in place; returns 1 / denominator
 template <int NKT>
-__device__ __forceinline__ float softmax_tiles(f32x4 (&s)[NKT]) {
-  float m0 = fmaxf(s[0][0], s[0][1]), m1 = fmaxf(s[0][2], s[0][3]);
+__device__ __forceinline__ float softmax_tiles(f32x4 (&s)[NKT], float inf) {
+  float m0 = vmax(s[0][0], s[0][1], inf), m1 = vmax(s[0][2], s[0][3], inf);      // (vmax: no canonicalising moves in front of the MFMA results, x3.h)
 #pragma unroll
-  for (int kt = 1; kt < NKT; ++kt) {        // two chains of v_max3_f32
-    m0 = fmaxf(fmaxf(m0, s[kt][0]), s[kt][1]);
-    m1 = fmaxf(fmaxf(m1, s[kt][2]), s[kt][3]);
+  for (int kt = 1; kt < NKT; ++kt) {
+    m0 = vmax(vmax(m0, s[kt][0], inf), s[kt][1], inf);
+    m1 = vmax(vmax(m1, s[kt][2], inf), s[kt][3], inf);
   }
-  const float mx = group_max4(fmaxf(m0, m1));
-  float acc0 = 0.f, acc1 = 0.f;        // (plain v_sub / v_add: full rate; the packed forms are not, and cost register moves)
+  const float mx = group_max4(vmax(m0, m1, inf), inf);
+  // (plain v_sub / v_add: full rate; the packed forms are not, and cost register moves; the sums start from the first pair, not from 0)
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
+  for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+  float acc0 = s[0][0] + s[0][1], acc1 = s[0][2] + s[0][3];
+#pragma unroll
+  for (int kt = 1; kt < NKT; ++kt) {
     acc0 += s[kt][0] + s[kt][1];
     acc1 += s[kt][2] + s[kt][3];
   }
@@ -293,24 +297,30 @@ __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, cons
   constexpr int NKP = (NKT + 1) / 2;              // key tiles NKT (an odd count: the last V^T pair is half used), pairs NKP
   const u32x4 qhu = __builtin_bit_cast(u32x4, qh), qlu = __builtin_bit_cast(u32x4, ql);
   const bool glo = g < 2;
+  unsigned ma = glo ? 0xFFFFFFFFu : 0u;      // lane groups 0, 1 carry the first head of a pair, 2, 3 the second
+  asm("" : "+v"(ma));                        // (opaque: the optimiser otherwise turns the full-rate v_and back into v_cndmask selects)
+  const unsigned mbm = ~ma;
+  const float inf = x3::opaque_inf();
+  f32x4 mb[NKT];                                               // key mask of this lane's token: the initial accumulator of both heads' scores
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mb[kt][r] = (16 * kt + r) < nv4 ? 0.f : -INFINITY;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     // heads 2 m (channels 16 m + 0..7: lane groups 0, 1) and 2 m + 1 (lane groups 2, 3): registers 2 m, 2 m + 1
     u32x4 ah = {0u, 0u, 0u, 0u}, al = ah, bh = ah, bl = ah;
-    ah[2 * m] = glo ? qhu[2 * m] : 0u; ah[2 * m + 1] = glo ? qhu[2 * m + 1] : 0u;
-    al[2 * m] = glo ? qlu[2 * m] : 0u; al[2 * m + 1] = glo ? qlu[2 * m + 1] : 0u;
-    bh[2 * m] = glo ? 0u : qhu[2 * m]; bh[2 * m + 1] = glo ? 0u : qhu[2 * m + 1];
-    bl[2 * m] = glo ? 0u : qlu[2 * m]; bl[2 * m + 1] = glo ? 0u : qlu[2 * m + 1];
+    ah[2 * m] = qhu[2 * m] & ma; ah[2 * m + 1] = qhu[2 * m + 1] & ma;
+    al[2 * m] = qlu[2 * m] & ma; al[2 * m + 1] = qlu[2 * m + 1] & ma;
+    bh[2 * m] = qhu[2 * m] & mbm; bh[2 * m + 1] = qhu[2 * m + 1] & mbm;
+    bl[2 * m] = qlu[2 * m] & mbm; bl[2 * m + 1] = qlu[2 * m + 1] & mbm;
     const f16x8 qah = __builtin_bit_cast(f16x8, ah), qal = __builtin_bit_cast(f16x8, al);
     const f16x8 qbh = __builtin_bit_cast(f16x8, bh), qbl = __builtin_bit_cast(f16x8, bl);
     f32x4 sa[NKT], sb[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const f16x8 kh = *reinterpret_cast<const f16x8 *>(kv + kt * PAIR_BYTES), kl = *reinterpret_cast<const f16x8 *>(kv + kt * PAIR_BYTES + 1024);
-      f32x4 mb;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mb[r] = (16 * kt + r) < nv4 ? 0.f : -INFINITY;
-      sa[kt] = mb; sb[kt] = mb;
+      sa[kt] = mb[kt]; sb[kt] = mb[kt];
       mfma3(sa[kt], kh, kl, qah, qal);
       mfma3(sb[kt], kh, kl, qbh, qbl);
     }
@@ -321,7 +331,7 @@ __device__ __forceinline__ void attention(const f16x8 &qh, const f16x8 &ql, cons
       const char *vp = kv + kv_v + (m * nkp + kb) * PAIR_BYTES;
       vh[kb] = *reinterpret_cast<const f16x8 *>(vp); vl[kb] = *reinterpret_cast<const f16x8 *>(vp + 1024);
     }
-    const float inva = softmax_tiles<NKT>(sa), invb = softmax_tiles<NKT>(sb);
+    const float inva = softmax_tiles<NKT>(sa, inf), invb = softmax_tiles<NKT>(sb, inf);
     f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = oa;
 #pragma unroll
     for (int kb = 0; kb < NKP; ++kb) {

@@ -87,11 +87,18 @@ __device__ __forceinline__ f32x4 frag_value(const f16x8 &hi, const f16x8 &lo, in
   }
   return v;
 }
-__device__ __forceinline__ float group_max4(float v) {
+// max(a, b) as v_med3_f32(a, b, +inf): llvm.maxnum (fmaxf) must quiet signalling NaNs in IEEE mode, so hipcc puts a canonicalising
+// `v_max_f32 x, x, x` in front of every fmaxf operand it cannot prove quiet -- MFMA accumulators and permlane outputs, i.e. every
+// operand of the softmax maxima: 6 of the ~14 instructions of a head's max reduction.  The median form is one instruction, is visible to
+// the compiler's hazard recogniser (unlike inline asm behind an MFMA) and ignores a NaN operand like maxnum does.
+// (the +inf travels in a register the optimiser cannot see through: with the literal it folds the median back into maxnum)
+__device__ __forceinline__ float opaque_inf() { float v = __builtin_inff(); asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ float vmax(float a, float b, float inf) { return __builtin_amdgcn_fmed3f(a, b, inf); }
+__device__ __forceinline__ float group_max4(float v, float inf) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  v = vmax(__uint_as_float(r[0]), __uint_as_float(r[1]), inf);
   r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]), inf);
 }
 
 // ---- images ---------------------------------------------------------------------------------------------------
@@ -669,6 +676,7 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], c
 #pragma unroll
     for (int r = 0; r < 4; ++r) mb[kt][r] = (16 * kt + r) < nv ? 0.f : -INFINITY;
   constexpr int NB = 2;      // (two heads ahead, three buffers: measured 1 % slower)
+  const float inf = opaque_inf();
   HeadKV<NKT> buf[NB];
   buf[0] = first;
 #pragma unroll
@@ -681,10 +689,10 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[H], f16x8 (&ql)[H], c
       s[kt] = mb[kt];
       mfma3(s[kt], __builtin_bit_cast(f16x8, c.k[2 * kt]), __builtin_bit_cast(f16x8, c.k[2 * kt + 1]), qh[h], ql[h]);
     }
-    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+    float mx = vmax(vmax(s[0][0], s[0][1], inf), vmax(s[0][2], s[0][3], inf), inf);
 #pragma unroll
-    for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
-    mx = group_max4(mx);
+    for (int kt = 1; kt < NKT; ++kt) mx = vmax(mx, vmax(vmax(s[kt][0], s[kt][1], inf), vmax(s[kt][2], s[kt][3], inf), inf), inf);
+    mx = group_max4(mx, inf);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)

@@ -11,6 +11,11 @@
    pad in the same block).
 2. No scalar-memory instruction and no scratch access inside the x3 pipelines' hot loops is NOT required any more (the
    x3 reads are compiler-visible), but spills in the x3 layer kernel are reported.
+3. The code shape behind round 1's run-to-run irreproducibility: an integer max on float bits (`v_max_i32` /
+   `v_max_u32`: the one-instruction ReLU) whose result is a source of a packed fp32 instruction (`v_pk_fma_f32`, `v_pk_mul_f32`,
+   `v_pk_add_f32`) in the same basic block.  ReLU is fmaxf everywhere and the library is built with -fno-slp-vectorize, so the
+   pattern must not occur: any occurrence fails the build.  (Packed fp32 instructions as such remain -- they come from f32x4
+   source arithmetic -- and are counted per kernel as a note.)
 """
 import re
 import subprocess
@@ -39,6 +44,7 @@ def main():
     for sweep in range(4):        # fixed point over backward branches (loops)
         findings, spills, n_reads = [], {}, 0
         kernel, since, in_asm = None, INF, False
+        imax_regs, n_pk = set(), 0   # VGPRs last written by an integer max in the current basic block; packed-fp32 instructions seen
         for ln, line in enumerate(lines, 1):
             s = line.strip()
             m = re.match(r"^(_Z\w+):", line)
@@ -48,6 +54,7 @@ def main():
             m = re.match(r"^(\.LBB\w+):", line)
             if m:                 # a label: the worst case over the fall-through path and every branch into it
                 since = min(since, label_in.get((kernel, m.group(1)), INF))
+                imax_regs = set()
                 continue
             if not s or s.startswith(".") or (s.startswith(";") and "ASM" not in s):
                 continue
@@ -59,6 +66,26 @@ def main():
                 continue
             if "scratch_" in s and kernel and "x312layer_kernel" in kernel:
                 spills[kernel] = spills.get(kernel, 0) + 1
+            # (3) integer max feeding a packed fp32 instruction
+            mo = re.match(r"(v_\w+)\s+(.*)", s)
+            if mo:
+                ops = [o.strip() for o in mo.group(2).split(",")]
+                regs = lambda o: ({int(o[1:])} if re.fullmatch(r"v\d+", o) else                       # noqa: E731
+                                  set(range(int(o[2:-1].split(":")[0]), int(o[2:-1].split(":")[1]) + 1)) if re.fullmatch(r"v\[\d+:\d+\]", o) else set())
+                dst = regs(ops[0]) if ops else set()
+                if mo.group(1).startswith("v_pk_") and mo.group(1).endswith("_f32"):
+                    n_pk += 1
+                    used = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+                    if used & imax_regs:
+                        findings.append(f"{kernel}: line {ln}: {mo.group(1)} reads v{sorted(used & imax_regs)} written by an integer max (the round-1 irreproducibility shape)")
+                if mo.group(1).startswith(("v_max_i32", "v_max_u32")):
+                    imax_regs |= dst
+                else:
+                    imax_regs -= dst
+            ml = re.match(r"(?:global_load|ds_read|buffer_load|scratch_load|flat_load)\w*\s+(v\d+|v\[\d+:\d+\])", s)
+            if ml:                # a load overwrites its destination registers
+                o = ml.group(1)
+                imax_regs -= ({int(o[1:])} if ":" not in o else set(range(int(o[2:-1].split(":")[0]), int(o[2:-1].split(":")[1]) + 1)))
             if s.startswith("v_mfma"):
                 since = 0
                 continue
@@ -75,6 +102,8 @@ def main():
                     continue
             since = min(INF, since + wait_states(s))
     print(f"check_isa: {n_reads} inline-asm v_accvgpr_read_b32 audited, required distance to the last v_mfma: {REQUIRED} wait states")
+    print(f"check_isa: {n_pk} packed-fp32 instructions in the code object, none fed by an integer max" if not any("integer max" in f for f in findings)
+          else "check_isa: packed-fp32 instruction fed by an integer max FOUND")
     for k, n in spills.items():
         print(f"check_isa: note: {n} scratch instructions in {k}")
     for f in findings:
