@@ -359,6 +359,9 @@ def main():
                     help="also time K full training steps (rollout + backward + all-reduce + AdamW); 0 = skip")
     ap.add_argument("--sustain-s", type=float, default=2.5,
                     help="after the timed steps, replay the rollout back to back for this many seconds (sustained_ms_per_step)")
+    ap.add_argument("--prewarm-s", type=float, default=1.0,
+                    help="untimed device warm-up in front of the W warm-up steps: the rollout replayed back to back for this many seconds, "
+                         "so that the K timed steps run at the clock / cache state of a job in progress (0 = none)")
     ap.add_argument("--no-d256", action="store_true", help="skip the d_model = 256 sub-measurement (N = 1 only)")
     ap.add_argument("--no-query-gmm", action="store_true", help="skip the value_with_query_gmm figure")
     ap.add_argument("--d256-precs", default="f16x3", help="arithmetic modes of the d_model = 256 sub-measurement (comma separated)")
@@ -428,6 +431,13 @@ def main():
     if os.environ.get("ALINE_DUMP_MAPS"):      # (diagnostic: where every library of this process is mapped, before the timed loop)
         with open(os.environ["ALINE_DUMP_MAPS"], "w") as f:
             f.write(open("/proc/self/maps").read())
+    if args.prewarm_s > 0:              # steady state first: the first rollouts after the capture run ~9 % slower than a job in progress
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < args.prewarm_s:
+            for _ in range(20):
+                ro.refresh_uniform()
+                run()
+            torch.cuda.synchronize(device)
     for _ in range(args.warmup):
         ro.refresh_uniform()
         run()
@@ -603,7 +613,7 @@ def main():
                    "heads": args.heads, "layers": args.layers, "components": 10,
                    "posterior_out_query": "lazy (not computed; same in the CPU baseline)",
                    "hip_graph": bool(args.graph), "exact_designs_per_rollout": exact, "path": path,
-                   "f16_range_status": range_status, "backend": backend if world > 1 else None,
+                   "f16_range_status": range_status, "backend": backend if world > 1 else None, "prewarm_s": args.prewarm_s,
                    "precision": args.precision,
                    "parallelism": f"episode-dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",

@@ -68,8 +68,16 @@ def test_ces_eig_bounds_match_reference(golden):
         ll = task.log_likelihood(y[:, t].unsqueeze(0), x[:, t].unsqueeze(0), thetas).cpu()
         fin = torch.isfinite(ref[t])
         assert (torch.isfinite(ll) == fin).all()
-        # fp32 powf / erff of |mu| up to 1e4: relative bound, as for the CPU oracle
-        assert torch.allclose(ll[fin], ref[t][fin], rtol=5e-3, atol=5e-3), float((ll[fin] - ref[t][fin]).abs().max())
+        # This fixture holds prior draws: log-likelihoods down to -1.2e8, utilities of |mu| up to 1e4, where the reference's own fp32
+        # arithmetic (powf / erff, a difference of two utilities) is several 1e-3 (relative) away from an fp64 evaluation.  So the
+        # arbiter is the oracle in fp64: an element passes when the kernel is within 1e-3 (relative) of fp64, or no further from fp64
+        # than twice the reference's own fp32 error, or -- the censor-limit branches, which fp64 never takes
+        # (censored_sigmoid_normal.py:60-75) -- within 1e-4 of the reference itself.  (Round 2: rtol 5e-3 against the reference.)
+        ll64 = orc.ces_log_likelihood(y[:, t].cpu().double().reshape(1, B, 1), x[:, t].cpu().double().reshape(1, B, -1),
+                                      thetas.cpu().double()).reshape(ref[t].shape)
+        k, r, d = ll[fin].double(), ref[t][fin].double(), ll64[fin]
+        ok = ((k - d).abs() <= 1e-3 * (1 + d.abs())) | ((k - d).abs() <= 2 * (r - d).abs()) | ((k - r).abs() <= 1e-4 * (1 + r.abs()))
+        assert ok.all(), (int((~ok).sum()), float(((k - d).abs() / (1 + d.abs()))[~ok].max()))
         pce, nmc = crit(y[:, t], x[:, t], thetas)
         # bounds reach 1e5 in magnitude on this fixture (likelihoods of order -1e5): relative bound
         assert torch.allclose((math.log(L + 1) - pce).cpu(), fx.t("ces_pce")[:, t], rtol=1e-4, atol=2e-2)
