@@ -196,7 +196,6 @@ def _flags_from_environment():
         lib.aline_debug_set_flags(bits)
 
 
-_flags_from_environment()
 
 
 def f16_range_status(ws, device):
@@ -239,3 +238,6 @@ class Workspace:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         return self.buf
+
+
+_flags_from_environment()

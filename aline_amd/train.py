@@ -203,10 +203,20 @@ def check_range_async(block=False):
     _RANGE_PENDING[:] = keep
 
 
+_RANGE_WORDS = None           # ring of pinned status words (pinning per step would cost a host allocation each time)
+_RANGE_NEXT = 0
+
+
 def _post_range_status(ro):
+    global _RANGE_WORDS, _RANGE_NEXT
     if ro.m.precision != _lib.PREC["f16x3"]:
         return
-    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    if _RANGE_WORDS is None:
+        _RANGE_WORDS = torch.zeros(64, dtype=torch.int32).pin_memory()
+    if len(_RANGE_PENDING) >= 48:          # (nobody looked for 48 steps: look now rather than wrap the ring)
+        check_range_async(block=True)
+    word = _RANGE_WORDS[_RANGE_NEXT:_RANGE_NEXT + 1]
+    _RANGE_NEXT = (_RANGE_NEXT + 1) % 64
     word.copy_(ro.ws[:4].view(torch.int32), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()

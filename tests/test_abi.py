@@ -91,6 +91,18 @@ def test_debug_word_and_kernel_name(lib):
         assert mo and (1 << int(mo.group(1))) == bit, name
 
 
+def test_aline_dbg_environment_convenience_of_the_python_side():
+    """`ALINE_DBG=NAME,KEY=value` (tools/ scripts) is applied by aline_amd._lib at import -- flags and parameters."""
+    code = ("import aline_amd._lib as L; print(L.lib.aline_debug_get_flags() & L.DBG['DISABLE_FUSED'] != 0)")
+    env = dict(os.environ, ALINE_DBG="DISABLE_FUSED,S3_WAVES=12,S3_EPW=3")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "True"
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ALINE_DBG="NO_SUCH_SWITCH"), cwd=ROOT,
+                         capture_output=True, text=True)
+    assert bad.returncode != 0
+
+
 def test_struct_layout_matches_c(tmp_path):
     """sizeof/offsetof from a tiny C program must equal the ctypes mirrors."""
     from aline_amd import _lib
