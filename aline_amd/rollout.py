@@ -94,7 +94,7 @@ class Rollout:
         self.fell_back = False          # run_checked() re-ran the rollout in f32 after an f16 range overflow
 
     PATHS = {0: "generic pipeline", 1: "fused::rollout_f32_kernel", 2: "wide::wide_step_kernel",
-             3: "x3::layer_kernel", 4: "s3::step_kernel"}
+             3: "x3::layer_kernel", 4: "s3::step_kernel", 5: "x5::layer_kernel"}
 
     @property
     def path(self):

@@ -177,7 +177,8 @@ enum { ALINE_PATH_GENERIC = 0,   /* stage kernels + GEMMs, any configuration */
        ALINE_PATH_FUSED = 1,     /* fused_rollout.h: d = 32, theta mode, F32, whole rollout in one launch */
        ALINE_PATH_WIDE = 2,      /* wide.h: d = 256, BF16 */
        ALINE_PATH_X3 = 3,        /* x3.h: d = 256, F16X3 (reference precision on the f16 matrix pipe) */
-       ALINE_PATH_S3 = 4 };      /* s3.h: d = 32, F16X3, any embedding mode, one launch per design step */
+       ALINE_PATH_S3 = 4,        /* s3.h: d = 32, F16X3, any embedding mode, one launch per design step */
+       ALINE_PATH_X5 = 5 };      /* x3.h, namespace x5: d = 512 / 8 heads of 64, F16X3 (the psychometric configuration's width) */
 int aline_rollout_path(const aline_model *m, const aline_rollout *r);
 /* Name (as rocprofv3 prints it, template arguments included) of the dominant kernel of that path for (m, r) -- the launch
  * the ev_kernel_start / ev_kernel_stop pair brackets -- written to buf; returns the ALINE_PATH_* value or a negative code. */

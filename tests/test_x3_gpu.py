@@ -16,7 +16,7 @@ DIMS = {"dim_x": 2, "dim_y": 1, "d": 256, "F": 1024, "n_head": 8, "L": 2, "C": 1
 LL_TOL, LP_TOL = 1e-4, 1e-4
 
 
-def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, dims=DIMS):
+def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, dims=DIMS, want_path=None):
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
     from aline_amd import _lib
@@ -30,7 +30,10 @@ def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, di
         g = torch.Generator(device="cpu").manual_seed(seed)
         forced = torch.stack([torch.stack([torch.randint(0, n_query - t, (1,), generator=g)[0] for t in range(T)])
                               for _ in range(B)]).to("cuda")
-        ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None).run()
+        ro = Rollout(model, batch, T, select=select, forced_idx=forced if select == "forced" else None)
+        if want_path is not None:
+            assert ro.path == want_path, ro.path
+        ro.run()
         torch.cuda.synchronize()
         return ro.target_ll.float().cpu().clone(), ro.log_prob.float().cpu().clone(), ro.idx.cpu().clone()
 
@@ -39,7 +42,7 @@ def _run(prec, env, B, n_query, T, seed=5, select="forced", target_mask=None, di
 def test_x3_matches_fp32_pipeline(B, n_query, T):
     """N = 203 (13 tiles, the headline shape), 40 (partial tile), 253, 19, more tiles than one workgroup round
     (9 episodes x 13 tiles), and 43 keys (three key tiles)."""
-    ll_x, lp_x, _ = _run("f16x3", {}, B, n_query, T)
+    ll_x, lp_x, _ = _run("f16x3", {}, B, n_query, T, want_path="x3::layer_kernel")
     ll_f, lp_f, _ = _run("f32", {}, B, n_query, T)
     assert torch.isfinite(ll_x).all() and torch.isfinite(lp_x).all()
     assert (ll_x - ll_f).abs().max() < LL_TOL, float((ll_x - ll_f).abs().max())
@@ -68,7 +71,7 @@ def test_x3_sixteen_components_and_wide_ffn():
     the fp32 pipeline itself is only good to ~3e-4 here (it differs from an fp64 evaluation by that much), so two
     fp32-grade pipelines are compared at 5e-4."""
     dims = dict(DIMS, C=16, F=2048, L=1)
-    ll_x, lp_x, _ = _run("f16x3", {}, 2, 40, 3, dims=dims)
+    ll_x, lp_x, _ = _run("f16x3", {}, 2, 40, 3, dims=dims, want_path="x3::layer_kernel")
     ll_f, lp_f, _ = _run("f32", {}, 2, 40, 3, dims=dims)
     assert (ll_x - ll_f).abs().max() < 5e-4 and (lp_x - lp_f).abs().max() < LP_TOL
 
@@ -93,7 +96,7 @@ def test_x3_is_reproducible():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("d,extra_env", [(512, {}), (256, {"ALINE_DISABLE_X3": "1"})])
+@pytest.mark.parametrize("d,extra_env", [(512, {"ALINE_DISABLE_X3": "1"}), (256, {"ALINE_DISABLE_X3": "1"})])
 def test_generic_mfma_attention_matches_valu_attention(d, extra_env):
     """Generic pipeline at head_dim 64 (d = 512, the cfg5 shape) and 32: the attention on the matrix pipe (attn3.h, 3-term
     f16 split, K / V of the key rows only) against the fp32 VALU attention kernel, same GEMMs around it; and against the

@@ -1,0 +1,55 @@
+"""x5 path (aline_amd/csrc/x3.h, namespace x5): d_model = 512, 8 heads of 64 -- the width of BASELINE configs[4] (psychometric,
+config/task/psychometric.yaml) -- on the split-f16 tile-image kernels of the x3 path, 4 waves per workgroup.  Same claim and same
+bounds as test_x3_gpu.py: posterior log-likelihood and design log-probabilities within 1e-4 of the exact-fp32 pipeline of the same
+C ABI on the same weights and forced designs.  The committed reference fixtures of this width (cfg5_psycho_d512,
+deep_cfg5_psycho_d512) are checked through this path by test_hip_parity / test_r2_gpu (precision f16x3)."""
+import pytest
+import torch
+
+from test_x3_gpu import DIMS, LL_TOL, LP_TOL, _run
+
+pytestmark = pytest.mark.gpu
+
+D512 = dict(DIMS, d=512, F=128, L=2)
+X5 = "x5::layer_kernel"
+
+
+@pytest.mark.parametrize("B,n_query,T", [(3, 200, 6), (5, 37, 4), (2, 250, 3), (4, 16, 5), (2, 90, 40), (90, 200, 2)])
+def test_x5_matches_fp32_pipeline(B, n_query, T):
+    """N = 203 (13 tiles), a partial tile, 253 rows, 19 rows, 43 keys (three key tiles, two V^T k-steps), and more tiles than one
+    round of workgroups holds (90 episodes x 13 tiles > 256 CUs x 4 waves: full rounds + the tail round)."""
+    ll_x, lp_x, _ = _run("f16x3", {}, B, n_query, T, dims=D512, want_path=X5)
+    ll_f, lp_f, _ = _run("f32", {}, B, n_query, T, dims=D512)
+    assert torch.isfinite(ll_x).all() and torch.isfinite(lp_x).all()
+    assert (ll_x - ll_f).abs().max() < LL_TOL, float((ll_x - ll_f).abs().max())
+    assert (lp_x - lp_f).abs().max() < LP_TOL, float((lp_x - lp_f).abs().max())
+
+
+def test_x5_matches_the_generic_f16x3_pipeline():
+    """The same rollout through the generic pipeline with the f16x3 GEMM policy (ALINE_DISABLE_X3): two fp32-grade evaluations."""
+    ll_x, lp_x, _ = _run("f16x3", {}, 3, 70, 5, dims=D512, want_path=X5)
+    ll_g, lp_g, _ = _run("f16x3", {"ALINE_DISABLE_X3": "1"}, 3, 70, 5, dims=D512, want_path="generic pipeline")
+    assert (ll_x - ll_g).abs().max() < LL_TOL and (lp_x - lp_g).abs().max() < LP_TOL
+
+
+@pytest.mark.parametrize("mask", [[True, False], [False, True], [False, False]])
+def test_x5_with_target_mask(mask):
+    """Queries attend only the selected targets (encoder.py:110-121): the predefined masks of the psychometric task."""
+    ll_x, lp_x, _ = _run("f16x3", {}, 3, 70, 5, target_mask=mask, dims=D512, want_path=X5)
+    ll_f, lp_f, _ = _run("f32", {}, 3, 70, 5, target_mask=mask, dims=D512)
+    assert (ll_x - ll_f).abs().max() < LL_TOL and (lp_x - lp_f).abs().max() < LP_TOL
+
+
+def test_x5_wide_ffn_and_three_layers():
+    """F = 2048 (the roofline variant of configs[4]: 64 hidden groups per tile) and L = 3."""
+    dims = dict(D512, F=2048, L=3)
+    ll_x, lp_x, _ = _run("f16x3", {}, 2, 40, 3, dims=dims, want_path=X5)
+    ll_f, lp_f, _ = _run("f32", {}, 2, 40, 3, dims=dims)
+    assert (ll_x - ll_f).abs().max() < LL_TOL and (lp_x - lp_f).abs().max() < LP_TOL
+
+
+def test_x5_sampling_is_reproducible():
+    a = _run("f16x3", {}, 6, 60, 8, select="sample", dims=D512, want_path=X5)
+    b = _run("f16x3", {}, 6, 60, 8, select="sample", dims=D512, want_path=X5)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert (a[1] <= 0).all() and torch.isfinite(a[1]).all()
