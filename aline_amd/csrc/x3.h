@@ -11,18 +11,25 @@
 #define X3_D 256
 #define X3_HD 32
 #define X3_THREADS 512
+#define X3_KV_AHEAD 1
 #include "x3_impl.h"
 #undef X3_NS
 #undef X3_D
 #undef X3_HD
 #undef X3_THREADS
+#undef X3_KV_AHEAD
 
 #define X3_NS x5
 #define X3_D 512
 #define X3_HD 64
 #define X3_THREADS 256
+#ifndef X5_KV_AHEAD
+#define X5_KV_AHEAD 1
+#endif
+#define X3_KV_AHEAD X5_KV_AHEAD
 #include "x3_impl.h"
 #undef X3_NS
 #undef X3_D
 #undef X3_HD
 #undef X3_THREADS
+#undef X3_KV_AHEAD

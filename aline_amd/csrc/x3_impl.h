@@ -548,9 +548,25 @@ __device__ __forceinline__ void load_tile(const u32x4 *X, long tile, int lane_id
   }
 }
 
+// The fp32 parameter vectors of a kernel sit in LDS behind the 128 KB chunk ring and are read as f32x4 at (word offset + 4 g).  Their
+// byte offsets are beyond the 16-bit immediate of ds_read, so, left alone, hipcc materialises one VGPR address per vector read, hoists
+// them all out of the tile loop and spills them (36 registers at d = 512, 11 at d = 256; every reload is a scratch load whose wait is
+// vmcnt(0), i.e. it also drains the K / V and residual loads in flight).  LaneParams is ONE per-lane base the optimiser cannot see
+// through: every read is base + immediate.
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+struct LaneParams {
+  unsigned base;          // LDS byte address of prm + 4 g
+  __device__ __forceinline__ f32x4 operator()(int word) const { return *(lds_cf32x4 *)(base + 4u * (unsigned)word); }
+};
+__device__ __forceinline__ LaneParams lane_params(const float *prm, int g) {
+  unsigned b = lds_addr(prm) + 16u * (unsigned)g;
+  asm volatile("" : "+v"(b));
+  return LaneParams{b};
+}
+
 // v = LayerNorm(v) over the D features of each token (NMT tiles x 4 registers x 4 lane groups), fp32, two passes
 // returns the reciprocal standard deviation (NaN iff an input was NaN / inf: the f16 range guard accumulates it)
-__device__ __forceinline__ float layer_norm(f32x4 (&v)[NMT], const float *lw, const float *lb, int g) {
+__device__ __forceinline__ float layer_norm(f32x4 (&v)[NMT], const LaneParams &P, int lw, int lb) {   // lw / lb: word offsets of weight / bias
   float s = 0.f;
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
@@ -563,7 +579,7 @@ __device__ __forceinline__ float layer_norm(f32x4 (&v)[NMT], const float *lw, co
   const float rstd = __builtin_amdgcn_rsqf(group_sum4(q) * (1.f / D) + 1e-5f);     // (v_rsq_f32: 1 ulp)
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
-    const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + 16 * mt + 4 * g), bv = *reinterpret_cast<const f32x4 *>(lb + 16 * mt + 4 * g);
+    const f32x4 wv = P(lw + 16 * mt), bv = P(lb + 16 * mt);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[mt][r] = fmaf(v[mt][r] * rstd, wv[r], bv[r]);
   }
@@ -694,14 +710,23 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[NKS], f16x8 (&ql)[NKS
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) mb[kt][r] = (16 * kt + r) < nv ? 0.f : -INFINITY;
-  constexpr int NB = 2;      // (two heads ahead, three buffers: measured 1 % slower)
+  // K / V pairs requested AHEAD heads in front of the one being computed.  d = 256: one (two waves per SIMD hide the rest; two ahead
+  // measured 1 % slower).  d = 512 (one wave per SIMD): a head is ~0.3 kcycles of work behind a round trip of ~5 kcycles, and with one
+  // head ahead the waits were 16 % of the kernel (in-kernel stamps) -- as many heads as the registers the input tile has just freed can
+  // hold (a head's pairs are 64 registers up to 32 keys, 128 beyond) are in flight at once; the scheduling barriers keep the requests
+  // where they are written (left alone the scheduler sinks every load towards its use).
+  constexpr int AHEAD = X3_KV_AHEAD > 1 && NKT > 2 ? 1 : X3_KV_AHEAD, NB = AHEAD + 1;
   const float inf = opaque_inf();
   HeadKV<NKT> buf[NB];
   buf[0] = first;
 #pragma unroll
+  for (int h = 1; h < AHEAD; ++h) buf[h].load(kv, h);
+  if (AHEAD > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
   for (int h = 0; h < H; ++h) {
     HeadKV<NKT> &c = buf[h % NB];
-    if (h + 1 < H) buf[(h + 1) % NB].load(kv, h + 1);
+    if (h + AHEAD < H) buf[(h + AHEAD) % NB].load(kv, h + AHEAD);
+    if (AHEAD > 1) __builtin_amdgcn_sched_barrier(0);
     f32x4 s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -752,7 +777,8 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     const float *gprm = reinterpret_cast<const float *>(a.img + (long)layer_chunks(F) * CHUNK_WORDS);
     for (int i = tid; i < np; i += THREADS) prm[i] = gprm[i];
   }
-  const float *bo = prm + 3 * D, *b1 = prm + 4 * D, *b2 = b1 + F, *ln1w = b2 + D, *ln1b = ln1w + D, *ln2w = ln1b + D, *ln2b = ln2w + D;
+  const LaneParams P = lane_params(prm, g);
+  const int o_bo = 3 * D, o_b1 = 4 * D, o_b2 = o_b1 + F, o_ln1w = o_b2 + D, o_ln1b = o_ln1w + D, o_ln2w = o_ln1b + D, o_ln2b = o_ln2w + D;   // word offsets
   // stream order of one tile group: Q (chunks 0 .. PC - 1), OUT (3 PC .. 4 PC - 1), FFN (4 PC ..)
   const char *wbase = reinterpret_cast<const char *>(a.img);
   const int seq = 2 * PC + (F / 32) * (W1C + CPK);
@@ -813,9 +839,10 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     auto q_epilogue = [&]() {
 #pragma unroll
       for (int h = 0; h < NKS; ++h) {
-        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(prm + 32 * h + 16 + 4 * g);
+        const f32x4 c0 = P(32 * h), c1 = P(32 * h + 16);
         split_frag(y[2 * h] * WINV + c0, y[2 * h + 1] * WINV + c1, qh[h], ql[h]);
       }
+      if (X3_KV_AHEAD > 1) __builtin_amdgcn_sched_barrier(0);      // (the Q accumulators are dead before more K / V pairs are requested)
       X3_LAP(st, 5);
     };
     {
@@ -839,8 +866,8 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
                        });
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
-      y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(bo + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
-    range_chk += layer_norm(y, ln1w, ln1b, g);
+      y[mt] = y[mt] * WINV + P(o_bo + 16 * mt) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
+    range_chk += layer_norm(y, P, o_ln1w, o_ln1b);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) split_frag(y[2 * ks], y[2 * ks + 1], xh[ks], xl[ks]);
     X3_LAP(st, 7);
@@ -851,7 +878,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
       f16x8 hbh, hbl;
       ffn_run(st, ring, F / 32, xh, xl,
               [&](int c, f32x4 &h0, f32x4 &h1) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 4 * g), c1 = *reinterpret_cast<const f32x4 *>(b1 + 32 * c + 16 + 4 * g);
+                const f32x4 c0 = P(o_b1 + 32 * c), c1 = P(o_b1 + 32 * c + 16);
                 h0 = h0 * WINV + c0; h1 = h1 * WINV + c1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h0[r] = relu_nn(h0[r]); h1[r] = relu_nn(h1[r]); }
@@ -868,8 +895,8 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
     rows_of(tn, bn, rn, ln);
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
-      y[mt] = y[mt] * WINV + *reinterpret_cast<const f32x4 *>(b2 + 16 * mt + 4 * g) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
-    range_chk += layer_norm(y, ln2w, ln2b, g);
+      y[mt] = y[mt] * WINV + P(o_b2 + 16 * mt) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
+    range_chk += layer_norm(y, P, o_ln2w, o_ln2b);
     const bool ztgt = LAST && a.zimg && rowok && r >= G.P;
     const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
     const int kp = (!LAST && rowok) ? a.keypos[(long)b * 16 * a.tpe + r] : -1;
