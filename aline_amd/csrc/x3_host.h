@@ -71,7 +71,8 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
   const size_t smem_kv = (size_t)NBUF * CHUNK_BYTES + 2 * D * 4;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&layer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_layer);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_layer);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kv_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kv_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
   const int cus = device_cus();
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
@@ -85,7 +86,12 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
       KvArgs ka{};
       ka.g = c.g; ka.tpe = tpe; ka.nkt2 = nkt2; ka.X = KX; ka.img = img + l * lw; ka.F = F; ka.keyrow = keyrow; ka.kcnt = kcnt; ka.KV = KV;
       ka.ngroups = (int)(((long)r->B * nkt2 + WAVES - 1) / WAVES);
-      hipLaunchKernelGGL(kv_kernel, dim3((unsigned)std::min(ka.ngroups, cus)), dim3(THREADS), smem_kv, c.st, ka);
+      // (fewer groups of key tiles than half the CUs: one job -- K | V x channel half -- per workgroup, so that every CU streams)
+      constexpr int NJ = 2 * CPK;
+      if (ka.ngroups * NJ <= 2 * cus)
+        hipLaunchKernelGGL(kv_split_kernel, dim3((unsigned)(std::min(ka.ngroups, std::max(1, cus / NJ)) * NJ)), dim3(THREADS), smem_kv, c.st, ka);
+      else
+        hipLaunchKernelGGL(kv_all_kernel, dim3((unsigned)std::min(ka.ngroups, cus)), dim3(THREADS), smem_kv, c.st, ka);
       CHECK_LAUNCH();
       LayerArgs la{};
       la.g = c.g; la.tpe = tpe; la.ngroups = (int)((tiles + WAVES - 1) / WAVES);

@@ -16,7 +16,7 @@
 // Kernels (one launch each per layer and step; activations travel as split-f16 TILE IMAGES, episodes padded to whole
 // 16-row tiles, so tiles never straddle episodes and every wave-level load / store is whole KBs):
 //   keys_kernel    per step: the key list of every episode (context rows, then the visible target rows)
-//   kv_kernel      K / V of the key rows only, written as the A fragments the attention needs
+//   kv_all_kernel / kv_split_kernel   K / V of the key rows only, written as the A fragments the attention needs
 //   layer_kernel   Q projection, masked set-attention, out-projection, LN1, FFN, LN2 of a token tile, all in
 //                  registers: 8 waves x one 16-token tile, weights streamed through LDS by LDS-DMA (32 KB chunks
 //                  of 16 pairs, 3 buffers); persistent workgroups walk the tile list, the weight stream is cyclic
@@ -596,7 +596,8 @@ struct KvArgs {
   u32x4 *KV;
 };
 
-__global__ __launch_bounds__(THREADS) void kv_kernel(KvArgs a) {
+// A workgroup computes K and V of its group of WAVES key tiles (all 2 PC chunks of Wk | Wv per group).
+__global__ __launch_bounds__(THREADS) void kv_all_kernel(KvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *prm = reinterpret_cast<float *>(lds + NBUF * CHUNK_BYTES);      // bk | bv
   const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
@@ -654,6 +655,89 @@ __global__ __launch_bounds__(THREADS) void kv_kernel(KvArgs a) {
         u32x2 *pl = reinterpret_cast<u32x2 *>(kv + KV_VOFF + ((i * 2 + (kt >> 1)) * 2 + 1) * 64 + lane) + (kt & 1);
         *ph = (u32x2){h0, h1};
         *pl = (u32x2){l0, l1};
+      }
+    }
+  }
+  st.finish();
+}
+
+// The same split into jobs -- (K | V) x (CPK halves of the D output channels): 16 output tiles and NKS chunks each --, one job per
+// workgroup (blockIdx % (2 CPK)), for launches with fewer groups of key tiles than CUs: at d = 512 / B = 256 there are 128 groups, each
+// streaming 2 MB of weights through one CU's LDS-DMA (60 us per launch, 14 % of the cfg5 rollout); split four ways every CU streams.
+__global__ __launch_bounds__(THREADS) void kv_split_kernel(KvArgs a) {
+  constexpr bool SPLIT = true;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float *prm = reinterpret_cast<float *>(lds + NBUF * CHUNK_BYTES);      // bk | bv
+  const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float *gprm = reinterpret_cast<const float *>(a.img + (long)layer_chunks(a.F) * CHUNK_WORDS);
+  for (int i = tid; i < 2 * D; i += THREADS) prm[i] = gprm[D + i];
+  constexpr int NJ = 2 * CPK;
+  const int job0 = SPLIT ? (int)(blockIdx.x % NJ) : 0;
+  const int grp0 = SPLIT ? (int)(blockIdx.x / NJ) : (int)blockIdx.x, gstride = SPLIT ? (int)(gridDim.x / NJ) : (int)gridDim.x;
+  const char *wbase = reinterpret_cast<const char *>(a.img) + (long)PC * CHUNK_BYTES;     // K chunks, then V chunks
+  // stream position s -> job (SPLIT: job0; else s / NKS), k-step s % NKS -> chunk (K | V) PC + CPK k + half
+  auto st = make_stream([wbase, job0](int s) {
+    const int job = SPLIT ? job0 : s / NKS, k = s % NKS;
+    return wbase + (long)((job / CPK) * PC + CPK * k + job % CPK) * CHUNK_BYTES;
+  }, lds, (SPLIT ? 1 : NJ) * NKS, tid);
+  st.start();
+  __syncthreads();
+  st.sync();
+  FragRing ring;
+  const long ntiles = (long)a.g.B * a.nkt2;
+  for (int grp = grp0; grp < a.ngroups; grp += gstride) {
+    const long tile = (long)grp * WAVES + wave;
+    const bool valid = tile < ntiles;
+    const long tl = valid ? tile : ntiles - 1;
+    const int b = tl / a.nkt2, kt = tl % a.nkt2, key = 16 * kt + tok;
+    const bool live = key < a.kcnt[2 * b + 1];          // (slots behind the key count hold stale rows: zeroed, the attention masks them)
+    f16x8 xh[NKS], xl[NKS];
+    load_tile(a.X, (long)b * (WNK / 16) + kt, lane, xh, xl);
+    if (!live) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) { xh[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; xl[ks] = xh[ks]; }
+    }
+    u32x4 *kv = a.KV + (long)b * KV_EP;
+#pragma unroll
+    for (int job = 0; job < NJ; ++job) {      // (unrolled: the job, and with it every register index and parameter offset, is a constant)
+      if (SPLIT && job != job0) continue;
+      const int half = job % CPK;
+      f32x4 y[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) y[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (job < CPK) {
+        // K^T = Wk KX^T: rows = channels, columns = keys -> A fragments of S^T = K Q^T, pair (channel k-step f, kt) -- a head is KPH k-steps
+        chunk_run<NKS>(st, ring, [&](int cc, int p, const f16x8 &ah, const f16x8 &al) { mfma3(y[p], ah, al, xh[cc], xl[cc]); });
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int f = 8 * half + j;
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(prm + 32 * f + 4 * g), b1 = *reinterpret_cast<const f32x4 *>(prm + 32 * f + 16 + 4 * g);
+          f16x8 fh, fl;
+          split_frag(y[2 * j] * WINV + b0, y[2 * j + 1] * WINV + b1, fh, fl);
+          if (valid) {
+            kv[((f * 4 + kt) * 2) * 64 + lane] = __builtin_bit_cast(u32x4, fh);
+            kv[((f * 4 + kt) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, fl);
+          }
+        }
+      } else {
+        // V = KX Wv^T with the MFMA operands swapped (rows = keys, columns = channels): accumulator tile i holds
+        // V[key 16 kt + 4 g + r][channel 16 i + tok] -- half (kt & 1) of this lane's piece of the V^T pair (i, kt / 2)
+        chunk_run<NKS>(st, ring, [&](int cc, int p, const f16x8 &bh, const f16x8 &bl) { mfma3(y[p], xh[cc], xl[cc], bh, bl); });
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int i = 16 * half + j;
+          const float bv = prm[D + 16 * i + tok];
+          unsigned h0, l0, h1, l1;
+          split2(y[j][0] * WINV + bv, y[j][1] * WINV + bv, h0, l0);
+          split2(y[j][2] * WINV + bv, y[j][3] * WINV + bv, h1, l1);
+          if (valid) {
+            u32x2 *ph = reinterpret_cast<u32x2 *>(kv + KV_VOFF + ((i * 2 + (kt >> 1)) * 2) * 64 + lane) + (kt & 1);
+            u32x2 *pl = reinterpret_cast<u32x2 *>(kv + KV_VOFF + ((i * 2 + (kt >> 1)) * 2 + 1) * 64 + lane) + (kt & 1);
+            *ph = (u32x2){h0, h1};
+            *pl = (u32x2){l0, l1};
+          }
+        }
       }
     }
   }
