@@ -197,14 +197,15 @@ def x3_layer_flops(d, F, n_c, n_q, n_t, n_s):
     return 2 * N * d * d + 4 * d * ((n_c + n_t) * n_c + n_q * (n_c + n_s)) + 2 * N * d * d + 4 * N * d * F
 
 
-def measure_d256(args, device, batch, precision):
-    """Sub-measurement (not `value`): the same workload on the matrix-core-bound model d = 256 / F = 1024 / H = 8.
-    precision f16x3 = the reference-precision x3 path (every product a 3-term f16 split, posterior NLL within 1e-4 of the
-    reference: tests/test_hip_parity.py, tests/test_r2_gpu.py); bf16 = the single-pass wide path (throughput mode, NLL
-    error ~1e-2)."""
+def measure_d256(args, device, batch, precision, d=256, F=1024, train=True):
+    """Sub-measurement (not `value`): the same workload on a matrix-core-bound model width: d = 256 / F = 1024 / H = 8 (the north
+    star's d_model >= 256 variant) or d = 512 / F = 128 / H = 8 (the width and literal FFN size of BASELINE configs[4], psychometric).
+    precision f16x3 = the reference-precision x3 / x5 path (every product a 3-term f16 split, posterior NLL within 1e-4 of the
+    reference: tests/test_hip_parity.py, tests/test_r2_gpu.py, tests/test_x5_gpu.py); bf16 = the single-pass wide path (d = 256
+    only; throughput mode, NLL error ~1e-2)."""
     from aline_amd import Aline, Embedder, Encoder, OutputHead
     from aline_amd.rollout import Rollout
-    d, F, H, L = 256, 1024, 8, args.layers
+    H, L = 8, args.layers
     torch.manual_seed(args.seed)
     model = Aline(Embedder(2, 1, d, F, 2, "theta"), Encoder(d, F, H, 0.0, L), OutputHead(2, 1, d, F, num_components=10))
     model = model.to(device).set_precision(precision).train()
@@ -250,14 +251,14 @@ def measure_d256(args, device, batch, precision):
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_DENSE_TFLOPS, "mfma_passes_per_product": passes,
                            "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / passes,
                            "frac_vs_instruction_mix_peak": ach * passes / PEAK_BF16_DENSE_TFLOPS,
-                           **profile_traffic("r03_x3_f16x3_d256_pmc_traffic.json" if precision == "f16x3" else None,
+                           **profile_traffic("r03_x3_f16x3_d256_pmc_traffic.json" if precision == "f16x3" and (d, F) == (256, 1024) else None,
                                              args.batch == 1000 and args.T == 30 and args.n_query == 200),
                            "peak_note": "dense f16/bf16 MFMA peak (MI355X_MICROARCH.md).  A reference-precision product costs "
                                         "3 MFMA passes (hi*hi + hi*lo + lo*hi), so the pipe can deliver at most peak / 3 of "
                                         "algorithmic FLOP/s in this mode: instruction_mix_peak; frac_vs_instruction_mix_peak is "
                                         "the matrix-pipe utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees: profiles/)"}
     out["f16_range_status"] = ro.range_status()
-    if args.train_steps > 0 and precision == "f16x3":
+    if train and args.train_steps > 0 and precision == "f16x3":
         # the training step of the same model (per-op exact-fp32 backward at this width)
         from aline_amd.train import train_step
         try:
@@ -363,6 +364,7 @@ def main():
                     help="untimed device warm-up in front of the W warm-up steps: the rollout replayed back to back for this many seconds, "
                          "so that the K timed steps run at the clock / cache state of a job in progress (0 = none)")
     ap.add_argument("--no-d256", action="store_true", help="skip the d_model = 256 sub-measurement (N = 1 only)")
+    ap.add_argument("--no-d512", action="store_true", help="skip the d_model = 512 / F = 128 sub-measurement (N = 1 only)")
     ap.add_argument("--no-query-gmm", action="store_true", help="skip the value_with_query_gmm figure")
     ap.add_argument("--d256-precs", default="f16x3", help="arithmetic modes of the d_model = 256 sub-measurement (comma separated)")
     args = ap.parse_args()
@@ -682,6 +684,9 @@ def main():
         for prec in args.d256_precs.split(","):
             out["d256"][prec] = measure_d256(args, device, batch, prec)
             log(f"d256 [{prec}]: {out['d256'][prec]['ms_per_rollout']:.2f} ms per rollout")
+    if world == 1 and not args.no_d512 and args.d_model != 512:
+        out["d512"] = {"f16x3": measure_d256(args, device, batch, "f16x3", d=512, F=128, train=False)}
+        log(f"d512 [f16x3]: {out['d512']['f16x3']['ms_per_rollout']:.2f} ms per rollout ({out['d512']['f16x3']['roofline']['kernel']})")
     if dist is not None:          # every collective is behind us: the ranks part here, rank 0 goes on to the CPU baseline
         dist.barrier()
         dist.destroy_process_group()

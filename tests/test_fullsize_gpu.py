@@ -211,6 +211,40 @@ def test_fullsize_cfg3_slice_against_the_cpu_oracle():
     assert float((ro.log_prob[take].cpu() - torch.stack(ref["log_prob"], 1)).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("mask", [[False, False, True, True], [True, True, False, False]])
+def test_fullsize_cfg5_slice_against_the_cpu_oracle(mask):
+    """BASELINE configs[4] (psychometric, d_model = 512 / 8 heads of 64, F = 128 as config/encoder/encoder.yaml, predefined target
+    masks of config/task/psychometric.yaml:12, T = 30, n_query = 200: 205 rows, up to 32 keys) at B = 256 on the x5 path: 8 of the 256
+    episodes through the CPU oracle, teacher-forced with the designs of the full-size HIP rollout."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import PsychometricTask
+    B, T, nq = 256, 30, 200
+    torch.manual_seed(5)
+    model = Aline(Embedder(1, 1, 512, 128, 4, "theta"), Encoder(512, 128, 8, 0.0, 3), OutputHead(1, 1, 512, 128)).cuda().eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    batch = PsychometricTask(n_query_init=nq, n_context_init=1, device=torch.device("cuda")).sample_batch(B)
+    batch["target_mask"] = torch.tensor(mask)
+    model.set_precision("f16x3")
+    ro = Rollout(model, batch, T, select="argmax", keep_zt=True)
+    assert ro.path == "x5::layer_kernel"
+    ro.run()
+    torch.cuda.synchronize()
+    assert ro.range_status() == 0
+    take = torch.tensor([0, 1, 2, 127, 128, 129, 254, 255])
+    cfg = dict(embedding_type="theta", n_head=8, num_layers=3, num_components=10, std_min=1e-4, n_target_theta=4)
+    ref = _oracle_slice(model, batch, ro, T, cfg, take)
+    sel = torch.tensor(mask)
+    d = (ro.target_ll[:, take].cpu() - torch.stack(ref["target_ll"])).abs()
+    assert float(d[..., sel].max()) < 1e-4, float(d[..., sel].max())       # the selected targets: what the loss reads (train_aline.py:97-110)
+    assert float(d.max()) < 5e-4, float(d.max())
+    assert float((ro.log_prob[take].cpu() - torch.stack(ref["log_prob"], 1)).abs().max()) < 2e-4
+    for t in (0, 15, T - 1):
+        assert float((ro.zt[t][take].cpu()[:, :nq - t] - ref["zt"][t]).abs().max()) < 5e-5
+
+
 def test_evaluation_protocol_size_against_the_cpu_oracle():
     """The README's evaluation runs n_query_final = 2000 candidates for T_final = 35 steps (README.md:45): P = 2001 point slots,
     126 token tiles per episode.  Eval-mode rollout on B = 2: the benchmarked mode (f16x3, s3 path) against the CPU oracle,

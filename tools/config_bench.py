@@ -35,6 +35,8 @@ def path_of(d, F, H, emb, precision, keys):
         return "wide::wide_step_kernel"
     if precision == "f16x3" and d == 256 and H == 8 and keys <= 64:
         return "x3::layer_kernel"
+    if precision == "f16x3" and d == 512 and H == 8 and keys <= 64:
+        return "x5::layer_kernel"
     return "generic pipeline"
 
 
