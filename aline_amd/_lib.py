@@ -67,7 +67,7 @@ class AlineRollout(C.Structure):
         + [(n, _fp) for n in ("uniform", "forced_idx")]
         + [("time_token_T", C.c_int32)]
         + [(n, _fp) for n in ("idx", "slot", "log_prob", "target_ll", "zt", "post_mean", "post_std",
-                              "post_weight", "ev_kernel_start", "ev_kernel_stop", "postq_mean", "postq_std", "postq_weight")]
+                              "post_weight", "ev_kernel_start", "ev_kernel_stop", "postq_mean", "postq_std", "postq_weight", "saved_acts")]
     )
 
 
@@ -93,6 +93,7 @@ def _load():
         "aline_rollout_step": (C.c_int, [MP, RP, C.c_int, _fp, C.c_size_t, _fp]),
         "aline_rollout_forward": (C.c_int, [MP, RP, _fp, C.c_size_t, _fp]),
         "aline_rollout_path": (C.c_int, [MP, RP]),
+        "aline_rollout_saved_acts_bytes": (C.c_size_t, [MP, RP]),
         "aline_rollout_kernel_name": (C.c_int, [MP, RP, C.c_char_p, C.c_size_t]),
         "aline_rollout_export": (C.c_int, [RP, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
         "aline_compute_ll": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, _fp, _fp]),
@@ -121,7 +122,7 @@ def _load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.aline_abi_version() != 3:
+    if lib.aline_abi_version() != 4:
         raise RuntimeError("aline_amd: libaline_hip.so ABI version mismatch")
     return lib, sig
 
@@ -134,7 +135,7 @@ DBG = {"DISABLE_FUSED": 1 << 0, "DISABLE_WIDE": 1 << 1, "DISABLE_X3": 1 << 2, "D
        "FUSED_STAMPS": 1 << 10, "WIDE_STAMPS": 1 << 11, "BWD_TAIL_PC": 1 << 12,
        "NO_BWD_TAIL": 1 << 16, "NO_BWD_ATTN_BLOCK": 1 << 17, "NO_BWD_ACQ": 1 << 18, "NO_BWD_LAYER_FWD": 1 << 19,
        "NO_BWD_LAYER_FWD_FLAT": 1 << 20, "NO_BWD_GMM_FUSED": 1 << 21, "NO_BWD_GMM128": 1 << 22, "NO_BWD_GMM_BATCHED": 1 << 23,
-       "NO_BWD_ATTN_MFMA": 1 << 24, "X3_LEGACY_HEAD": 1 << 25}
+       "NO_BWD_ATTN_MFMA": 1 << 24, "X3_LEGACY_HEAD": 1 << 25, "NO_BWD_GMM_WIDE": 1 << 26, "NO_BWD_SAVED_ACTS": 1 << 27}
 DBG_PARAM = {"S3_WAVES": 0, "S3_EPW": 1, "BWD_PREC": 2}
 
 

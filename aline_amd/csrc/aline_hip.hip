@@ -625,6 +625,14 @@ static int launch_s3_step_v(const Ctx &c, const S3Shape &sh, const s3::StepArgs 
   constexpr bool PF = false;
 #endif
   // (set at every launch: the attribute is per device, and a process may drive several)
+  if constexpr (F == 128) {      // (the width of the fused backward: the only one whose rollouts are asked to keep their activations)
+    if (a.sv) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F, NW, MAXNKP, PF, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
+      hipLaunchKernelGGL((s3::step_kernel<F, NW, MAXNKP, PF, true>), dim3(sh.nwg), dim3(NW * 64), sh.lds, c.st, a);
+      CHECK_LAUNCH();
+      return ALINE_OK;
+    }
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&s3::step_kernel<F, NW, MAXNKP, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
   hipLaunchKernelGGL((s3::step_kernel<F, NW, MAXNKP, PF>), dim3(sh.nwg), dim3(NW * 64), sh.lds, c.st, a);
   CHECK_LAUNCH();
@@ -1187,6 +1195,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     sa.logits = logits; sa.NP = NP;
     sa.zimg = want_gmm ? Zimg : nullptr; sa.zrow0 = (long)t * r->B * n_t;
     sa.zq = Zq; sa.zq_row0 = (long)t * r->B * r->P;
+    sa.sv = r->saved_acts; sa.sv_rows = (long)r->T * r->B * N; sa.sv_row0 = (long)t * r->B * N;
 #ifdef S3_STAMPS
     sa.stamps = want_gmm ? nullptr : reinterpret_cast<unsigned long long *>(c.at(c.pl.sRaw));
 #endif
@@ -1240,6 +1249,18 @@ int aline_rollout_path(const aline_model *m, const aline_rollout *r) {
   return ALINE_PATH_GENERIC;
 }
 
+// aline_rollout.saved_acts: written by the s3 path, read by the backward of the model width whose tail backward needs nothing but
+// a layer's input and attention output (tail_bwd.h)
+static bool saved_acts_usable(const aline_model &m, const aline_rollout &r) {
+  const bool fused_tail = m.d == tailbwd::D && m.F == tailbwd::F && !dbg(ALINE_DBG_NO_BWD_TAIL);      // (= bwd_fused_tail below)
+  return r.T > 0 && fused_tail && aline_rollout_path(&m, &r) == ALINE_PATH_S3;
+}
+size_t aline_rollout_saved_acts_bytes(const aline_model *m, const aline_rollout *r) {
+  if (!m || !r || validate_model(*m) != 0 || !saved_acts_usable(*m, *r)) return 0;
+  const size_t N = (size_t)r->P + r->n_target_data + m->n_theta;
+  return (size_t)(2 * m->L + 1) * r->T * r->B * N * m->d * sizeof(float);
+}
+
 int aline_rollout_kernel_name(const aline_model *m, const aline_rollout *r, char *buf, size_t n) {
   if (!buf || n == 0) return ALINE_EINVAL;
   const int path = aline_rollout_path(m, r);
@@ -1251,7 +1272,8 @@ int aline_rollout_kernel_name(const aline_model *m, const aline_rollout *r, char
     case ALINE_PATH_X5: snprintf(buf, n, "x5::layer_kernel<true>"); break;
     case ALINE_PATH_S3: {
       const S3Shape sh = s3_shape(*m, *r);
-      snprintf(buf, n, "s3::step_kernel<%d, %d, %d, false>", m->F, sh.nw, sh.nw == 8 ? s3::NKP_MAX : 2);
+      snprintf(buf, n, "s3::step_kernel<%d, %d, %d, false, %s>", m->F, sh.nw, sh.nw == 8 ? s3::NKP_MAX : 2,
+               (r->saved_acts && m->F == 128) ? "true" : "false");
       break;
     }
     default: snprintf(buf, n, "generic pipeline (no dominant kernel)"); break;
@@ -1686,9 +1708,12 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     g.B = I; g.P = P; g.n_td = n_td; g.n_th = n_th; g.N = N; g.n_ctx = 0; g.role = r->role;
     g.tmask = r->target_mask; g.inst_B = B; g.inst_t0 = tA; g.n_ctx0 = r->n_ctx0;
     const int max_keys = r->n_ctx0 + tA + nt_steps - 1 + n_t;
-    auto Xs = [&](int l) { return c.at(c.pl.Xs) + (size_t)l * M * d; };
+    // layer inputs / attention outputs of this chunk: recomputed into the workspace, or the rows the s3 rollout saved (aline_rollout.saved_acts)
+    const bool use_saved = r->saved_acts && do_emb && do_enc && do_head && saved_acts_usable(*m, *r) && !dbg(ALINE_DBG_NO_BWD_SAVED_ACTS);
+    const size_t sv_rows = (size_t)r->T * B * N, sv_off = (size_t)tA * B * N * d;
+    auto Xs = [&](int l) { return use_saved ? r->saved_acts + (size_t)l * sv_rows * d + sv_off : c.at(c.pl.Xs) + (size_t)l * M * d; };
     auto QKVl = [&](int l) { return c.at(c.pl.QKV) + (size_t)l * M * 3 * d; };
-    auto Al = [&](int l) { return c.at(c.pl.A) + (size_t)l * M * d; };
+    auto Al = [&](int l) { return use_saved ? r->saved_acts + (size_t)(L + 1 + l) * sv_rows * d + sv_off : c.at(c.pl.A) + (size_t)l * M * d; };
     auto U1l = [&](int l) { return c.at(c.pl.U1) + (size_t)l * M * d; };
     auto X1l = [&](int l) { return c.at(c.pl.X1) + (size_t)l * M * d; };
     auto Hidl = [&](int l) { return c.at(c.pl.Hid) + (size_t)l * M * F; };
@@ -1696,7 +1721,9 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     float *dTmp = c.at(c.pl.dTmp), *dQKV = c.at(c.pl.dQKV), *dHid = c.at(c.pl.dHid);
 
     // ---- forward recompute, saving what the backward needs --------------------------------------------
-    if (do_emb && do_enc) {
+    if (use_saved) {
+      // (X_0 is in the saved rows too)
+    } else if (do_emb && do_enc) {
       if (d % 4 == 0) hipLaunchKernelGGL(assemble4_kernel, grid1d((size_t)M * d / 4), dim3(256), 0, c.st, g, d, Ex, Ey, P, m->theta_tokens, Xs(0));
       else
       hipLaunchKernelGGL(assemble_kernel, grid1d((size_t)M * d), dim3(256), 0, c.st, g, d, Ex, Ey, P,
@@ -1723,6 +1750,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, KVl(l), 2 * d, I * max_keys, 2 * d, d, false);
         ka.row_index = keyidx;
         TRY(launch_gemm(bwd_prec(), ka, 1, c.st));
+      }
+      if (use_saved) {      // a and the layer's output are in the saved rows; without the fused attention block its backward reads QKV
+        if (!ckv) TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
+        continue;
       }
       if (ckv && ft && !dbg(ALINE_DBG_NO_BWD_LAYER_FWD)) {      // the rest of the layer in one kernel (layer_fwd.h): Xs(l) -> Al(l), Xs(l + 1)
         lfwd::Args fa{};
@@ -1868,8 +1899,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         hipLaunchKernelGGL((gmm_bwd128_kernel<10, 128>), dim3((unsigned)((a.rows + 127) / 128)), dim3(256), 0, c.st, a);
       else if (F == 128 && !dbg(ALINE_DBG_NO_BWD_GMM128))
         hipLaunchKernelGGL((gmm_bwd128_kernel<16, GMM_BWD_ROWS>), dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
+      else if (F > 128 && C <= 16 && !dbg(ALINE_DBG_NO_BWD_GMM_WIDE))
+        hipLaunchKernelGGL(gmm_bwd_wide_kernel, dim3((unsigned)((a.rows + GMM_WIDE_ROWS - 1) / GMM_WIDE_ROWS)), dim3(256), 0, c.st, a);
       else
-      hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
+        hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();
       float *Wt = c.at(c.pl.Wt);   // [d, C*F]: column block k = W1_k^T
       if (F == 128 && d % 32 == 0 && !dbg(ALINE_DBG_NO_BWD_GMM_BATCHED)) {

@@ -588,6 +588,83 @@ __global__ __launch_bounds__(256) void gmm_bwd_kernel(GmmBwdArgs a) {
   if (threadIdx.x < a.C * 3) atomicAdd(a.db2[threadIdx.x / 3] + threadIdx.x % 3, red[16 * 3 * 128 + threadIdx.x]);
 }
 
+// The same for F > 128 (the d = 256 / 512 models: F = 1024 ...), where gmm_bwd_kernel falls back to one global atomic per (row, component,
+// hidden unit, output) -- 1.8e9 atomics and 15 ms per call at d = 256 / F = 1024 / 60 000 rows, 28 % of that model's training step.
+// Two passes per workgroup of 64 rows: (1) a wave per row: raw head outputs, responsibilities, d ll / d raw of every component -> LDS;
+// (2) a thread per hidden unit (f = tid, tid + 256, ...): for every component, the weight-gradient partials of its units summed over the
+// rows in registers (one atomic per element and workgroup) and the hidden gradient written in place -- hidden rows are read coalesced.
+constexpr int GMM_WIDE_ROWS = 64;
+__global__ __launch_bounds__(256) void gmm_bwd_wide_kernel(GmmBwdArgs a) {
+  __shared__ float dsh[GMM_WIDE_ROWS][3][16];
+  __shared__ float pbs[16 * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r_lo = (long)blockIdx.x * GMM_WIDE_ROWS, r_hi = min(a.rows, r_lo + GMM_WIDE_ROWS);
+  if (threadIdx.x < 48) pbs[threadIdx.x] = 0.f;
+  __syncthreads();
+  float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;      // lane c: bias gradients of component c
+  for (long row = r_lo + wave; row < r_hi; row += 4) {
+    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      const float *hp = a.hid + (row * a.C + c) * a.F;
+      const float *w = a.w2[c];
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      for (int f = lane; f < a.F; f += 64) {
+        const float hv = hp[f];
+        s0 = fmaf(hv, w[f], s0); s1 = fmaf(hv, w[a.F + f], s1); s2 = fmaf(hv, w[2 * a.F + f], s2);
+      }
+      s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+      if (lane == c) { raw0 = s0 + a.b2[c][0]; raw1 = s1 + a.b2[c][1]; raw2 = s2 + a.b2[c][2]; }
+    }
+    const bool act = lane < a.C;
+    const float mean = raw0, sd = softplus_f(raw1) + a.std_min;
+    const float mxw = wave_max(act ? raw2 : -INFINITY);
+    const float ew = act ? __expf(raw2 - mxw) : 0.f;
+    const float wgt = ew / wave_sum(ew);
+    const float v = a.value[row % a.value_mod];
+    const float z = (v - mean) / sd;
+    const float lp = act ? (-0.5f * z * z - logf(sd) - 0.91893853320467274178f + logf(wgt)) : -INFINITY;
+    const float m2 = wave_max(lp);
+    const float er = act ? __expf(lp - m2) : 0.f;
+    const float resp = er / wave_sum(er);
+    const float gl = a.g_ll ? a.g_ll[row] : 0.f;
+    float d0 = act ? gl * resp * z / sd : 0.f;
+    float dsd = act ? gl * resp * (z * z - 1.f) / sd : 0.f;
+    float d2 = act ? gl * (resp - wgt) : 0.f;
+    if (a.g_mean && act) d0 += a.g_mean[row * a.C + lane];
+    if (a.g_std && act) dsd += a.g_std[row * a.C + lane];
+    if (a.g_wgt) {
+      const float gw = act ? a.g_wgt[row * a.C + lane] : 0.f;
+      const float dot = wave_sum(gw * wgt);
+      if (act) d2 += wgt * (gw - dot);
+    }
+    const float d1 = dsd * (1.f / (1.f + __expf(-raw1)));
+    pb0 += d0; pb1 += d1; pb2 += d2;
+    if (lane < 16) { dsh[row - r_lo][0][lane] = d0; dsh[row - r_lo][1][lane] = d1; dsh[row - r_lo][2][lane] = d2; }
+  }
+  if (lane < a.C) { atomicAdd(&pbs[lane * 3 + 0], pb0); atomicAdd(&pbs[lane * 3 + 1], pb1); atomicAdd(&pbs[lane * 3 + 2], pb2); }
+  __syncthreads();
+  const int nrow = (int)(r_hi - r_lo);
+  for (int c = 0; c < a.C; ++c) {
+    const float *w = a.w2[c];
+    for (int f = threadIdx.x; f < a.F; f += 256) {
+      const float w0 = w[f], w1 = w[a.F + f], w2 = w[2 * a.F + f];
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+      float *hp = a.hid + ((long)r_lo * a.C + c) * a.F + f;
+      for (int rr = 0; rr < nrow; ++rr, hp += (long)a.C * a.F) {
+        const float hv = *hp, g0 = dsh[rr][0][c], g1 = dsh[rr][1][c], g2 = dsh[rr][2][c];
+        if (hv > 0.f) {
+          p0 = fmaf(g0, hv, p0); p1 = fmaf(g1, hv, p1); p2 = fmaf(g2, hv, p2);
+          *hp = g0 * w0 + g1 * w1 + g2 * w2;
+        } else {
+          *hp = 0.f;
+        }
+      }
+      atomicAdd(a.dw2[c] + f, p0); atomicAdd(a.dw2[c] + a.F + f, p1); atomicAdd(a.dw2[c] + 2 * a.F + f, p2);
+    }
+  }
+  if (threadIdx.x < a.C * 3) atomicAdd(a.db2[threadIdx.x / 3] + threadIdx.x % 3, pbs[threadIdx.x]);
+}
+
 // The same for F = 128 (lane owns hidden units lane, lane + 64), written around the latency of a row: gmm_bwd_kernel walks the
 // components of a row one after the other, every one with its own global loads (twice) and its own cross-lane reductions:
 // ~25 us per row on the one wave per SIMD its 424 registers allow (1.65 ms per call at the headline shape, VALU busy 9 %).

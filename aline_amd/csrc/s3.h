@@ -383,12 +383,15 @@ struct StepArgs {
   float *logits; int NP;           // logits[b * NP + row]
   u32x4 *zimg; long zrow0;         // dense-row image of the target rows of all steps (null: not wanted)
   u32x4 *zq; long zq_row0;         // dense-row image of the P point rows of all steps (null: posterior_out_query not wanted)
+  float *sv; long sv_rows, sv_row0;   // aline_rollout.saved_acts (null: not wanted): [2 L + 1][sv_rows][32] fp32; this step's rows start at sv_row0
 #ifdef S3_STAMPS
   unsigned long long *stamps;      // [8 waves][S3_NSTAMP] of workgroup 0
 #endif
 };
 
-template <int F, int NW, int MAXNKP, bool PREFETCH>
+// SAVE: the instantiation of training rollouts (StepArgs.sv: layer inputs / attention outputs kept for the backward); the inference
+// instantiation carries none of its registers or branches.
+template <int F, int NW, int MAXNKP, bool PREFETCH, bool SAVE = false>
 __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const Geo &G = a.g;
@@ -570,6 +573,13 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         split_frag(y0 * WINV + ld4(bq + 4 * g), y1 * WINV + ld4(bq + 16 + 4 * g), qh, ql);
       }
       S3_LAP(3);
+      // training rollouts: the layer's input and (below) attention output of the tile's rows as fp32 rows, for the backward
+      float *svrow = (SAVE && a.sv && r < G.N) ? a.sv + (a.sv_row0 + (long)b * G.N + r) * D + 4 * g : nullptr;
+      if (svrow) {
+        float *px = svrow + (long)l * a.sv_rows * D;
+        *reinterpret_cast<f32x4 *>(px) = frag_value(xh, xl, 0);
+        *reinterpret_cast<f32x4 *>(px + 16) = frag_value(xh, xl, 1);
+      }
       f32x4 o[2];
       {
         const char *kv = lds + KV_OFF + e * kv_ep + lane * 16;
@@ -594,6 +604,11 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       asm volatile("" :: "v"(o[0]), "v"(o[1]));
 #endif
       S3_LAP(4);
+      if (svrow) {
+        float *pa = svrow + (long)(a.L + 1 + l) * a.sv_rows * D;
+        *reinterpret_cast<f32x4 *>(pa) = o[0];
+        *reinterpret_cast<f32x4 *>(pa + 16) = o[1];
+      }
       // X1 = LN1(X + bo + Wo A)
       f32x4 x1a, x1b;
       f16x8 x1h, x1l;
@@ -650,6 +665,11 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
         a.XW[xpiece(tl, 0, lane)] = __builtin_bit_cast(u32x4, oh);
         a.XW[xpiece(tl, 1, lane)] = __builtin_bit_cast(u32x4, ol);
       } else {
+        if (svrow) {      // X_L: what the heads read (the fp32 value of the split pair they are given)
+          float *px = svrow + (long)a.L * a.sv_rows * D;
+          *reinterpret_cast<f32x4 *>(px) = frag_value(oh, ol, 0);
+          *reinterpret_cast<f32x4 *>(px + 16) = frag_value(oh, ol, 1);
+        }
         if (a.zimg && r >= G.P && r < G.N) {
           const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
           a.zimg[xpiece(zr >> 4, 0, 16 * g + (int)(zr & 15))] = __builtin_bit_cast(u32x4, oh);

@@ -86,9 +86,9 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
       KvArgs ka{};
       ka.g = c.g; ka.tpe = tpe; ka.nkt2 = nkt2; ka.X = KX; ka.img = img + l * lw; ka.F = F; ka.keyrow = keyrow; ka.kcnt = kcnt; ka.KV = KV;
       ka.ngroups = (int)(((long)r->B * nkt2 + WAVES - 1) / WAVES);
-      // (fewer groups of key tiles than half the CUs: one job -- K | V x channel half -- per workgroup, so that every CU streams)
+      // (groups of key tiles that do not fill the chip: one job -- K | V x channel half -- per workgroup, so that every CU streams)
       constexpr int NJ = 2 * CPK;
-      if (ka.ngroups * NJ <= 2 * cus)
+      if ((ka.ngroups * NJ + cus - 1) / cus < NJ * ((ka.ngroups + cus - 1) / cus))      // fewer chunk passes per CU when split
         hipLaunchKernelGGL(kv_split_kernel, dim3((unsigned)(std::min(ka.ngroups, std::max(1, cus / NJ)) * NJ)), dim3(THREADS), smem_kv, c.st, ka);
       else
         hipLaunchKernelGGL(kv_all_kernel, dim3((unsigned)std::min(ka.ngroups, cus)), dim3(THREADS), smem_kv, c.st, ka);

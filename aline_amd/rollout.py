@@ -19,7 +19,7 @@ class Rollout:
 
     def __init__(self, model, batch, T, select="argmax", forced_idx=None, uniform=None,
                  time_token_T=0, keep_zt=False, keep_posterior=True, time_token_reverse=False,
-                 keep_query_posterior=False):
+                 keep_query_posterior=False, keep_acts=False):
         self.model = model
         self.m = model.model_struct()
         g = _native._get
@@ -86,6 +86,14 @@ class Rollout:
                                                   _lib.ptr(self.post_weight))
         r.postq_mean, r.postq_std, r.postq_weight = (_lib.ptr(self.postq_mean), _lib.ptr(self.postq_std),
                                                      _lib.ptr(self.postq_weight))
+        # training rollouts: the encoder layers' inputs and attention outputs of every (step, episode, row), kept for the backward
+        # (aline_rollout.saved_acts: the s3 path writes them, aline_rollout_backward reads them instead of recomputing the layers)
+        self.saved_acts = None
+        if keep_acts:
+            sb = _lib.lib.aline_rollout_saved_acts_bytes(C.byref(self.m), C.byref(r))
+            if sb:
+                self.saved_acts = torch.empty(sb // 4, dtype=torch.float32, device=dev)
+                r.saved_acts = self.saved_acts.data_ptr()
         nbytes = _lib.lib.aline_rollout_workspace_bytes(C.byref(self.m), C.byref(r))
         if nbytes == 0:
             raise RuntimeError("aline_amd: unsupported model/batch configuration")

@@ -232,7 +232,7 @@ def _sampled_rollout(model, batch, T):
     import os
     global _GRAPH_OK, _GRAPH_MISSES
     if os.environ.get("ALINE_TRAIN_GRAPH", "1") == "0" or not _GRAPH_OK:
-        return Rollout(model, batch, T, select="sample").run()
+        return Rollout(model, batch, T, select="sample", keep_acts=True).run()
     g = lambda k: batch.get(k) if isinstance(batch, dict) else getattr(batch, k, None)    # noqa: E731
     tens = {k: g(k) for k in ("context_x", "context_y", "query_x", "query_y", "target_all", "target_x", "target_mask")}
     prm = list(model.parameters())
@@ -242,7 +242,7 @@ def _sampled_rollout(model, batch, T):
     if ro is None:
         _GRAPH_MISSES += 1
         if _GRAPH_MISSES > _MAX_GRAPHS:          # thrashing: eager launches (+0.3 ms) beat a warm-up run + a capture per step
-            return Rollout(model, batch, T, select="sample").run()
+            return Rollout(model, batch, T, select="sample", keep_acts=True).run()
         if len(_ROLLOUT_GRAPHS) >= _MAX_GRAPHS:
             _ROLLOUT_GRAPHS.pop(next(iter(_ROLLOUT_GRAPHS)))         # least recently used
         try:
@@ -252,13 +252,13 @@ def _sampled_rollout(model, batch, T):
                     own[k] = _own(own[k])
             if torch.is_tensor(own.get("target_mask")):
                 own["target_mask"] = own["target_mask"].clone()
-            ro = Rollout(model, own, T, select="sample").capture()
+            ro = Rollout(model, own, T, select="sample", keep_acts=True).capture()
         except RuntimeError as e:                   # a runtime that refuses the capture: eager launches from now on
             import warnings
             warnings.warn(f"aline_amd: HIP-graph capture of the training rollout failed ({e}); using eager launches")
             _GRAPH_OK = False
             torch.cuda.synchronize()
-            return Rollout(model, batch, T, select="sample").run()
+            return Rollout(model, batch, T, select="sample", keep_acts=True).run()
     else:
         _GRAPH_MISSES = 0
         torch.cat([_lib.f32(tens["context_x"]), _lib.f32(tens["query_x"])], dim=1, out=ro.px)
@@ -305,7 +305,7 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
         flat, gstruct = flat_grads(model)
         flat.zero_()
         if forced_idx is not None:
-            ro = Rollout(model, batch, T, select="forced", forced_idx=forced_idx).run()
+            ro = Rollout(model, batch, T, select="forced", forced_idx=forced_idx, keep_acts=True).run()
         else:
             ro = _sampled_rollout(model, batch, T)
         _post_range_status(ro)

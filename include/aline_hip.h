@@ -28,7 +28,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define ALINE_ABI_VERSION 3
+#define ALINE_ABI_VERSION 4
 #define ALINE_MAX_LAYERS 8
 #define ALINE_MAX_COMPONENTS 16
 #define ALINE_MAX_POINTS 4096     /* P = n_ctx0 + n_query0 of a rollout / n_ctx + n_query of a step (README.md:45,50 evaluate at n_query = 2000) */
@@ -140,6 +140,12 @@ typedef struct aline_rollout {
    * a step hold unspecified values there.  NULL = not computed (no caller in train_aline.py / utils/eval.py reads
    * it).  Served by the s3 and generic paths (a request routes the rollout to one of them). */
   float *postq_mean, *postq_std, *postq_weight;
+  /* Training rollouts: [2 L + 1][T * B * N * d] floats -- the encoder layers' inputs X_0 .. X_L, then their attention outputs
+   * A_0 .. A_{L-1}, row (t * B + b) * N + token row -- written by aline_rollout_forward when non-NULL (s3 path; other paths leave it
+   * alone) and read by aline_rollout_backward[_ex] INSTEAD of recomputing the layers of the rollout it is handed (fused small-width
+   * backward; the caller passes the struct the forward ran with).  aline_rollout_saved_acts_bytes sizes it (0: this (m, r) cannot
+   * use it).  NULL: the backward recomputes. */
+  float *saved_acts;
 } aline_rollout;
 
 /* ABI / build info. */
@@ -180,6 +186,7 @@ enum { ALINE_PATH_GENERIC = 0,   /* stage kernels + GEMMs, any configuration */
        ALINE_PATH_S3 = 4,        /* s3.h: d = 32, F16X3, any embedding mode, one launch per design step */
        ALINE_PATH_X5 = 5 };      /* x3.h, namespace x5: d = 512 / 8 heads of 64, F16X3 (the psychometric configuration's width) */
 int aline_rollout_path(const aline_model *m, const aline_rollout *r);
+size_t aline_rollout_saved_acts_bytes(const aline_model *m, const aline_rollout *r);   /* see aline_rollout.saved_acts */
 /* Name (as rocprofv3 prints it, template arguments included) of the dominant kernel of that path for (m, r) -- the launch
  * the ev_kernel_start / ev_kernel_stop pair brackets -- written to buf; returns the ALINE_PATH_* value or a negative code. */
 int aline_rollout_kernel_name(const aline_model *m, const aline_rollout *r, char *buf, size_t n);
@@ -303,7 +310,9 @@ enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off 
        ALINE_DBG_NO_BWD_LAYER_FWD = 1u << 19, ALINE_DBG_NO_BWD_LAYER_FWD_FLAT = 1u << 20,
        ALINE_DBG_NO_BWD_GMM_FUSED = 1u << 21, ALINE_DBG_NO_BWD_GMM128 = 1u << 22, ALINE_DBG_NO_BWD_GMM_BATCHED = 1u << 23,
        ALINE_DBG_NO_BWD_ATTN_MFMA = 1u << 24,
-       ALINE_DBG_X3_LEGACY_HEAD = 1u << 25 };  /* x3: acquisition logits by the stand-alone head kernel */
+       ALINE_DBG_X3_LEGACY_HEAD = 1u << 25,    /* x3: acquisition logits by the stand-alone head kernel */
+       ALINE_DBG_NO_BWD_GMM_WIDE = 1u << 26,   /* GMM head backward at F > 128: the per-row-atomics kernel instead of gmm_bwd_wide_kernel */
+       ALINE_DBG_NO_BWD_SAVED_ACTS = 1u << 27 }; /* backward: recompute the layers even when aline_rollout.saved_acts is given */
 uint32_t aline_debug_set_flags(uint32_t flags);
 uint32_t aline_debug_get_flags(void);
 /* Integer knobs of the same kind (0 = automatic): launch shape of the s3 step kernel, precision of the backward GEMMs. */

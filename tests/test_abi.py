@@ -37,7 +37,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_errors(lib):
     lib.aline_abi_version.restype = ctypes.c_int
-    assert lib.aline_abi_version() == 3
+    assert lib.aline_abi_version() == 4
     lib.aline_error_string.restype = ctypes.c_char_p
     assert lib.aline_error_string(0) == b"ok"
     assert b"workspace" in lib.aline_error_string(-3)
@@ -67,12 +67,12 @@ def test_debug_word_and_kernel_name(lib):
     r.B, r.P, r.n_ctx0, r.n_target_data, r.T = 1000, 201, 1, 0, 30
     buf = ctypes.create_string_buffer(128)
     assert L.aline_rollout_kernel_name(ctypes.byref(m), ctypes.byref(r), buf, 128) == 4
-    assert buf.value == b"s3::step_kernel<128, 12, 2, false>"
+    assert buf.value == b"s3::step_kernel<128, 12, 2, false, false>"
     with _lib.debug("DISABLE_S3"):
         assert L.aline_rollout_path(ctypes.byref(m), ctypes.byref(r)) == 0
     with _lib.debug(S3_WAVES=16):
         L.aline_rollout_kernel_name(ctypes.byref(m), ctypes.byref(r), buf, 128)
-        assert buf.value == b"s3::step_kernel<128, 16, 2, false>"
+        assert buf.value == b"s3::step_kernel<128, 16, 2, false, false>"
     with _lib.debug_env({"ALINE_DISABLE_S3": "1", "ALINE_BWD_TAIL": "0"}):
         assert L.aline_debug_get_flags() == _lib.DBG["DISABLE_S3"] | _lib.DBG["NO_BWD_TAIL"]
     assert L.aline_debug_get_flags() == 0
@@ -81,7 +81,7 @@ def test_debug_word_and_kernel_name(lib):
     m.n_theta, m.embedding_type = 3, 2
     r.B = 512
     L.aline_rollout_kernel_name(ctypes.byref(m), ctypes.byref(r), buf, 128)
-    assert buf.value == b"s3::step_kernel<128, 8, 5, false>"
+    assert buf.value == b"s3::step_kernel<128, 8, 5, false, false>"
     assert L.aline_debug_set_param(99, 1) == -1
     assert L.aline_f16_range_offset() == 0
     # every enumerator of the header's ALINE_DBG_* list has the value the Python mirror uses

@@ -209,6 +209,92 @@ def test_fused_backward_kernels_match_per_op_pipeline(T, B):
     assert worst[1] < 2e-4, worst
 
 
+@pytest.mark.parametrize("d,F,H,B,T,nq", [(64, 256, 4, 70, 3, 20), (256, 1024, 8, 5, 2, 12)])
+def test_wide_gmm_head_backward_matches_the_per_row_kernel(d, F, H, B, T, nq):
+    """GMM head backward at F > 128 (the d = 256 / 512 models): `gmm_bwd_wide_kernel` (d ll / d raw per row into LDS, then weight-gradient
+    partials per hidden unit in registers, one atomic per element and workgroup) against `gmm_bwd_kernel`'s per-row atomics it replaces
+    (15 ms per call at d = 256 / F = 1024) -- every gradient of the model, same rollout, same upstream gradients; 70 episodes x 2 targets
+    are more rows than one 64-row workgroup."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd.train import backward, reinforce_terms
+    torch.manual_seed(9)
+    model = Aline(Embedder(2, 1, d, F, 2, "theta"), Encoder(d, F, H, 0.0, 2), OutputHead(2, 1, d, F)).cuda()
+    batch = HiddenLocation(n_query_init=nq).sample_batch(B)
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        terms = reinforce_terms(ro, "theta")
+        grads = []
+        for flags in ([], ["NO_BWD_GMM_WIDE"]):
+            with _lib.debug(*flags):
+                for p in model.parameters():
+                    p.grad = None
+                backward(model, ro, terms["g_logp"], terms["g_ll"])
+                torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    worst = ("", 0.0)
+    floor = 1e-2 * max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[0]:
+        ref = grads[1][k]
+        assert torch.isfinite(grads[0][k]).all(), k
+        err = float((grads[0][k] - ref).abs().max()) / max(float(ref.abs().max()), floor)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 2e-4, worst       # the same fp32 products in another summation order
+
+
+@pytest.mark.parametrize("emb,T,B,kw", [("theta", 30, 24, {}), ("theta", 9, 7, {"t_chunk": 4}), ("mix", 12, 6, {"n_td": 100}), ("mix", 8, 5, {"n_td": 20, "mask": "split"})])
+def test_backward_from_the_activations_the_s3_rollout_saved(emb, T, B, kw):
+    """aline_rollout.saved_acts: the training rollout on the s3 path writes every layer's input and attention output (fp32 rows) and
+    the backward reads them instead of recomputing the layers (layer_fwd.h / the per-op recompute).  Same rollout, same upstream
+    gradients, against the recomputing backward (NO_BWD_SAVED_ACTS): the saved values are the f16x3 forward's (fp32-grade), the
+    recomputed ones exact fp32 -- gradients agree to the reference-precision bound; with more than 48 keys (mix mode, 100 data
+    targets) the per-op attention backward runs on the saved rows too; a chunked backward (t_chunk < T) reads its slice."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import GPTask, HiddenLocation
+    from aline_amd.train import backward, reinforce_terms
+    from aline_amd.utils import create_target_mask
+    torch.manual_seed(12)
+    if emb == "theta":
+        model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda()
+        batch = HiddenLocation(n_query_init=60).sample_batch(B)
+        mask_type = "all"
+    else:
+        n_td = kw["n_td"]
+        model = Aline(Embedder(2, 1, 32, 128, 3, "mix"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda()
+        batch = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=40, n_target_theta=3, n_target_data=n_td,
+                       device=torch.device("cuda")).sample_batch(B)
+        mask_type = kw.get("mask", "all")
+        if mask_type == "split":
+            batch["target_mask"] = create_target_mask("split", "mix", n_td, 3, None, None, None, None, "data")
+    model.set_precision("f16x3").train()
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample", keep_acts=True)
+        assert ro.path == "s3::step_kernel" and ro.saved_acts is not None
+        ro.run()
+        assert torch.isfinite(ro.saved_acts).all()
+        terms = reinforce_terms(ro, emb, mask_type)
+        grads = []
+        for flags in ([], ["NO_BWD_SAVED_ACTS"]):
+            with _lib.debug(*flags):
+                for p in model.parameters():
+                    p.grad = None
+                backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=kw.get("t_chunk"))
+                torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    worst = ("", 0.0)
+    floor = 1e-2 * max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[0]:
+        ref = grads[1][k]
+        assert torch.isfinite(grads[0][k]).all(), k
+        err = float((grads[0][k] - ref).abs().max()) / max(float(ref.abs().max()), floor)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 5e-4, worst
+
+
 @pytest.mark.parametrize("T,B,n_td", [(12, 8, 100), (50, 4, 100), (20, 6, 40)])
 def test_fused_backward_kernels_at_the_cfg3_key_counts(T, B, n_td):
     """BASELINE configs[2] (al_mix dx = 2: 100 target points + 3 theta tokens among the keys, split mask): up to 1 + 49 + 103 = 153
