@@ -467,3 +467,46 @@ def test_fused_backward_kernels_in_mix_mode_with_target_data_keys(mask, B):
                 worst = (k, err)
             off += n
         assert worst[1] < 2e-4, (name, worst, len(deltas), flips)
+
+
+@pytest.mark.parametrize("d,F,H", [(64, 256, 8), (128, 192, 4)])
+def test_per_op_backward_of_wider_models_against_the_fp64_oracle(d, F, H):
+    """The backward of the model widths that have no fused kernels (what `d256.train_step` of the bench line runs: exact-fp32 GEMMs,
+    LayerNorm / attention backward kernels at head_dim 8 and 32, `gmm_bwd_wide_kernel` at F > 128) against fp64 autograd of the oracle
+    on the same designs and upstream gradients, with the knife-edge ReLU arbitration of the test above."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd.train import backward, reinforce_terms
+    torch.manual_seed(21)
+    model = Aline(Embedder(2, 1, d, F, 2, "theta"), Encoder(d, F, H, 0.0, 2), OutputHead(2, 1, d, F)).cuda()
+    batch = HiddenLocation(n_query_init=30).sample_batch(6)
+    T = 5
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        terms = reinforce_terms(ro, "theta", "all")
+        backward(model, ro, terms["g_logp"], terms["g_ll"])
+        torch.cuda.synchronize()
+    g = {k: p.grad.cpu().double() for k, p in model.named_parameters()}
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    cpu = {k: (v.cpu().double() if v.is_floating_point() else v.cpu()) for k, v in batch.items() if torch.is_tensor(v)}
+    cfg = dict(embedding_type="theta", n_head=H, num_layers=2, num_components=10, std_min=1e-4, n_target_theta=2)
+    g0, deltas, ref, n_gates = _oracle_gradients_with_gate_flips(sd, cpu, cfg, T, ro.idx.cpu(), "all", terms["g_logp"].cpu().double(),
+                                                              terms["g_ll"].cpu().double(), eps=5e-6)
+    assert float((ro.target_ll.cpu().double() - torch.stack(ref["target_ll"]).detach()).abs().max()) < 1e-4
+    assert len(deltas) <= 64, (len(deltas), n_gates)
+    flat = torch.cat([g[k].reshape(-1) for k in sd])
+    res = flat - g0
+    if deltas:
+        D = torch.stack(deltas, 1)
+        c = torch.linalg.lstsq(D, res.unsqueeze(1)).solution.squeeze(1)
+        res = res - D @ (c > 0.5).double()
+    floor = 1e-2 * float(g0.abs().max())
+    worst, off = ("", 0.0), 0
+    for k, v in sd.items():
+        n = v.numel()
+        err = float(res[off:off + n].abs().max()) / max(float(g0[off:off + n].abs().max()), floor)
+        if err > worst[1]:
+            worst = (k, err)
+        off += n
+    assert worst[1] < 2e-4, (worst, len(deltas))
