@@ -1418,9 +1418,18 @@ extern "C" int aline_f16_range_status(const void *ws, void *stream) {
 // (3-term f16 split) was measured and is NOT used: upstream gradients are ~1e-8 .. 1e-5 (1 / (T B n_t) scaling), below
 // f16's normal range, so the split loses them (tests/test_backward_gpu.py fails), and the step is bound by HBM traffic of
 // the saved activations, not by the matrix pipe (67.7 -> 66.9 ms).
+// The forward RECOMPUTE products of the per-op backward (activations x weights, exactly the products of the forward pass) take the
+// forward's own arithmetic when that is the 3-term f16 split and the model is wide enough to be bound by its GEMMs (d >= 64: the
+// small-width model has its fused exact-fp32 kernels and per-op A/B tests against them): 3 passes on the f16 pipe instead of the
+// fp32 MFMA -- the recompute GEMMs were 40 % of the d = 256 training step.  The gradient products (dX, dW) stay exact fp32.
+static int recompute_prec(const aline_model &m);
 static int bwd_prec() {
   const int p = dbg_param(ALINE_DBG_BWD_PREC);
   return (p < 0 || p > 3) ? ALINE_PREC_F32 : p;
+}
+
+static int recompute_prec(const aline_model &m) {
+  return (m.precision == ALINE_PREC_F16X3 && m.d >= 64 && !dbg(ALINE_DBG_BWD_RECOMPUTE_F32)) ? ALINE_PREC_F16X3 : bwd_prec();
 }
 
 namespace {
@@ -1690,11 +1699,11 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
   hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_x * F), dim3(256), 0, c.st, xs, P + n_td, B,
                      m->dim_x, F, m->x_w1, m->x_b1, EHx);
   CHECK_LAUNCH();
-  TRY(launch_gemm(bwd_prec(), gemm_args(EHx, F, m->x_w2, m->x_b2, F, Ex, d, rows_x, d, F, false), 1, c.st));
+  TRY(launch_gemm(recompute_prec(*m), gemm_args(EHx, F, m->x_w2, m->x_b2, F, Ex, d, rows_x, d, F, false), 1, c.st));
   hipLaunchKernelGGL(embed_hidden_kernel, grid1d((size_t)rows_y * F), dim3(256), 0, c.st, ys, P, B, m->dim_y,
                      F, m->y_w1, m->y_b1, EHy);
   CHECK_LAUNCH();
-  TRY(launch_gemm(bwd_prec(), gemm_args(EHy, F, m->y_w2, m->y_b2, F, Ey, d, rows_y, d, F, false), 1, c.st));
+  TRY(launch_gemm(recompute_prec(*m), gemm_args(EHy, F, m->y_w2, m->y_b2, F, Ey, d, rows_y, d, F, false), 1, c.st));
   CHECK_LAUNCH();
   (void)hipMemsetAsync(c.at(c.pl.dEx), 0, (size_t)rows_x * d * sizeof(float), c.st);
   (void)hipMemsetAsync(c.at(c.pl.dEy), 0, (size_t)rows_y * d * sizeof(float), c.st);
@@ -1749,10 +1758,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       if (ckv) {      // K / V of the key rows: row-gather GEMM on the key list
         GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, KVl(l), 2 * d, I * max_keys, 2 * d, d, false);
         ka.row_index = keyidx;
-        TRY(launch_gemm(bwd_prec(), ka, 1, c.st));
+        TRY(launch_gemm(recompute_prec(*m), ka, 1, c.st));
       }
       if (use_saved) {      // a and the layer's output are in the saved rows; without the fused attention block its backward reads QKV
-        if (!ckv) TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
+        if (!ckv) TRY(launch_gemm(recompute_prec(*m), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
         continue;
       }
       if (ckv && ft && !dbg(ALINE_DBG_NO_BWD_LAYER_FWD)) {      // the rest of the layer in one kernel (layer_fwd.h): Xs(l) -> Al(l), Xs(l + 1)
@@ -1775,10 +1784,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         continue;
       }
       if (ckv) {
-        TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, Qbuf, d, (int)M, d, d, false), 1, c.st));
+        TRY(launch_gemm(recompute_prec(*m), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, Qbuf, d, (int)M, d, d, false), 1, c.st));
         TRY(launch_attention<8>(fc, Qbuf, Al(l), max_keys, KVl(l), kcnt));
       } else {
-      TRY(launch_gemm(bwd_prec(), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
+      TRY(launch_gemm(recompute_prec(*m), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
       switch (hd) {
         case 4: TRY(launch_attention<4>(fc, QKVl(l), Al(l), max_keys)); break;
         case 8: TRY(launch_attention<8>(fc, QKVl(l), Al(l), max_keys)); break;
@@ -1789,10 +1798,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       }
       }
       if (ft) { TRY(launch_tail(c, l, Xs(l), Al(l), Xs(l + 1), nullptr, nullptr, nullptr, nullptr, M)); continue; }
-      TRY(launch_gemm(bwd_prec(), gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));
+      TRY(launch_gemm(recompute_prec(*m), gemm_args(Al(l), d, m->out_proj_w[l], m->out_proj_b[l], d, dTmp, d, (int)M, d, d, false), 1, c.st));
       TRY(launch_add_layernorm(c.st, Xs(l), dTmp, m->norm1_w[l], m->norm1_b[l], X1l(l), M, d, U1l(l)));
-      TRY(launch_gemm(bwd_prec(), gemm_args(X1l(l), d, m->lin1_w[l], m->lin1_b[l], d, Hidl(l), F, (int)M, F, d, true), 1, c.st));
-      TRY(launch_gemm(bwd_prec(), gemm_args(Hidl(l), F, m->lin2_w[l], m->lin2_b[l], F, dTmp, d, (int)M, d, F, false), 1, c.st));
+      TRY(launch_gemm(recompute_prec(*m), gemm_args(X1l(l), d, m->lin1_w[l], m->lin1_b[l], d, Hidl(l), F, (int)M, F, d, true), 1, c.st));
+      TRY(launch_gemm(recompute_prec(*m), gemm_args(Hidl(l), F, m->lin2_w[l], m->lin2_b[l], F, dTmp, d, (int)M, d, F, false), 1, c.st));
       TRY(launch_add_layernorm(c.st, X1l(l), dTmp, m->norm2_w[l], m->norm2_b[l], Xs(l + 1), M, d, U2l(l)));
     }
     const float *Z = do_enc ? Xs(L) : io.z_in;
@@ -1812,13 +1821,13 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         CHECK_LAUNCH();
         a.tvec = tvec; a.tvec_div = P; a.tcol = m->acq_w1 + d; a.tcol_stride = d + 1;
       }
-      TRY(launch_gemm(bwd_prec(), a, 1, c.st));
+      TRY(launch_gemm(recompute_prec(*m), a, 1, c.st));
       }
       if (!fgmm) {
       GemmArgs ag = gemm_args(Z, d, nullptr, nullptr, d, HidG, C * F, I * n_t, F, d, true);
       ag.R_in = n_t; ag.G_in = N; ag.off_in = P; ag.col_per_group = F;
       for (int k = 0; k < C; ++k) { ag.W[k] = m->gmm_w1[k]; ag.bias[k] = m->gmm_b1[k]; }
-      TRY(launch_gemm(bwd_prec(), ag, C, c.st));
+      TRY(launch_gemm(recompute_prec(*m), ag, C, c.st));
       }
       CHECK_LAUNCH();
     }
