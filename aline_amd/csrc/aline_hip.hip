@@ -575,6 +575,13 @@ static int launch_wide_block(const Ctx &c, wide::BlockArgs a) {
 }
 
 
+// The time token of step t (model.time_token): t / T as the training loop feeds it (train_aline.py:82); time_token_T < 0 selects the
+// schedule of the reference's evaluation loop, (T - t) / T (utils/eval.py:24)
+static float step_time_token(const aline_rollout &r, int t) {
+  const int TT = r.time_token_T > 0 ? r.time_token_T : r.time_token_T < 0 ? -r.time_token_T : r.T;
+  return r.time_token_T < 0 ? (float)(TT - t) / (float)TT : (float)t / (float)TT;
+}
+
 static int device_cus() {      // compute units of the CURRENT device (cached per device: a process may drive several)
   static std::atomic<int> cache[64] = {};
   int dev = 0, v = 0;
@@ -814,11 +821,7 @@ int aline_rollout_step(const aline_model *m, const aline_rollout *r, int t, void
   HeadIO io{};
   if (m->time_token) {
     float *sc = c.at(c.pl.scalar);
-    // t / T as the training loop feeds it (train_aline.py:82); time_token_T < 0 selects the schedule of the reference's
-    // evaluation loop, (T - t) / T (utils/eval.py:24)
-    const int TT = r->time_token_T > 0 ? r->time_token_T : r->time_token_T < 0 ? -r->time_token_T : r->T;
-    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, c.st, sc,
-                       r->time_token_T < 0 ? (float)(TT - t) / (float)TT : (float)t / (float)TT);
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, c.st, sc, step_time_token(*r, t));
     CHECK_LAUNCH();
     io.time_t = sc;
   }
@@ -1129,7 +1132,7 @@ extern "C++" {
 // launch per design step, a workgroup owns two whole episodes.
 static bool s3_eligible(const aline_model &m, const aline_rollout &r) {
   if (dbg(ALINE_DBG_DISABLE_S3)) return false;
-  if (m.precision != ALINE_PREC_F16X3 || m.d != s3::D || m.H != s3::H || m.F % 32 || m.F > s3::F_MAX || m.time_token) return false;
+  if (m.precision != ALINE_PREC_F16X3 || m.d != s3::D || m.H != s3::H || m.F % 32 || m.F > s3::F_MAX) return false;
   if (r.n_ctx0 < 1 || r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > s3::NK_MAX) return false;
   return true;
 }
@@ -1157,7 +1160,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
   for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
   unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.sImg));
-  pa.out = img; pa.range_flag = c.flag();
+  pa.out = img; pa.range_flag = c.flag(); pa.time_token = m->time_token ? 1 : 0;
   hipLaunchKernelGGL(s3::pack_kernel, dim3(256), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
   {   // step-invariant point embeddings (fp32 rows): x-embedder on the points + target-data rows, y-embedder on the points
@@ -1196,6 +1199,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     sa.zimg = want_gmm ? Zimg : nullptr; sa.zrow0 = (long)t * r->B * n_t;
     sa.zq = Zq; sa.zq_row0 = (long)t * r->B * r->P;
     sa.sv = r->saved_acts; sa.sv_rows = (long)r->T * r->B * N; sa.sv_row0 = (long)t * r->B * N;
+    sa.tau = m->time_token ? step_time_token(*r, t) : 0.f;
 #ifdef S3_STAMPS
     sa.stamps = want_gmm ? nullptr : reinterpret_cast<unsigned long long *>(c.at(c.pl.sRaw));
 #endif

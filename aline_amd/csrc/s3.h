@@ -78,6 +78,8 @@ struct PackArgs {
   const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
   unsigned *out;
   unsigned *range_flag;
+  int time_token;      // model.time_token: the acquisition head's W1 is [F, d + 1] (model/head.py:24-25); its last column goes to the
+                       // free slot [2 F, 3 F) of the head's parameters and is folded into the bias per step (StepArgs.tau)
 };
 
 __global__ void pack_kernel(PackArgs a) {
@@ -118,11 +120,13 @@ __global__ void pack_kernel(PackArgs a) {
       const float *w1 = k == 0 ? a.acq_w1 : a.gmm_w1[k - 1], *b1 = k == 0 ? a.acq_b1 : a.gmm_b1[k - 1];
       const float *w2 = k == 0 ? a.acq_w2 : a.gmm_w2[k - 1], *b2 = k == 0 ? a.acq_b2 : a.gmm_b2[k - 1];
       const int nout = k == 0 ? 1 : 3;
+      const int ldw1 = D + ((k == 0 && a.time_token) ? 1 : 0);
       if (o < nfw) {
-        v = x3::pair_word(w1, D, 16 * (int)(o / PAIR_WORDS), 0, (int)(o % PAIR_WORDS), WSCALE, a.range_flag);
+        v = x3::pair_word(w1, ldw1, 16 * (int)(o / PAIR_WORDS), 0, (int)(o % PAIR_WORDS), WSCALE, a.range_flag);
       } else {
         const int p = o - nfw;
-        const float f = p < F ? b1[p] : p < (1 + nout) * F ? w2[p - F] : (p >= 4 * F && p < 4 * F + nout) ? b2[p - 4 * F] : 0.f;
+        float f = p < F ? b1[p] : p < (1 + nout) * F ? w2[p - F] : (p >= 4 * F && p < 4 * F + nout) ? b2[p - 4 * F] : 0.f;
+        if (k == 0 && a.time_token && p >= 2 * F && p < 3 * F) f = w1[(long)(p - 2 * F) * ldw1 + D];      // the time column
         v = __float_as_uint(f);
       }
     }
@@ -383,6 +387,7 @@ struct StepArgs {
   float *logits; int NP;           // logits[b * NP + row]
   u32x4 *zimg; long zrow0;         // dense-row image of the target rows of all steps (null: not wanted)
   u32x4 *zq; long zq_row0;         // dense-row image of the P point rows of all steps (null: posterior_out_query not wanted)
+  float tau;                       // time token of this step (t / T or (T - t) / T: model/head.py:342-345), 0 without one
   float *sv; long sv_rows, sv_row0;   // aline_rollout.saved_acts (null: not wanted): [2 L + 1][sv_rows][32] fp32; this step's rows start at sv_row0
 #ifdef S3_STAMPS
   unsigned long long *stamps;      // [8 waves][S3_NSTAMP] of workgroup 0
@@ -457,6 +462,10 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   }
   wait_vmcnt<0>();
   __syncthreads();
+  if (a.tau != 0.f && tid < F) {      // W1 [z | t] = W1[:, :d] z + t W1[:, d]: the step's time token is a bias (read in the last layer, barriers away)
+    float *hp = reinterpret_cast<float *>(whd + head_pairs(F) * PAIR_BYTES);
+    hp[tid] = fmaf(a.tau, hp[2 * F + tid], hp[tid]);
+  }
   S3_LAP(0);
   float range_chk = 0.f;
 

@@ -17,7 +17,7 @@ static int launch_head(const Ctx &c, HeadArgs a) {
 static bool eligible(const aline_model &m, const aline_rollout &r) {
   if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
   if (dbg(ALINE_DBG_DISABLE_X3)) return false;
-  if (m.precision != ALINE_PREC_F16X3 || m.d != D || m.H != H || m.F % 32 || m.time_token) return false;
+  if (m.precision != ALINE_PREC_F16X3 || m.d != D || m.H != H || m.F % 32) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > WNK) return false;
   if ((size_t)NBUF * CHUNK_BYTES + (size_t)std::max(layer_params(m.F), head_lds_params(m.F)) * 4 > 160 * 1024) return false;
   return true;
@@ -47,7 +47,7 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
   pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
   for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
   unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.xImg));
-  pa.out = img; pa.range_flag = c.flag();
+  pa.out = img; pa.range_flag = c.flag(); pa.time_token = m->time_token ? 1 : 0;
   hipLaunchKernelGGL(pack_kernel, dim3(2048), dim3(256), 0, c.st, pa);
   CHECK_LAUNCH();
   // step-invariant point embeddings (fp32 rows; the generic GEMM runs the same 3-term f16 split)
@@ -113,6 +113,7 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
       HeadArgs ha{};
       ha.X = xin; ha.ntiles = tiles; ha.M = tiles * 16; ha.img = img + (long)m->L * lw; ha.F = F;
       ha.out = logits; ha.out_stride = 1; ha.out_off = 0;
+      ha.tau = m->time_token ? step_time_token(*r, t) : 0.f;
       TRY(launch_head<1>(c, ha));
     }
     SelectArgs sel{};

@@ -134,6 +134,8 @@ struct PackArgs {
   const float *gmm_w1[16], *gmm_b1[16], *gmm_w2[16], *gmm_b2[16];
   unsigned *out;
   unsigned *range_flag;
+  int time_token;      // model.time_token: the acquisition head's W1 is [F, d + 1] (model/head.py:24-25); its last column goes to the free
+                       // slot [2 F, 3 F) of that head's parameters and becomes a bias term per step (HeadArgs.tau)
 };
 
 // word e (0..511) of the pair (rows row0.., k-step ks) of the row-major weight W [*, K]: hi fragment, lo fragment
@@ -186,12 +188,14 @@ __global__ void pack_kernel(PackArgs a) {
       const float *w1 = k == 0 ? a.acq_w1 : a.gmm_w1[k - 1], *b1 = k == 0 ? a.acq_b1 : a.gmm_b1[k - 1];
       const float *w2 = k == 0 ? a.acq_w2 : a.gmm_w2[k - 1], *b2 = k == 0 ? a.acq_b2 : a.gmm_b2[k - 1];
       const int nout = k == 0 ? 1 : 3;
+      const int ldw1 = D + ((k == 0 && a.time_token) ? 1 : 0);
       if (o < nfw) {
         const int ch = o / CHUNK_WORDS, cw = o % CHUNK_WORDS, p = cw >> 9, e = cw & 511, q = 16 * (ch % W1C) + p;
-        v = pair_word(w1, D, 32 * (ch / W1C) + 16 * (q & 1), q >> 1, e, WSCALE, a.range_flag);
+        v = pair_word(w1, ldw1, 32 * (ch / W1C) + 16 * (q & 1), q >> 1, e, WSCALE, a.range_flag);
       } else {
         const int p = o - nfw;
-        const float f = p < a.F ? b1[p] : p < (1 + nout) * a.F ? w2[p - a.F] : (p >= 4 * a.F && p < 4 * a.F + nout) ? b2[p - 4 * a.F] : 0.f;
+        float f = p < a.F ? b1[p] : p < (1 + nout) * a.F ? w2[p - a.F] : (p >= 4 * a.F && p < 4 * a.F + nout) ? b2[p - 4 * a.F] : 0.f;
+        if (k == 0 && a.time_token && p >= 2 * a.F && p < 3 * a.F) f = w1[(long)(p - 2 * a.F) * ldw1 + D];      // the time column
         v = __float_as_uint(f);
       }
     }
@@ -1023,6 +1027,7 @@ struct HeadArgs {
   const u32x4 *X; long ntiles, M;
   const unsigned *img; int F, ngroups;
   float *out; int out_stride, out_off;
+  float tau;      // acquisition head with a time token: this step's t / T (b1 + tau W1[:, d] is the hidden layer's bias), else 0
 };
 template <int NOUT>
 __global__ __launch_bounds__(THREADS) void head_kernel(HeadArgs a) {
@@ -1033,7 +1038,7 @@ __global__ __launch_bounds__(THREADS) void head_kernel(HeadArgs a) {
   const int F = a.F;
   const float *gprm = reinterpret_cast<const float *>(a.img + (long)head_chunks(F) * CHUNK_WORDS);
   {
-    for (int i = tid; i < head_lds_params(F); i += THREADS) prm[i] = gprm[i];
+    for (int i = tid; i < head_lds_params(F); i += THREADS) prm[i] = (a.tau != 0.f && i < F) ? fmaf(a.tau, gprm[2 * F + i], gprm[i]) : gprm[i];
   }
   const char *wbase = reinterpret_cast<const char *>(a.img);
   auto st = make_stream([wbase](int s) { return wbase + (long)s * CHUNK_BYTES; }, lds, head_chunks(F), tid);

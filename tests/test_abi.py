@@ -236,8 +236,8 @@ def test_rollout_path_selection_is_pure_host(lib):
     m.precision = _lib.PREC["f32"]
     assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == GENERIC    # fused kernel: theta mode only
     m.precision = _lib.PREC["f16x3"]
-    m.time_token = 1
-    assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == GENERIC
+    m.time_token = 1                                                          # a time token is a per-step bias of the head: same path
+    assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == S3
     m.time_token = 0
     m.H = 8                                                                   # head_dim 4: not an s3 shape
     assert L.aline_rollout_path(byref(m), byref(rollout(B=512, n_td=100, T=50))) == GENERIC

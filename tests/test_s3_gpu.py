@@ -172,3 +172,37 @@ def test_rollout_query_posterior(emb, kw):
     assert ((a["qmean"] - b["qmean"]).abs() * m).max() < 2e-4
     assert ((a["qw"] - b["qw"]).abs() * m).max() < 1e-4
     assert (((a["qstd"] - b["qstd"]).abs() / b["qstd"]) * m).max() < 1e-3
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("emb,d,path", [("theta", 32, "s3::step_kernel"), ("mix", 32, "s3::step_kernel"), ("theta", 256, "x3::layer_kernel"),
+                                        ("theta", 512, "x5::layer_kernel")])
+def test_time_token_on_the_fused_reference_precision_paths(emb, d, path, reverse):
+    """model.time_token (model/head.py:24-25, 342-345: the acquisition head reads [z | t]): on the s3 / x3 / x5 paths W1[:, d] t is
+    folded into the hidden layer's bias per step (t / T of the training loop, or (T - t) / T of the reference's eval loop) -- against
+    the exact-fp32 generic pipeline, which feeds the token as a GEMM column, on the same weights and forced designs; and the token
+    matters (the same rollout without the schedule differs)."""
+    from aline_amd.rollout import Rollout
+    T, B, nq = 6, 3, 40
+    H = 4 if d == 32 else 8
+    dims = dict(dims_of(emb), d=d, n_head=H, F=128, time_token=True)
+    out = {}
+    for prec in ("f16x3", "f32"):
+        model, _ = native_model(dims, 11, prec)
+        batch = make_batch(emb, B, nq, 5)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        forced = torch.stack([torch.stack([torch.randint(0, nq - t, (1,), generator=g)[0] for t in range(T)]) for _ in range(B)]).to("cuda")
+        ro = Rollout(model, batch, T, select="forced", forced_idx=forced, time_token_T=T, time_token_reverse=reverse, keep_zt=True)
+        if prec == "f16x3":
+            assert ro.path == path, ro.path
+        ro.run()
+        torch.cuda.synchronize()
+        out[prec] = (ro.log_prob.float().cpu().clone(), ro.zt.float().cpu().clone(), ro.target_ll.float().cpu().clone())
+    assert torch.isfinite(out["f16x3"][0]).all()
+    assert (out["f16x3"][0] - out["f32"][0]).abs().max() < LP_TOL, float((out["f16x3"][0] - out["f32"][0]).abs().max())
+    assert (out["f16x3"][1] - out["f32"][1]).abs().max() < 1e-5
+    assert (out["f16x3"][2].mean(-1) - out["f32"][2].mean(-1)).abs().max() < NLL_TOL
+    other = Rollout(native_model(dims, 11, "f16x3")[0], make_batch(emb, B, nq, 5), T, select="forced", forced_idx=forced,
+                    time_token_T=T, time_token_reverse=not reverse, keep_zt=True).run()
+    torch.cuda.synchronize()
+    assert (other.zt.float().cpu() - out["f16x3"][1]).abs().max() > 1e-4       # the other schedule is another function
