@@ -1585,7 +1585,8 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
   if (smem > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_bwd_kernel<HD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(attention_bwd_kernel<HD>, dim3((unsigned)c.g.B), dim3(256), smem, c.st, c.g, c.m->d, qkv,
+  const int nthr = HD <= 16 ? std::min(512, std::max(256, (c.g.N + 63) / 64 * 64)) : 256;      // whole waves of token rows
+  hipLaunchKernelGGL(attention_bwd_kernel<HD>, dim3((unsigned)c.g.B), dim3(nthr), smem, c.st, c.g, c.m->d, qkv,
                      dA, dqkv, max_keys);
   CHECK_LAUNCH();
   return ALINE_OK;

@@ -237,7 +237,7 @@ __global__ void transpose_kernel(const float *__restrict__ src, int rows, int co
 // pair)): every key row sums its own dK / dV over the token rows from the statistics kept in LDS -- no
 // atomics.  dQKV rows of non-key tokens get zero K/V gradients.
 template <int HD>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const float *__restrict__ QKV,
+__global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo g, int d, const float *__restrict__ QKV,
                                                             const float *__restrict__ dA,
                                                             float *__restrict__ dQKV, int max_keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -248,18 +248,20 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   float *St = Gs + (size_t)g.N * HD;                               // [N][4]   max, 1/l, delta, #keys
   float *dKV = St + (size_t)g.N * 4;                               // [max_keys][2 HD]  dK | dV sums
   int *keyrow = reinterpret_cast<int *>(dKV + (size_t)max_keys * 2 * HD);     // [max_keys]
-  __shared__ int wave_cnt[4];
+  __shared__ int wave_cnt[8];
   __shared__ int s_base;
   // one workgroup per instance, the heads one after the other: the key list is built once and the four 32-byte head
   // slices of a QKV row are read by the same CU back to back (a workgroup per (instance, head) spent most of its time
   // in the prologue: 60 000 workgroups of ~5 us of arithmetic per call)
   const int H = d / HD, b = blockIdx.x;
   if (b >= g.B) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // NT threads: the launcher rounds the token count up to whole waves (<= 512 at head_dim <= 16) -- phase 1 is a thread per token row,
+  // phase 2 a thread per (key, row slice): 304 rows / 150 keys on 256 threads left 41 % of the lanes idle in both (cfg3)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x, NWV = NT >> 6;
   const int n_t = g.n_td + g.n_th;
   if (tid == 0) s_base = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < g.N; c0 += 256) {
+  for (int c0 = 0; c0 < g.N; c0 += NT) {
     int row = c0 + tid;
     bool key = false;
     if (row < g.P) key = is_ctx(g, b, row);
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     for (int w = 0; w < wave; ++w) off += wave_cnt[w];
     if (key) keyrow[off + __popcll(bal & ((1ull << lane) - 1ull))] = row;
     __syncthreads();
-    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (tid == 0) { int tot = 0; for (int w = 0; w < NWV; ++w) tot += wave_cnt[w]; s_base += tot; }
     __syncthreads();
   }
   const int n_ck = s_base;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   const int n_ak = s_base;
   const long ep = (long)b * g.N;
   for (int h = 0; h < H; ++h) {
-  for (int i = tid; i < n_ak * HD; i += 256) {
+  for (int i = tid; i < n_ak * HD; i += NT) {
     int j = i / HD, c = i % HD;
     const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
     Ks[j * HD + c] = src[d];
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   }
   __syncthreads();
   const float scale = rsqrtf((float)HD);
-  for (int row = tid; row < g.N; row += 256) {
+  for (int row = tid; row < g.N; row += NT) {
     const bool isq = row < g.P && !is_ctx(g, b, row);
     const int nk = isq ? n_ak : n_ck;
     float q[HD], go[HD], dq[HD];
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
   __syncthreads();
   // phase 2: thread = (key j, slice of the token rows): softmax weight and score gradient once per (row, key),
   // partial dK / dV rows in registers, summed per key through LDS
-  const int nsl = max(1, 256 / max(n_ak, 1));
-  for (int w = tid; w < n_ak * nsl; w += 256) {
+  const int nsl = max(1, NT / max(n_ak, 1));
+  for (int w = tid; w < n_ak * nsl; w += NT) {
     const int j = w % n_ak, sl = w / n_ak;
     float kj[HD], vj[HD], dk[HD], dv[HD];
 #pragma unroll
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Geo g, int d, const 
     for (int c = 0; c < HD; ++c) { atomicAdd(&dKV[j * 2 * HD + c], dk[c]); atomicAdd(&dKV[j * 2 * HD + HD + c], dv[c]); }
   }
   __syncthreads();
-  for (int e = tid; e < n_ak * HD; e += 256) {
+  for (int e = tid; e < n_ak * HD; e += NT) {
     const int j = e / HD, c = e % HD;
     float *dst = dQKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
     dst[d] = dKV[j * 2 * HD + c];            // Qs already carries the 1/sqrt(hd)
