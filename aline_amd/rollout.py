@@ -88,11 +88,14 @@ class Rollout:
                                                      _lib.ptr(self.postq_weight))
         # training rollouts: the encoder layers' inputs and attention outputs of every (step, episode, row), kept for the backward
         # (aline_rollout.saved_acts: the s3 path writes them, aline_rollout_backward reads them instead of recomputing the layers)
+        # keep_acts: True (own buffer) or a callable nbytes -> float32 tensor of at least that size (a buffer shared by the cached
+        # rollouts of a training loop: only one rollout is between its forward and its backward at a time)
         self.saved_acts = None
         if keep_acts:
             sb = _lib.lib.aline_rollout_saved_acts_bytes(C.byref(self.m), C.byref(r))
             if sb:
-                self.saved_acts = torch.empty(sb // 4, dtype=torch.float32, device=dev)
+                self.saved_acts = keep_acts(sb) if callable(keep_acts) else torch.empty(sb // 4, dtype=torch.float32, device=dev)
+                assert self.saved_acts.numel() * 4 >= sb and self.saved_acts.device == dev
                 r.saved_acts = self.saved_acts.data_ptr()
         nbytes = _lib.lib.aline_rollout_workspace_bytes(C.byref(self.m), C.byref(r))
         if nbytes == 0:

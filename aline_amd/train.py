@@ -172,6 +172,21 @@ def all_reduce_grads(model, dist, world, flat=None):
         off += n
 
 
+_SAVED_ACTS = [None]          # one grow-only buffer for the activations the training rollouts keep for their backward
+
+
+def _shared_acts(nbytes):
+    """The shared `saved_acts` buffer (Rollout(keep_acts=...)).  Growing it invalidates the captured rollouts, whose graphs hold the
+    old address: the cache is dropped."""
+    buf = _SAVED_ACTS[0]
+    if buf is None or buf.numel() * 4 < nbytes or buf.device != torch.device("cuda", torch.cuda.current_device()):
+        _ROLLOUT_GRAPHS.clear()
+        _SAVED_ACTS[0] = None
+        buf = None                                   # (free the old one before allocating the new)
+        _SAVED_ACTS[0] = buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device="cuda")
+    return buf
+
+
 _ROLLOUT_GRAPHS = {}          # (model, shapes, T) -> captured Rollout, most recently used last; at most _MAX_GRAPHS of them
 _MAX_GRAPHS = 8
 _GRAPH_OK = True
@@ -232,7 +247,7 @@ def _sampled_rollout(model, batch, T):
     import os
     global _GRAPH_OK, _GRAPH_MISSES
     if os.environ.get("ALINE_TRAIN_GRAPH", "1") == "0" or not _GRAPH_OK:
-        return Rollout(model, batch, T, select="sample", keep_acts=True).run()
+        return Rollout(model, batch, T, select="sample", keep_acts=_shared_acts).run()
     g = lambda k: batch.get(k) if isinstance(batch, dict) else getattr(batch, k, None)    # noqa: E731
     tens = {k: g(k) for k in ("context_x", "context_y", "query_x", "query_y", "target_all", "target_x", "target_mask")}
     prm = list(model.parameters())
@@ -242,7 +257,7 @@ def _sampled_rollout(model, batch, T):
     if ro is None:
         _GRAPH_MISSES += 1
         if _GRAPH_MISSES > _MAX_GRAPHS:          # thrashing: eager launches (+0.3 ms) beat a warm-up run + a capture per step
-            return Rollout(model, batch, T, select="sample", keep_acts=True).run()
+            return Rollout(model, batch, T, select="sample", keep_acts=_shared_acts).run()
         if len(_ROLLOUT_GRAPHS) >= _MAX_GRAPHS:
             _ROLLOUT_GRAPHS.pop(next(iter(_ROLLOUT_GRAPHS)))         # least recently used
         try:
@@ -252,13 +267,13 @@ def _sampled_rollout(model, batch, T):
                     own[k] = _own(own[k])
             if torch.is_tensor(own.get("target_mask")):
                 own["target_mask"] = own["target_mask"].clone()
-            ro = Rollout(model, own, T, select="sample", keep_acts=True).capture()
+            ro = Rollout(model, own, T, select="sample", keep_acts=_shared_acts).capture()
         except RuntimeError as e:                   # a runtime that refuses the capture: eager launches from now on
             import warnings
             warnings.warn(f"aline_amd: HIP-graph capture of the training rollout failed ({e}); using eager launches")
             _GRAPH_OK = False
             torch.cuda.synchronize()
-            return Rollout(model, batch, T, select="sample", keep_acts=True).run()
+            return Rollout(model, batch, T, select="sample", keep_acts=_shared_acts).run()
     else:
         _GRAPH_MISSES = 0
         torch.cat([_lib.f32(tens["context_x"]), _lib.f32(tens["query_x"])], dim=1, out=ro.px)
@@ -297,6 +312,8 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
 
     The returned `ro` is the step's rollout; when it came from the graph cache its outputs (log_prob, target_ll, idx, ...) are
     the cache entry's buffers and are overwritten by the next step with the same shapes -- clone what must outlive the step.
+    The activations it kept for the backward (`ro.saved_acts`) live in ONE buffer shared by all training rollouts of the process and
+    are overwritten by the next step's rollout whatever its shape.
     global_reward_moments (N > 1): z-score the rewards with the moments of the WHOLE data-parallel batch (one extra all-reduce
     of [3, T - 1] floats before the backward; SURVEY 8-e option ii) instead of the rank-local moments (option i)."""
     model.train()
@@ -305,7 +322,7 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
         flat, gstruct = flat_grads(model)
         flat.zero_()
         if forced_idx is not None:
-            ro = Rollout(model, batch, T, select="forced", forced_idx=forced_idx, keep_acts=True).run()
+            ro = Rollout(model, batch, T, select="forced", forced_idx=forced_idx, keep_acts=_shared_acts).run()
         else:
             ro = _sampled_rollout(model, batch, T)
         _post_range_status(ro)
