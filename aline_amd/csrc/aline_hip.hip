@@ -1572,7 +1572,7 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 }
 
 template <int HD>
-int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys) {
+int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys, const float *aout = nullptr) {
   const bool mfma_on = !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA);      // 0: the VALU kernel (A/B measurements)
   if (mfma_on && HD == abwd::HD && c.m->d == abwd::D && max_keys <= abwd::MAXK) {
     hipLaunchKernelGGL(abwd::attention_bwd_mfma_kernel, dim3((unsigned)c.g.B), dim3(abwd::THREADS), 0, c.st, c.g, qkv, dA, dqkv);
@@ -1587,7 +1587,7 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int nthr = HD <= 16 ? std::min(512, std::max(256, (c.g.N + 63) / 64 * 64)) : 256;      // whole waves of token rows
   hipLaunchKernelGGL(attention_bwd_kernel<HD>, dim3((unsigned)c.g.B), dim3(nthr), smem, c.st, c.g, c.m->d, qkv,
-                     dA, dqkv, max_keys);
+                     dA, dqkv, max_keys, dbg(ALINE_DBG_NO_BWD_ATTN_MFMA) ? (const float *)nullptr : aout);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -1995,11 +1995,11 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       }
       // attention
       switch (hd) {
-        case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
-        case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
-        case 16: TRY(launch_attention_bwd<16>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
-        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
-        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys)); break;
+        case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
+        case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
+        case 16: TRY(launch_attention_bwd<16>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
+        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
+        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
         default: return ALINE_EUNSUPPORTED;
       }
       // in-proj

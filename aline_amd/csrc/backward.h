@@ -239,7 +239,10 @@ __global__ void transpose_kernel(const float *__restrict__ src, int rows, int co
 template <int HD>
 __global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo g, int d, const float *__restrict__ QKV,
                                                             const float *__restrict__ dA,
-                                                            float *__restrict__ dQKV, int max_keys) {
+                                                            float *__restrict__ dQKV, int max_keys,
+                                                            const float *__restrict__ Aout = nullptr) {
+  // Aout (the attention output the backward keeps for the out-projection gradient, or null): delta_i = dO_i . O_i is then known
+  // before the key loop of phase 1, and dQ needs one accumulator per channel instead of two (sum e dp k and sum e k)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *Ks = reinterpret_cast<float *>(smem_raw);                 // [max_keys][HD]
   float *Vs = Ks + (size_t)max_keys * HD;                          // [max_keys][HD]
@@ -319,24 +322,44 @@ __global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo
       for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j * HD + c], s);
       mx = fmaxf(mx, s);
     }
-    // dq = sum_j p_j (dp_j - delta) k_j = (sum_j e_j dp_j k_j - delta sum_j e_j k_j) / l  in one pass over the keys
-    float l = 0.f, delta = 0.f, pk[HD];
+    float l = 0.f, delta = 0.f, inv;
+    if (Aout) {
+      // dq = sum_j p_j (dp_j - delta) k_j = (sum_j e_j (dp_j - delta) k_j) / l with delta = dO . O
+      const float *ap = Aout + (ep + row) * d + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) pk[c] = 0.f;
-    for (int j = 0; j < nk; ++j) {
-      float s = 0.f, dp = 0.f;
+      for (int c = 0; c < HD; ++c) delta = fmaf(go[c], ap[c], delta);
+      for (int j = 0; j < nk; ++j) {
+        float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
-      const float e = __expf(s - mx), edp = e * dp;
-      l += e;
-      delta += edp;
+        for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
+        const float e = __expf(s - mx), w = e * (dp - delta);
+        l += e;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) { dq[c] = fmaf(edp, Ks[j * HD + c], dq[c]); pk[c] = fmaf(e, Ks[j * HD + c], pk[c]); }
+        for (int c = 0; c < HD; ++c) dq[c] = fmaf(w, Ks[j * HD + c], dq[c]);
+      }
+      inv = 1.f / l;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dq[c] *= inv;
+    } else {
+      // dq = sum_j p_j (dp_j - delta) k_j = (sum_j e_j dp_j k_j - delta sum_j e_j k_j) / l  in one pass over the keys
+      float pk[HD];
+#pragma unroll
+      for (int c = 0; c < HD; ++c) pk[c] = 0.f;
+      for (int j = 0; j < nk; ++j) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { s = fmaf(q[c], Ks[j * HD + c], s); dp = fmaf(go[c], Vs[j * HD + c], dp); }
+        const float e = __expf(s - mx), edp = e * dp;
+        l += e;
+        delta += edp;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { dq[c] = fmaf(edp, Ks[j * HD + c], dq[c]); pk[c] = fmaf(e, Ks[j * HD + c], pk[c]); }
+      }
+      inv = 1.f / l;
+      delta *= inv;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dq[c] = (dq[c] - delta * pk[c]) * inv;
     }
-    const float inv = 1.f / l;
-    delta *= inv;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) dq[c] = (dq[c] - delta * pk[c]) * inv;
     *reinterpret_cast<float4 *>(St + row * 4) = make_float4(mx, inv, delta, (float)nk);
     float *out = dQKV + (ep + row) * 3 * d + h * HD;
 #pragma unroll
