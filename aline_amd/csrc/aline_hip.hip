@@ -1545,7 +1545,9 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
   }
   const int Nw = a.N, Kn = a.K;
   const unsigned gx = (unsigned)((M + a.mchunk - 1) / a.mchunk);
-  if (Nw % 128 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3(gx, Nw / 128, Kn / 32), dim3(256), 0, c.st, a);
+  const bool tk4 = Kn % 64 == 0 && !dbg(ALINE_DBG_BWD_DW_TK2);      // 64 columns of the narrow operand per workgroup
+  if (Nw % 128 == 0 && tk4) hipLaunchKernelGGL((gemm_tn_block_kernel<8, 4>), dim3(gx, Nw / 128, Kn / 64), dim3(256), 0, c.st, a);
+  else if (Nw % 128 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3(gx, Nw / 128, Kn / 32), dim3(256), 0, c.st, a);
   else if (Nw % 96 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<6>, dim3(gx, Nw / 96, Kn / 32), dim3(256), 0, c.st, a);
   else if (Nw % 64 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<4>, dim3(gx, Nw / 64, Kn / 32), dim3(256), 0, c.st, a);
   else hipLaunchKernelGGL(gemm_tn_block_kernel<2>, dim3(gx, Nw / 32, Kn / 32), dim3(256), 0, c.st, a);

@@ -22,27 +22,32 @@ struct GemmTnArgs {
   float *dWg[16]; float *dbg[16]; int grouped;
 };
 
-// The workgroup owns a [16 TN x 32] block of dW for its row chunk (TN = 8, 6, 4, 2 by the divisibility of N):
-// a row of dY is read once per 32 columns of X, 2 TN MFMAs per (TN + 2) loads, four row groups in flight per wave.
-template <int TN>
+// The workgroup owns a [16 TN x 16 TK] block of dW for its row chunk (TN = 8, 6, 4, 2 by the divisibility of N; TK = 4 where the other
+// dimension is a multiple of 64, else 2): a row of dY is read once per 16 TK columns of X, TN TK MFMAs per (TN + TK) loads, four row
+// groups in flight per wave.  (TK was 2 everywhere: at d = 512 the in-projection's dY [M, 1536] was read 16 times -- 190 GB out of
+// L2 per call -- and the dW products were 37 - 41 % of the training step of the wide models.)
+template <int TN, int TK = 2>
 __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
-  constexpr int BN = 16 * TN;
-  __shared__ float red[BN][33];
+  constexpr int BN = 16 * TN, BK = 16 * TK;
+  __shared__ float red[BN][BK + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.y * BN, k0 = blockIdx.z * 32;
+  const int n0 = blockIdx.y * BN, k0 = blockIdx.z * BK;
   const long m_lo = (long)blockIdx.x * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
-  for (int e = threadIdx.x; e < BN * 33; e += 256) (&red[0][0])[e] = 0.f;
-  f32x4 acc[TN][2];
-  float bsum[TN], bsum2[2] = {0.f, 0.f};
+  for (int e = threadIdx.x; e < BN * (BK + 1); e += 256) (&red[0][0])[e] = 0.f;
+  f32x4 acc[TN][TK];
+  float bsum[TN], bsum2[TK];
+#pragma unroll
+  for (int j = 0; j < TK; ++j) bsum2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
-    acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bsum[i] = 0.f;
   }
   constexpr int UN = 4;                  // row groups (of 4 rows) in flight per wave
   for (long mb = m_lo + 4 * UN * wave; mb < m_hi; mb += 16 * UN) {
-    float av[UN][TN], bv[UN][2];
+    float av[UN][TN], bv[UN][TK];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const long m = mb + 4 * u + fg;
@@ -52,21 +57,20 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
       const float *px = a.X + ((mm / a.Rx) * a.Gx + a.offx + (mm % a.Rx)) * a.ldx + k0 + fr;
 #pragma unroll
       for (int i = 0; i < TN; ++i) av[u][i] = ok ? py[16 * i] : 0.f;
-      bv[u][0] = ok ? px[0] : 0.f;
-      bv[u][1] = ok ? px[16] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TK; ++j) bv[u][j] = ok ? px[16 * j] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      bsum2[0] += bv[u][0];
-      bsum2[1] += bv[u][1];
-    }
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int j = 0; j < TK; ++j) bsum2[j] += bv[u][j];
 #pragma unroll
     for (int u = 0; u < UN; ++u)
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         bsum[i] += av[u][i];
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][1], acc[i][1], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
       }
   }
   __syncthreads();
@@ -74,15 +78,15 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TK; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(&red[16 * i + 4 * fg + r][16 * j + fr], acc[i][j][r]);
   __syncthreads();
   if (!a.swap) {
     float *dWo = a.grouped ? a.dWg[blockIdx.y] : a.dW + (long)n0 * a.ldw;
     float *dbo = a.grouped ? a.dbg[blockIdx.y] : (a.db ? a.db + n0 : nullptr);
-    for (int e = threadIdx.x; e < BN * 32; e += 256) {
-      const int n = e >> 5, k = e & 31;
+    for (int e = threadIdx.x; e < BN * BK; e += 256) {
+      const int n = e / BK, k = e % BK;
       atomicAdd(dWo + (long)n * a.ldw + k0 + k, red[n][k]);
     }
     if (dbo && blockIdx.z == 0) {
@@ -96,13 +100,13 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
     }
   } else {
     // the wide operand is X: this block holds dW^T[n0.., k0..]; dW is [K_args, N_args] = [32-wide index, wide index]
-    for (int e = threadIdx.x; e < BN * 32; e += 256) {
+    for (int e = threadIdx.x; e < BN * BK; e += 256) {
       const int k = e / BN, n = e % BN;
       atomicAdd(a.dW + (long)(k0 + k) * a.ldw + n0 + n, red[n][k]);
     }
     if (a.db && blockIdx.y == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < TK; ++j) {
         float s = bsum2[j];
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
