@@ -248,6 +248,21 @@ def test_rollout_path_selection_is_pure_host(lib):
     w.precision = _lib.PREC["bf16"]
     assert L.aline_rollout_path(byref(w), byref(rollout())) == WIDE
     assert L.aline_rollout_path(byref(w), byref(rollout(T=70))) == GENERIC    # 72 keys > 64
+    w.d, w.F, w.precision = 512, 128, _lib.PREC["f16x3"]                      # the psychometric configuration's width (cfg5)
+    assert L.aline_rollout_path(byref(w), byref(rollout(B=256))) == 5         # ALINE_PATH_X5
+    w.F = 2048
+    assert L.aline_rollout_path(byref(w), byref(rollout(B=256))) == 5
+    assert L.aline_rollout_path(byref(w), byref(rollout(B=256, T=70))) == GENERIC
+    buf = ctypes.create_string_buffer(64)
+    assert L.aline_rollout_kernel_name(byref(w), byref(rollout(B=256)), buf, 64) == 5 and buf.value == b"x5::layer_kernel<true>"
     w.d = 48
     assert L.aline_rollout_path(byref(w), byref(rollout())) == -2             # ALINE_EUNSUPPORTED, as the forward would say
     assert L.aline_rollout_path(None, byref(rollout())) == -1
+    # aline_rollout.saved_acts: sized for the s3 path of the fused-backward width only ([2 L + 1][T B N d] floats), 0 elsewhere
+    m = _small_model()
+    m.precision = _lib.PREC["f16x3"]
+    r = rollout(B=10, P=21, T=5)
+    assert L.aline_rollout_saved_acts_bytes(byref(m), byref(r)) == (2 * m.L + 1) * 5 * 10 * (21 + m.n_theta) * 32 * 4
+    m.precision = _lib.PREC["f32"]
+    assert L.aline_rollout_saved_acts_bytes(byref(m), byref(r)) == 0          # the exact-fp32 fused rollout does not keep them
+    assert L.aline_rollout_saved_acts_bytes(byref(w), byref(r)) == 0 and L.aline_rollout_saved_acts_bytes(None, byref(r)) == 0
