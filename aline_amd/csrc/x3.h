@@ -12,12 +12,17 @@
 #define X3_HD 32
 #define X3_THREADS 512
 #define X3_KV_AHEAD 1
+#ifndef X3_ILV256
+#define X3_ILV256 1
+#endif
+#define X3_INTERLEAVE X3_ILV256
 #include "x3_impl.h"
 #undef X3_NS
 #undef X3_D
 #undef X3_HD
 #undef X3_THREADS
 #undef X3_KV_AHEAD
+#undef X3_INTERLEAVE
 
 #define X3_NS x5
 #define X3_D 512
@@ -27,9 +32,14 @@
 #define X5_KV_AHEAD 1
 #endif
 #define X3_KV_AHEAD X5_KV_AHEAD
+#ifndef X3_ILV512
+#define X3_ILV512 1
+#endif
+#define X3_INTERLEAVE X3_ILV512
 #include "x3_impl.h"
 #undef X3_NS
 #undef X3_D
 #undef X3_HD
 #undef X3_THREADS
 #undef X3_KV_AHEAD
+#undef X3_INTERLEAVE

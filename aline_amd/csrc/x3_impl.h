@@ -377,7 +377,7 @@ struct Stream {
   char *ring;
   int seq_len, s_issue, b_issue, b_use;
   unsigned lane_off, wave_off;
-  int dma_slot;           // the MFMA batch (0..3) of a chunk behind which this wave issues its pieces (0: all waves)
+  static constexpr int dma_slot = 0;   // the MFMA batch (0..3) of a chunk with which a wave issues its pieces of the stream
   __device__ __forceinline__ void issue() {
 #ifndef X3_NO_DMA      // (timing experiments only: tools/x3_variants.sh)
     // buffer_load ... lds with the chunk's base in a scalar buffer descriptor and a constant 32-bit lane offset: no per-piece
@@ -421,8 +421,7 @@ __device__ __forceinline__ Stream<SrcFn> make_stream(SrcFn src, char *ring, int 
 #ifdef X3_STAMPS
                   Stamps{},
 #endif
-                  src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u, (unsigned)wave * (unsigned)(PIECES_PER_WAVE * 1024),
-                  0};
+                  src, ring, seq_len, 0, 0, 0, (unsigned)(tid & 63) * 16u, (unsigned)wave * (unsigned)(PIECES_PER_WAVE * 1024)};
   return s;
 }
 
@@ -459,6 +458,42 @@ __device__ __forceinline__ void chunk_pipe(St &st, FragRing &r, const f16x8 *cur
 #endif
     X3_LAP(st, 0);
     __builtin_amdgcn_sched_barrier(0);
+#if X3_INTERLEAVE && !defined(X3_STAMPS)
+    // The fragment reads of the next batch and the wave's LDS-DMA pieces go BETWEEN the MFMAs of the batch instead of in front of /
+    // behind them (a wave that issues 8 reads or 8 pieces in a row leaves the matrix pipe of its SIMD idle meanwhile; at d = 512 it
+    // has no partner wave to fill it): a read behind each of the first eight MFMAs; in the batch that carries the stream, two reads
+    // behind each of the first four and a piece behind each of the following ones.  Same-box A/B (profiles/r03_x3_timing_experiments.txt):
+    // x5 cfg5 35.2 -> 33.2 ms (F = 128), 101.3 -> 92.5 ms (F = 2048); x3 layer kernel 697 -> 661 us.
+    const bool reads = k < 3 || PREFETCH_NEXT;
+    if (k < 3) fetch_batch(r, (k + 1) & 1, cur, k + 1);
+    else if (PREFETCH_NEXT) fetch_batch(r, 0, nxt, 0);
+    if (k == st.dma_slot) st.issue();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(4 * k + j, r.hi[k & 1][j], r.lo[k & 1][j]);
+    constexpr int NP = PIECES_PER_WAVE < 8 ? PIECES_PER_WAVE : 8;
+#define X3_MFMA1() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0)
+#define X3_READ(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define X3_DMA1() __builtin_amdgcn_sched_group_barrier(0x020, 1, 0)
+    if (k != st.dma_slot) {
+      if (reads) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { X3_MFMA1(); X3_READ(1); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      }
+    } else {                                         // two reads behind each of four MFMAs, then the pieces
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { X3_MFMA1(); if (reads) X3_READ(2); }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) { X3_MFMA1(); X3_DMA1(); }
+      if constexpr (NP < 8) __builtin_amdgcn_sched_group_barrier(0x008, 8 - NP, 0);
+    }
+#undef X3_MFMA1
+#undef X3_READ
+#undef X3_DMA1
+    __builtin_amdgcn_sched_barrier(0);
+#else
     if (k < 3) {
       fetch_batch(r, (k + 1) & 1, cur, k + 1);
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
@@ -472,6 +507,7 @@ __device__ __forceinline__ void chunk_pipe(St &st, FragRing &r, const f16x8 *cur
     __builtin_amdgcn_sched_barrier(0);
     X3_LAP(st, 1);
     if (k == st.dma_slot) { st.issue(); X3_LAP(st, 2); }
+#endif
   }
   __builtin_amdgcn_sched_barrier(0);
   st.sync();
