@@ -458,7 +458,7 @@ __device__ __forceinline__ void chunk_pipe(St &st, FragRing &r, const f16x8 *cur
 #endif
     X3_LAP(st, 0);
     __builtin_amdgcn_sched_barrier(0);
-#if X3_INTERLEAVE && !defined(X3_STAMPS)
+#if X3_INTERLEAVE
     // The fragment reads of the next batch and the wave's LDS-DMA pieces go BETWEEN the MFMAs of the batch instead of in front of /
     // behind them (a wave that issues 8 reads or 8 pieces in a row leaves the matrix pipe of its SIMD idle meanwhile; at d = 512 it
     // has no partner wave to fill it): a read behind each of the first eight MFMAs; in the batch that carries the stream, two reads
@@ -493,6 +493,7 @@ __device__ __forceinline__ void chunk_pipe(St &st, FragRing &r, const f16x8 *cur
 #undef X3_READ
 #undef X3_DMA1
     __builtin_amdgcn_sched_barrier(0);
+    X3_LAP(st, 1);          // (stamps: the DMA pieces are inside the batch now, lap 2 stays empty)
 #else
     if (k < 3) {
       fetch_batch(r, (k + 1) & 1, cur, k + 1);
