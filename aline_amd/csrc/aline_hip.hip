@@ -1581,15 +1581,28 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
     CHECK_LAUNCH();
     return ALINE_OK;
   }
-  size_t smem = (size_t)max_keys * (4 * HD * sizeof(float) + sizeof(int)) +
+  const int nthr = HD <= 16 ? std::min(512, std::max(256, (c.g.N + 63) / 64 * 64)) : 256;      // whole waves of token rows
+  // K, V (+ the dK / dV sums where they cannot take their place: backward.h), key list | scaled Q, dO, row statistics
+  const bool reuse = HD <= 16 && max_keys <= nthr;
+  size_t smem = (size_t)max_keys * ((reuse ? 2 : 4) * HD * sizeof(float) + sizeof(int)) +
                 (size_t)c.g.N * (2 * HD + 4) * sizeof(float);
   if (smem > 160 * 1024 - 1024) return ALINE_EUNSUPPORTED;
+  const float *ao = dbg(ALINE_DBG_NO_BWD_ATTN_MFMA) ? (const float *)nullptr : aout;
+  if constexpr (HD <= 16) {
+    if (reuse) {
+      if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_bwd_kernel<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+      hipLaunchKernelGGL((attention_bwd_kernel<HD, true>), dim3((unsigned)c.g.B), dim3(nthr), smem, c.st, c.g, c.m->d, qkv, dA, dqkv, max_keys, ao);
+      CHECK_LAUNCH();
+      return ALINE_OK;
+    }
+  }
   if (smem > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_bwd_kernel<HD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_bwd_kernel<HD, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  const int nthr = HD <= 16 ? std::min(512, std::max(256, (c.g.N + 63) / 64 * 64)) : 256;      // whole waves of token rows
-  hipLaunchKernelGGL(attention_bwd_kernel<HD>, dim3((unsigned)c.g.B), dim3(nthr), smem, c.st, c.g, c.m->d, qkv,
-                     dA, dqkv, max_keys, dbg(ALINE_DBG_NO_BWD_ATTN_MFMA) ? (const float *)nullptr : aout);
+  hipLaunchKernelGGL((attention_bwd_kernel<HD, false>), dim3((unsigned)c.g.B), dim3(nthr), smem, c.st, c.g, c.m->d, qkv,
+                     dA, dqkv, max_keys, ao);
   CHECK_LAUNCH();
   return ALINE_OK;
 }

@@ -240,7 +240,7 @@ __global__ void transpose_kernel(const float *__restrict__ src, int rows, int co
 // Phase 1 (threads = token rows): softmax statistics, delta and dQ.  Phase 2 (threads = (key, channel
 // pair)): every key row sums its own dK / dV over the token rows from the statistics kept in LDS -- no
 // atomics.  dQKV rows of non-key tokens get zero K/V gradients.
-template <int HD>
+template <int HD, bool REUSE = false>
 __global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo g, int d, const float *__restrict__ QKV,
                                                             const float *__restrict__ dA,
                                                             float *__restrict__ dQKV, int max_keys,
@@ -253,8 +253,14 @@ __global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo
   float *Qs = Vs + (size_t)max_keys * HD;                          // [N][HD]  scaled queries
   float *Gs = Qs + (size_t)g.N * HD;                               // [N][HD]  dO
   float *St = Gs + (size_t)g.N * HD;                               // [N][4]   max, 1/l, delta, #keys
-  float *dKV = St + (size_t)g.N * 4;                               // [max_keys][2 HD]  dK | dV sums
-  int *keyrow = reinterpret_cast<int *>(dKV + (size_t)max_keys * 2 * HD);     // [max_keys]
+  // dK / dV sums of the second phase.  REUSE (the launcher picks it at head_dim <= 16 while max_keys <= blockDim.x: a thread has one work item
+  // then and copies its key's K / V row into registers first): they take the place of Ks / Vs -- 10 KB less LDS at the cfg3 shape, four
+  // workgroups per CU instead of three (the kernel is latency-bound: profiles/r03_attention_bwd_hd8_cfg3_pmc.txt); otherwise their own
+  // [2][max_keys][HD] block
+  constexpr bool reuse = REUSE;
+  float *dKx = St + (size_t)g.N * 4;
+  float *dKs = reuse ? Ks : dKx, *dVs = reuse ? Vs : dKx + (size_t)max_keys * HD;
+  int *keyrow = reinterpret_cast<int *>(dKx + (reuse ? 0 : (size_t)max_keys * 2 * HD));     // [max_keys]
   __shared__ int wave_cnt[8];
   __shared__ int s_base;
   // one workgroup per instance, the heads one after the other: the key list is built once and the four 32-byte head
@@ -299,8 +305,7 @@ __global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo
     const float *src = QKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
     Ks[j * HD + c] = src[d];
     Vs[j * HD + c] = src[2 * d];
-    dKV[j * 2 * HD + c] = 0.f;
-    dKV[j * 2 * HD + HD + c] = 0.f;
+    if (!reuse) { dKs[j * HD + c] = 0.f; dVs[j * HD + c] = 0.f; }
   }
   __syncthreads();
   const float scale = rsqrtf((float)HD);
@@ -377,11 +382,23 @@ __global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo
   // phase 2: thread = (key j, slice of the token rows): softmax weight and score gradient once per (row, key),
   // partial dK / dV rows in registers, summed per key through LDS
   const int nsl = max(1, NT / max(n_ak, 1));
+  float kj[HD], vj[HD];
+  if (reuse) {        // (one work item per thread) K / V rows into registers, then Ks / Vs become the dK / dV sums
+    const int j0 = tid < n_ak * nsl ? tid % n_ak : 0;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { kj[c] = Ks[j0 * HD + c]; vj[c] = Vs[j0 * HD + c]; }
+    __syncthreads();
+    for (int i = tid; i < n_ak * HD; i += NT) { Ks[i] = 0.f; Vs[i] = 0.f; }
+    __syncthreads();
+  }
   for (int w = tid; w < n_ak * nsl; w += NT) {
     const int j = w % n_ak, sl = w / n_ak;
-    float kj[HD], vj[HD], dk[HD], dv[HD];
+    float dk[HD], dv[HD];
 #pragma unroll
-    for (int c = 0; c < HD; ++c) { kj[c] = Ks[j * HD + c]; vj[c] = Vs[j * HD + c]; dk[c] = 0.f; dv[c] = 0.f; }
+    for (int c = 0; c < HD; ++c) {
+      if (!reuse) { kj[c] = Ks[j * HD + c]; vj[c] = Vs[j * HD + c]; }
+      dk[c] = 0.f; dv[c] = 0.f;
+    }
     for (int row = sl; row < g.N; row += nsl) {
       if ((float)j >= St[row * 4 + 3]) continue;      // key not visible to this row
       float s = 0.f, dp = 0.f;
@@ -393,14 +410,14 @@ __global__ __launch_bounds__(HD <= 16 ? 512 : 256) void attention_bwd_kernel(Geo
       for (int c = 0; c < HD; ++c) { dv[c] = fmaf(p, Gs[row * HD + c], dv[c]); dk[c] = fmaf(ds, Qs[row * HD + c], dk[c]); }
     }
 #pragma unroll
-    for (int c = 0; c < HD; ++c) { atomicAdd(&dKV[j * 2 * HD + c], dk[c]); atomicAdd(&dKV[j * 2 * HD + HD + c], dv[c]); }
+    for (int c = 0; c < HD; ++c) { atomicAdd(&dKs[j * HD + c], dk[c]); atomicAdd(&dVs[j * HD + c], dv[c]); }
   }
   __syncthreads();
   for (int e = tid; e < n_ak * HD; e += NT) {
     const int j = e / HD, c = e % HD;
     float *dst = dQKV + (ep + keyrow[j]) * 3 * d + h * HD + c;
-    dst[d] = dKV[j * 2 * HD + c];            // Qs already carries the 1/sqrt(hd)
-    dst[2 * d] = dKV[j * 2 * HD + HD + c];
+    dst[d] = dKs[j * HD + c];            // Qs already carries the 1/sqrt(hd)
+    dst[2 * d] = dVs[j * HD + c];
   }
   __syncthreads();     // the staging arrays are reused by the next head
   }   // heads
