@@ -1546,11 +1546,15 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
   const int Nw = a.N, Kn = a.K;
   const unsigned gx = (unsigned)((M + a.mchunk - 1) / a.mchunk);
   const bool tk4 = Kn % 64 == 0 && !dbg(ALINE_DBG_BWD_DW_TK2);      // 64 columns of the narrow operand per workgroup
-  if (Nw % 128 == 0 && tk4) hipLaunchKernelGGL((gemm_tn_block_kernel<8, 4>), dim3(gx, Nw / 128, Kn / 64), dim3(256), 0, c.st, a);
-  else if (Nw % 128 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3(gx, Nw / 128, Kn / 32), dim3(256), 0, c.st, a);
-  else if (Nw % 96 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<6>, dim3(gx, Nw / 96, Kn / 32), dim3(256), 0, c.st, a);
-  else if (Nw % 64 == 0) hipLaunchKernelGGL(gemm_tn_block_kernel<4>, dim3(gx, Nw / 64, Kn / 32), dim3(256), 0, c.st, a);
-  else hipLaunchKernelGGL(gemm_tn_block_kernel<2>, dim3(gx, Nw / 32, Kn / 32), dim3(256), 0, c.st, a);
+#define TNB_LAUNCH(TN, TK, NBY, NBZ) do { a.gx = (int)gx; a.nby = (NBY); a.nbz = (NBZ);                                          \
+    const dim3 grid((gx + 7) / 8 * 8 * (unsigned)((NBY) * (NBZ)));                                                            \
+    hipLaunchKernelGGL((gemm_tn_block_kernel<TN, TK>), grid, dim3(256), 0, c.st, a); } while (0)
+  if (Nw % 128 == 0 && tk4) TNB_LAUNCH(8, 4, Nw / 128, Kn / 64);
+  else if (Nw % 128 == 0) TNB_LAUNCH(8, 2, Nw / 128, Kn / 32);
+  else if (Nw % 96 == 0) TNB_LAUNCH(6, 2, Nw / 96, Kn / 32);
+  else if (Nw % 64 == 0) TNB_LAUNCH(4, 2, Nw / 64, Kn / 32);
+  else TNB_LAUNCH(2, 2, Nw / 32, Kn / 32);
+#undef TNB_LAUNCH
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -1943,7 +1947,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         for (int k = 0; k < C; ++k) { ta.dWg[k] = gr->gmm_w1[k]; ta.dbg[k] = gr->gmm_b1[k]; }
         ta.mchunk = 4096;
         while (ta.mchunk > 256 && ((ta.M + ta.mchunk - 1) / ta.mchunk) * C * (d / 32) < 512) ta.mchunk /= 2;
-        hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3((unsigned)((ta.M + ta.mchunk - 1) / ta.mchunk), C, d / 32), dim3(256), 0, c.st, ta);
+        ta.gx = (int)((ta.M + ta.mchunk - 1) / ta.mchunk); ta.nby = C; ta.nbz = d / 32;
+        hipLaunchKernelGGL(gemm_tn_block_kernel<8>, dim3((unsigned)((ta.gx + 7) / 8 * 8 * C * (d / 32))), dim3(256), 0, c.st, ta);
         CHECK_LAUNCH();
         PackW1Args pa{};
         for (int k = 0; k < C; ++k) pa.w1[k] = m->gmm_w1[k];

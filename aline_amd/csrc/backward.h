@@ -20,6 +20,7 @@ struct GemmTnArgs {
   // optional (TN = 8, no swap): one [128, K] gradient per column block of dY -- the C first layers of the GMM heads, whose hidden
   // gradients sit side by side in one [rows, C F] matrix, in ONE launch (blockIdx.y = component)
   float *dWg[16]; float *dbg[16]; int grouped;
+  int gx, nby, nbz;                              // block kernel: row chunks, blocks along N (or components), blocks along K
 };
 
 // The workgroup owns a [16 TN x 16 TK] block of dW for its row chunk (TN = 8, 6, 4, 2 by the divisibility of N; TK = 4 where the other
@@ -27,14 +28,30 @@ struct GemmTnArgs {
 // groups in flight per wave.  (TK was 2 everywhere: at d = 512 the in-projection's dY [M, 1536] was read 16 times -- 190 GB out of
 // L2 per call -- and the dW products were 37 - 41 % of the training step of the wide models.)
 template <int TN, int TK = 2>
-__global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_block_kernel(GemmTnArgs a) {
   constexpr int BN = 16 * TN, BK = 16 * TK;
   __shared__ float red[BN][BK + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.y * BN, k0 = blockIdx.z * BK;
-  const long m_lo = (long)blockIdx.x * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
-  for (int e = threadIdx.x; e < BN * (BK + 1); e += 256) (&red[0][0])[e] = 0.f;
+  // Workgroup order.  The nby x nbz blocks of dW that share a row chunk read the same rows of dY and X: they must run at the same time and on the
+  // same XCD, or every one of them streams its rows from HBM again (chunk-fastest order, the first version: the 32 blocks of a [1024 x 256]
+  // gradient were up to 1 487 workgroup ids apart and each streamed its rows from HBM: PMC FETCH_SIZE now 1.75 x the operands' size per launch).
+  // Ids go round-robin over the 8 XCDs: ids congruent mod 8 inside a group of 8 nby nbz consecutive ones share a chunk.
+#if defined(TNB_OLD_ORDER)      // (timing experiments only)
+  const unsigned nb_all = (unsigned)(a.nby * a.nbz);
+  const long chunk = blockIdx.x % (unsigned)a.gx;
+  const int nb = blockIdx.x / (unsigned)a.gx;
+  if (nb >= (int)nb_all) return;
+#else
+  const unsigned nb_all = (unsigned)(a.nby * a.nbz), per = 8u * nb_all;
+  const unsigned grp = blockIdx.x / per, within = blockIdx.x - grp * per;
+  const long chunk = (long)grp * 8 + (within & 7u);
+  const int nb = (int)(within >> 3);
+  if (chunk >= a.gx) return;
+#endif
+  const int by = nb % a.nby, bz = nb / a.nby;
+  const int n0 = by * BN, k0 = bz * BK;
+  const long m_lo = chunk * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
   f32x4 acc[TN][TK];
   float bsum[TN], bsum2[TK];
 #pragma unroll
@@ -73,23 +90,32 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
         for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
       }
   }
-  __syncthreads();
+  // The four waves' tiles are summed in LDS one wave after the other with plain stores / read-modify-writes (an element belongs to one lane of
+  // a wave): as LDS float atomics this epilogue kept the LDS busy for 17 % of the kernel (PMC: 126 cycles per ds_add_f32 instruction).
   // acc[i][j][r]: n = 16 i + 4 fg + r, k = 16 j + fr
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < TK; ++j)
+        for (int j = 0; j < TK; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[16 * i + 4 * fg + r][16 * j + fr], acc[i][j][r]);
-  __syncthreads();
+          for (int r = 0; r < 4; ++r) {
+            float *p = &red[16 * i + 4 * fg + r][16 * j + fr];
+            *p = w == 0 ? acc[i][j][r] : *p + acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
   if (!a.swap) {
-    float *dWo = a.grouped ? a.dWg[blockIdx.y] : a.dW + (long)n0 * a.ldw;
-    float *dbo = a.grouped ? a.dbg[blockIdx.y] : (a.db ? a.db + n0 : nullptr);
+    float *dWo = a.grouped ? a.dWg[by] : a.dW + (long)n0 * a.ldw;
+    float *dbo = a.grouped ? a.dbg[by] : (a.db ? a.db + n0 : nullptr);
     for (int e = threadIdx.x; e < BN * BK; e += 256) {
       const int n = e / BK, k = e % BK;
       atomicAdd(dWo + (long)n * a.ldw + k0 + k, red[n][k]);
     }
-    if (dbo && blockIdx.z == 0) {
+    if (dbo && bz == 0) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         float s = bsum[i];
@@ -104,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_tn_block_kernel(GemmTnArgs a) {
       const int k = e / BN, n = e % BN;
       atomicAdd(a.dW + (long)(k0 + k) * a.ldw + n0 + n, red[n][k]);
     }
-    if (a.db && blockIdx.y == 0) {
+    if (a.db && by == 0) {
 #pragma unroll
       for (int j = 0; j < TK; ++j) {
         float s = bsum2[j];
