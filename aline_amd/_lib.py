@@ -135,7 +135,7 @@ DBG = {"DISABLE_FUSED": 1 << 0, "DISABLE_WIDE": 1 << 1, "DISABLE_X3": 1 << 2, "D
        "FUSED_STAMPS": 1 << 10, "WIDE_STAMPS": 1 << 11, "BWD_TAIL_PC": 1 << 12,
        "NO_BWD_TAIL": 1 << 16, "NO_BWD_ATTN_BLOCK": 1 << 17, "NO_BWD_ACQ": 1 << 18, "NO_BWD_LAYER_FWD": 1 << 19,
        "NO_BWD_LAYER_FWD_FLAT": 1 << 20, "NO_BWD_GMM_FUSED": 1 << 21, "NO_BWD_GMM128": 1 << 22, "NO_BWD_GMM_BATCHED": 1 << 23,
-       "NO_BWD_ATTN_MFMA": 1 << 24, "NO_BWD_GMM_WIDE": 1 << 26, "NO_BWD_SAVED_ACTS": 1 << 27, "BWD_RECOMPUTE_F32": 1 << 28, "BWD_DW_TK2": 1 << 29}
+       "NO_BWD_ATTN_MFMA": 1 << 24, "NO_BWD_DW_WALK": 1 << 25, "NO_BWD_GMM_WIDE": 1 << 26, "NO_BWD_SAVED_ACTS": 1 << 27, "BWD_RECOMPUTE_F32": 1 << 28, "BWD_DW_TK2": 1 << 29}
 DBG_PARAM = {"S3_WAVES": 0, "S3_EPW": 1, "BWD_PREC": 2}
 
 

@@ -1546,6 +1546,7 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
   const int Nw = a.N, Kn = a.K;
   const unsigned gx = (unsigned)((M + a.mchunk - 1) / a.mchunk);
   const bool tk4 = Kn % 64 == 0 && !dbg(ALINE_DBG_BWD_DW_TK2);      // 64 columns of the narrow operand per workgroup
+  a.walk = (a.Ry == a.Gy || a.Ry >= 64) && (a.Rx == a.Gx || a.Rx >= 64) && M < (1l << 30) && !dbg(ALINE_DBG_NO_BWD_DW_WALK);
 #define TNB_LAUNCH(TN, TK, NBY, NBZ) do { a.gx = (int)gx; a.nby = (NBY); a.nbz = (NBZ);                                          \
     const dim3 grid((gx + 7) / 8 * 8 * (unsigned)((NBY) * (NBZ)));                                                            \
     hipLaunchKernelGGL((gemm_tn_block_kernel<TN, TK>), grid, dim3(256), 0, c.st, a); } while (0)

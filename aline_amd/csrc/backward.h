@@ -21,8 +21,25 @@ struct GemmTnArgs {
   // gradients sit side by side in one [rows, C F] matrix, in ONE launch (blockIdx.y = component)
   float *dWg[16]; float *dbg[16]; int grouped;
   int gx, nby, nbz;                              // block kernel: row chunks, blocks along N (or components), blocks along K
+  int walk;                                      // block kernel: row groups of >= 64 rows (or identity maps), M < 2^30: the walked loop
 };
 
+// Row m of a gathered operand lives at row (m / R) * G + off + m % R of its matrix (gemm.h).  The product below walks m in small fixed steps: the
+// quotient / remainder pair is kept per lane and advanced without a division or a branch (steps <= R; R == G is the identity map m + off).
+struct RowWalk {
+  int R, G, off, r, q;
+  __device__ __forceinline__ void init(long m, int R_, int G_, int off_) {
+    if (R_ == G_) { R = 0x7fffffff; G = 0; off = off_; q = 0; r = (int)m; }
+    else { R = R_; G = G_; off = off_; q = (int)(m / R_); r = (int)(m - (long)q * R_); }
+  }
+  __device__ __forceinline__ void step(int d) {
+    r += d;
+    const bool w = r >= R;
+    r = w ? r - R : r;
+    q += w ? 1 : 0;
+  }
+  __device__ __forceinline__ long src() const { return (long)q * G + (off + r); }
+};
 // The workgroup owns a [16 TN x 16 TK] block of dW for its row chunk (TN = 8, 6, 4, 2 by the divisibility of N; TK = 4 where the other
 // dimension is a multiple of 64, else 2): a row of dY is read once per 16 TK columns of X, TN TK MFMAs per (TN + TK) loads, four row
 // groups in flight per wave.  (TK was 2 everywhere: at d = 512 the in-projection's dY [M, 1536] was read 16 times -- 190 GB out of
@@ -63,7 +80,44 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_block_kernel(GemmTnArgs a) {
     bsum[i] = 0.f;
   }
   constexpr int UN = 4;                  // row groups (of 4 rows) in flight per wave
-  for (long mb = m_lo + 4 * UN * wave; mb < m_hi; mb += 16 * UN) {
+  long t_lo = m_lo;
+  if (a.walk) {
+    // The complete 64-row groups of the chunk, every lane in range: one basic block per group -- 4 (TN + TK) unmasked loads, then the MFMAs --
+    // with the row maps walked.  (A two-register-set pipeline of half groups -- loads of one behind the MFMAs of the other -- was built twice and
+    // spilled 26 - 50 registers at two waves per SIMD; a spill reload waits for every load in flight, and it ran 1.7 x slower.  In the general loop below every load sits behind its own range test and each row costs two 64-bit divisions
+    // per operand: ~1 500 cycles of vector work per 128 MFMAs that nothing overlaps within the wave.)
+    const long nfull = (m_hi - m_lo) / 64;
+    t_lo = m_lo + 64 * nfull;
+    RowWalk wy, wx;
+    wy.init(m_lo + 16 * wave + fg, a.Ry, a.Gy, a.offy);
+    wx.init(m_lo + 16 * wave + fg, a.Rx, a.Gx, a.offx);
+    const float *const Ybase = a.dY + n0 + fr, *const Xbase = a.X + k0 + fr;
+    for (long gi = 0; gi < nfull; ++gi) {
+      float av[UN][TN], bv[UN][TK];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const float *py = Ybase + wy.src() * a.ldy, *px = Xbase + wx.src() * a.ldx;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) av[u][i] = py[16 * i];
+#pragma unroll
+        for (int j = 0; j < TK; ++j) bv[u][j] = px[16 * j];
+        wy.step(u + 1 < UN ? 4 : 52); wx.step(u + 1 < UN ? 4 : 52);        // rows +0, +4, +8, +12 | +64 ...
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) bsum2[j] += bv[u][j];
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          bsum[i] += av[u][i];
+#pragma unroll
+          for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  for (long mb = t_lo + 4 * UN * wave; mb < m_hi; mb += 16 * UN) {
     float av[UN][TN], bv[UN][TK];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {

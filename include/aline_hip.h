@@ -310,7 +310,7 @@ enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off 
        ALINE_DBG_NO_BWD_LAYER_FWD = 1u << 19, ALINE_DBG_NO_BWD_LAYER_FWD_FLAT = 1u << 20,
        ALINE_DBG_NO_BWD_GMM_FUSED = 1u << 21, ALINE_DBG_NO_BWD_GMM128 = 1u << 22, ALINE_DBG_NO_BWD_GMM_BATCHED = 1u << 23,
        ALINE_DBG_NO_BWD_ATTN_MFMA = 1u << 24,
-       /* bit 25: unused */
+       ALINE_DBG_NO_BWD_DW_WALK = 1u << 25,    /* weight-gradient products: the masked loop with per-row divisions for every row */
        ALINE_DBG_NO_BWD_GMM_WIDE = 1u << 26,   /* GMM head backward at F > 128: the per-row-atomics kernel instead of gmm_bwd_wide_kernel */
        ALINE_DBG_NO_BWD_SAVED_ACTS = 1u << 27,  /* backward: recompute the layers even when aline_rollout.saved_acts is given */
        ALINE_DBG_BWD_RECOMPUTE_F32 = 1u << 28,  /* per-op backward of an F16X3 model: forward recompute GEMMs in exact fp32 too */
