@@ -92,29 +92,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_block_kernel(GemmTnArgs a) {
     wy.init(m_lo + 16 * wave + fg, a.Ry, a.Gy, a.offy);
     wx.init(m_lo + 16 * wave + fg, a.Rx, a.Gx, a.offx);
     const float *const Ybase = a.dY + n0 + fr, *const Xbase = a.X + k0 + fr;
-    for (long gi = 0; gi < nfull; ++gi) {
-      float av[UN][TN], bv[UN][TK];
+    // Rotated by a row group of 4: the operands of (group g + 1, rows 4 u ..) are requested right behind the MFMAs of (group g, rows 4 u ..),
+    // into the registers those have just freed -- three MFMA phases (~3 000 cycles) ahead of their use, no second register set.
+    float av[UN][TN], bv[UN][TK];
+    auto load_u = [&](int u) {
+      const float *py = Ybase + wy.src() * a.ldy, *px = Xbase + wx.src() * a.ldx;
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const float *py = Ybase + wy.src() * a.ldy, *px = Xbase + wx.src() * a.ldx;
+      for (int i = 0; i < TN; ++i) av[u][i] = py[16 * i];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) av[u][i] = py[16 * i];
+      for (int j = 0; j < TK; ++j) bv[u][j] = px[16 * j];
+      wy.step(u + 1 < UN ? 4 : 52); wx.step(u + 1 < UN ? 4 : 52);        // rows +0, +4, +8, +12 | +64 ...
+    };
+    auto mul_u = [&](int u) {
 #pragma unroll
-        for (int j = 0; j < TK; ++j) bv[u][j] = px[16 * j];
-        wy.step(u + 1 < UN ? 4 : 52); wx.step(u + 1 < UN ? 4 : 52);        // rows +0, +4, +8, +12 | +64 ...
+      for (int j = 0; j < TK; ++j) bsum2[j] += bv[u][j];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        bsum[i] += av[u][i];
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
       }
+    };
+    if (nfull > 0) {
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
+      for (int u = 0; u < UN; ++u) load_u(u);
+      for (long gi = 0; gi + 1 < nfull; ++gi) {
 #pragma unroll
-        for (int j = 0; j < TK; ++j) bsum2[j] += bv[u][j];
-#pragma unroll
-      for (int u = 0; u < UN; ++u)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          bsum[i] += av[u][i];
-#pragma unroll
-          for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+        for (int u = 0; u < UN; ++u) {
+          __builtin_amdgcn_sched_barrier(0);
+          mul_u(u);
+          __builtin_amdgcn_sched_barrier(0);
+          load_u(u);
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UN; ++u) mul_u(u);
     }
   }
   for (long mb = t_lo + 4 * UN * wave; mb < m_hi; mb += 16 * UN) {
