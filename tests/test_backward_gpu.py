@@ -527,3 +527,37 @@ def test_per_op_backward_of_wider_models_against_the_fp64_oracle(d, F, H, prec):
             worst = (k, err)
         off += n
     assert worst[1] < 2e-4, (worst, len(deltas))
+
+
+@pytest.mark.gpu
+def test_weight_gradient_products_walked_loop_equals_the_general_loop():
+    """`gemm_tn_block_kernel`: complete 64-row groups run a branch-free loop with walked row maps (identity maps and row groups of >= 64 rows),
+    the rest the masked loop with per-row divisions.  Same gradients from both (the order of the fp32 sums differs: relative 1e-5), on a mix-mode
+    model without fused backward kernels (d = 64, F = 256: per-op pipeline), 100 data targets + 2 theta tokens (the target rows are a 102-row group
+    out of every 140-row instance: a non-identity map), B x T chosen so that the row counts are not multiples of 64."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import GPTask
+    from aline_amd.train import backward, reinforce_terms
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    model = Aline(Embedder(1, 1, 64, 256, 2, "mix"), Encoder(64, 256, 8, 0.0, 2), OutputHead(1, 1, 64, 256)).cuda().set_precision("f32")
+    task = GPTask(dim_x=1, embedding_type="mix", n_context_init=1, n_query_init=37, n_target_theta=2, n_target_data=100, device=dev)
+    batch = task.sample_batch(7)
+    T = 3
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        terms = reinforce_terms(ro, "mix", "all")
+    grads = []
+    for flags in ((), ("NO_BWD_DW_WALK",)):
+        for p in model.parameters():
+            p.grad = None
+        with _lib.debug(*flags), torch.no_grad():
+            backward(model, ro, terms["g_logp"], terms["g_ll"])
+            torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        scale = float(b.abs().max())
+        assert scale > 0 or float(a.abs().max()) == 0, k
+        assert float((a - b).abs().max()) <= 1e-5 * max(scale, 1e-30) + 1e-12, (k, float((a - b).abs().max()), scale)
