@@ -1,5 +1,6 @@
 """Sanity run of the training driver (aline_amd.driver.train) on a small location-finding problem: the prediction loss
-must fall during burn-in and keep falling once the design loss is switched on.   python tools/train_convergence.py [f32|f16x3]"""
+must fall during burn-in and keep falling once the design loss is switched on.   python tools/train_convergence.py [f32|f16x3] [d F H]
+(d = 32 / F = 128 / H = 4: fused backward kernels; any other width: the per-op pipeline)"""
 import json
 import os
 import random
@@ -19,7 +20,8 @@ class Cfg(dict):
 
 torch.manual_seed(0); random.seed(0)
 dev = torch.device("cuda")
-model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).to(dev)
+d, F, H = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (32, 128, 4)
+model = Aline(Embedder(2, 1, d, F, 2, "theta"), Encoder(d, F, H, 0.0, 3), OutputHead(2, 1, d, F)).to(dev)
 model.set_precision(sys.argv[1] if len(sys.argv) > 1 else "f32")       # "f16x3": rollouts on the s3 path, backward in exact fp32
 task = HiddenLocation(n_query_init=50, device=dev)
 cfg = Cfg(optimizer="AdamW", lr=1e-3, max_epoch=400, burning_epoch=200, checkpoint=0, output_dir="/tmp/aline_probe",
