@@ -202,6 +202,11 @@ int launch_acq_select(const Ctx &c, const SelectArgs &sel) {
   if (sel.g.P > ALINE_MAX_POINTS) return ALINE_EUNSUPPORTED;
   SelectArgs a = sel;
   a.range_flag = c.flag();
+  if (a.logits && a.g.P <= 256 && a.g.inst_B == 0 && !dbg(ALINE_DBG_SELECT_WORKGROUP)) {      // one wave per episode (kernels.h)
+    hipLaunchKernelGGL(acq_select_wave_kernel, dim3((unsigned)((a.g.B + 3) / 4)), dim3(256), 0, c.st, a);
+    CHECK_LAUNCH();
+    return ALINE_OK;
+  }
   hipLaunchKernelGGL(acq_select_kernel, dim3(a.g.B), dim3(256), (size_t)a.g.P * 12, c.st, a);
   CHECK_LAUNCH();
   return ALINE_OK;

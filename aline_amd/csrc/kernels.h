@@ -513,6 +513,97 @@ __global__ __launch_bounds__(256) void acq_select_kernel(SelectArgs a) {
   }
 }
 
+// The same selection for P <= 256 points with precomputed logits (the s3 / x3 / x5 rollouts): ONE WAVE per episode, four episodes per workgroup,
+// no LDS and no barrier -- lane l holds the points l, l + 64, l + 128, l + 192; the compacted (remaining-query) order is the point order, so
+// ballots give every query its place and the inverse-CDF scan walks the four 64-point chunks with a wave prefix sum.
+__global__ __launch_bounds__(256) void acq_select_wave_kernel(SelectArgs a) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.g.B) return;
+  const int P = a.g.P;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  float lg[4], pr[4];
+  bool isq[4];
+  int ci[4], nq = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int p = 64 * c + lane;
+    const bool valid = p < P;
+    float s = -INFINITY;
+    if (valid) {
+      s = a.logits[(long)b * a.logit_stride + p];
+      for (int k = 1; k < a.logit_nblk; ++k) s += a.logits[k * a.logit_blk_stride + (long)b * a.logit_stride + p];
+    }
+    lg[c] = s;
+    isq[c] = valid && !is_ctx(a.g, b, p);
+    const unsigned long long bal = __ballot(isq[c]);
+    ci[c] = nq + __popcll(bal & below);
+    nq += __popcll(bal);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mx = fmaxf(mx, isq[c] ? lg[c] : -INFINITY);
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { pr[c] = isq[c] ? __expf(lg[c] - mx) : 0.f; sum += pr[c]; }
+  sum = wave_sum(sum);
+  if (lane == 0 && !(sum <= 3.4e38f)) range_raise(a.range_flag, ALINE_RANGE_ACT);     // a NaN / +inf logit
+  const float inv = 1.f / sum;
+  float tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { pr[c] *= inv; tot += pr[c]; }
+  tot = wave_sum(tot);
+  if (a.zt) {
+    float *z = a.zt + (long)b * a.zt_stride;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (isq[c] && ci[c] < a.zt_width) z[ci[c]] = pr[c];
+    for (int i = nq + lane; i < a.zt_width; i += 64) z[i] = 0.f;
+  }
+  int choice = 0;
+  if (a.mode == 0) {            // argmax, first maximal index (torch.max semantics)
+    float best = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (isq[c] && (pr[c] > best || (pr[c] == best && ci[c] < bi))) { best = pr[c]; bi = ci[c]; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    choice = bi == 0x7fffffff ? 0 : bi;
+  } else if (a.mode == 2) {
+    choice = (int)a.forced[(long)b * a.forced_stride];
+    choice = min(max(choice, 0), nq - 1);
+  } else {                      // inverse CDF of Categorical(probs = zt / sum zt)
+    const float u = a.uniform[b] * tot;
+    float run = 0.f; int found = nq - 1; bool done = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float incl = pr[c];
+      for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      const unsigned long long bal = __ballot(isq[c] && (run + incl) > u);
+      if (!done && bal) { found = __shfl(ci[c], __ffsll((long long)bal) - 1, 64); done = true; }
+      run += __shfl(incl, 63, 64);
+    }
+    choice = found;
+  }
+  // probability and point slot of the chosen query (one lane holds it)
+  float val = 0.f; int sl = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (isq[c] && ci[c] == choice) { val = pr[c]; sl = 64 * c + lane; }
+  val = wave_sum(val);
+  sl = (int)wave_sum((float)sl);          // (slots < 256: exact in fp32)
+  if (a.mode != 0) val = val / tot;       // Categorical(probs).log_prob uses probs / probs.sum() ...
+  if (lane == 0) {
+    if (a.mode != 0) val = fminf(fmaxf(val, 1.1920929e-07f), 1.f - 1.1920929e-07f);      // ... clamped to [eps, 1 - eps]
+    if (a.idx) a.idx[(long)b * a.idx_stride] = choice;
+    if (a.log_prob) a.log_prob[(long)b * a.lp_stride] = logf(val);
+    if (a.slot) a.slot[(long)b * a.slot_stride] = sl;
+    if (a.role_out) a.role_out[(long)b * P + sl] = (P - nq) + 1;
+  }
+}
+
 // (G9/G10: the second layers of the C GMM heads are reduced in the GEMM epilogue, gemm.h `red_*`; the parameter
 // maps mean_c = raw[c][0], std_c = softplus(raw[c][1]) + std_min, weight = softmax_c(raw[c][2]) -- the reference's
 // stack/movedim/flatten/chunk, head.py:264-265, with dim_y == 1 -- and compute_ll are wide::gmm_raw_finish_kernel.)

@@ -305,6 +305,7 @@ enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off 
        ALINE_DBG_FUSED_STAMPS = 1u << 10,      /* in-kernel phase stamps (diagnostic instantiations) */
        ALINE_DBG_WIDE_STAMPS = 1u << 11,
        ALINE_DBG_BWD_TAIL_PC = 1u << 12,       /* producer / consumer tail backward */
+       ALINE_DBG_SELECT_WORKGROUP = 1u << 13,  /* design selection: the workgroup-per-episode kernel also where one wave per episode would do */
        /* backward: switch ONE fused kernel back to the per-op pipeline it replaces */
        ALINE_DBG_NO_BWD_TAIL = 1u << 16, ALINE_DBG_NO_BWD_ATTN_BLOCK = 1u << 17, ALINE_DBG_NO_BWD_ACQ = 1u << 18,
        ALINE_DBG_NO_BWD_LAYER_FWD = 1u << 19, ALINE_DBG_NO_BWD_LAYER_FWD_FLAT = 1u << 20,

@@ -206,3 +206,36 @@ def test_time_token_on_the_fused_reference_precision_paths(emb, d, path, reverse
                     time_token_T=T, time_token_reverse=not reverse, keep_zt=True).run()
     torch.cuda.synchronize()
     assert (other.zt.float().cpu() - out["f16x3"][1]).abs().max() > 1e-4       # the other schedule is another function
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("select", ["sample", "argmax", "forced"])
+def test_one_wave_per_episode_selection_equals_the_workgroup_kernel(select):
+    """model/head.py:347-362 on the device: `acq_select_wave_kernel` (P <= 256, one wave per episode, no LDS) against `acq_select_kernel`
+    (any P, a workgroup per episode) on the same rollout -- same designs, slots and roles, probabilities / log-probabilities to fp32 rounding
+    (the two sum the softmax in different orders)."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    torch.manual_seed(11)
+    dev = torch.device("cuda")
+    model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda().set_precision("f16x3")
+    batch = HiddenLocation(n_query_init=150, device=dev).sample_batch(37)       # P = 151: three 64-point chunks, the last one ragged
+    T = 12
+    kw = {}
+    if select == "sample":
+        kw["uniform"] = torch.rand(T, 37, device=dev)
+    if select == "forced":
+        kw["forced_idx"] = torch.stack([torch.randint(0, 150 - t, (37,)) for t in range(T)], 1)
+    outs = []
+    for flags in ((), ("SELECT_WORKGROUP",)):
+        with _lib.debug(*flags), torch.no_grad():
+            ro = Rollout(model, batch, T, select=select, keep_zt=True, **kw).run()
+            torch.cuda.synchronize()
+        assert ro.path == "s3::step_kernel"
+        outs.append((ro.idx.clone(), ro.slot.clone(), ro.log_prob.clone(), ro.zt.clone(), ro.role.clone(), ro.target_ll.clone()))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4])
+    assert float((a[2] - b[2]).abs().max()) < 2e-6
+    assert float((a[3] - b[3]).abs().max()) < 1e-7
+    assert float((a[5] - b[5]).abs().max()) < 1e-6
