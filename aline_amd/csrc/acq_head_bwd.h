@@ -114,15 +114,25 @@ __global__ __launch_bounds__(THREADS) void bwd_kernel(Args a) {
   for (int ob = 0; ob < 8; ++ob) { gW1[ob][0] = gW1[ob][1] = gw2[ob] = zero4(); gB1[ob] = 0.f; }
   const long ntiles = (a.M + 15) / 16;
   const long tstep = (long)gridDim.x * WAVES;
+  // the rows of the tile after this one are requested while this one is computed (as in tailbwd::tail_kernel and gmmb::bwd_kernel)
+  f32x4 nz[2];
+  float ndl;
+  auto load_tile = [&](long tile) {
+    const long rn = min(tile * 16 + tok, a.M - 1);
+    nz[0] = ld4(a.Z + rn * D + 4 * g); nz[1] = ld4(a.Z + rn * D + 16 + 4 * g);
+    ndl = a.logit[rn];
+  };
+  if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
   for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
     int zoff = 0;
     asm volatile("" : "+v"(zoff));
     const float *W = lds + zoff;
     float *scr = lds + zoff + L_SCR + wave * SCR;
-    const long row = tile * 16 + tok, rc = min(row, a.M - 1);
+    const long row = tile * 16 + tok;
     const bool ok = row < a.M;
-    const f32x4 z[2] = {ld4(a.Z + rc * D + 4 * g), ld4(a.Z + rc * D + 16 + 4 * g)};
-    const float dl = ok ? a.logit[rc] : 0.f;
+    const f32x4 z[2] = {nz[0], nz[1]};
+    const float dl = ok ? ndl : 0.f;
+    if (tile + tstep < ntiles) load_tile(tile + tstep);
     f32x4 h[8];
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
@@ -315,16 +325,26 @@ __global__ __launch_bounds__(THREADS) void bwd_kernel(Args a) {
   for (int ob = 0; ob < 8; ++ob) { gW1[ob][0] = gW1[ob][1] = gw2[0][ob] = gw2[1][ob] = gw2[2][ob] = zero4(); gB1[ob] = 0.f; }
   const long ntiles = (a.rows + 15) / 16;
   float *dzc = a.dzc + (long)c * a.rows * D;
-  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += (long)gridDim.x * WAVES) {
+  // the rows of the tile after this one are requested while this one is computed (one wave per SIMD: nobody else hides the round trip --
+  // PMC at the cfg3 shape: matrix pipe 49 %, the wave waiting for an operand 41 % of its life before this)
+  const long tstep = (long)gridDim.x * WAVES;
+  f32x4 nz[2], ndr;
+  auto load_tile = [&](long tile) {
+    const long qn = min(tile * 16 + tok, a.rows - 1), zr = token_row(a, qn);
+    nz[0] = ld4(a.Z + zr * D + 4 * g); nz[1] = ld4(a.Z + zr * D + 16 + 4 * g);
+    ndr = ld4(a.draw + (qn * a.C + c) * 4);
+  };
+  if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
     int zoff = 0;
     asm volatile("" : "+v"(zoff));
     const float *W = lds + zoff;
     float *scr = lds + zoff + L_SCR + wave * SCR;
-    const long q = tile * 16 + tok, qc = min(q, a.rows - 1), zr = token_row(a, qc);
+    const long q = tile * 16 + tok;
     const bool ok = q < a.rows;
-    const f32x4 z[2] = {ld4(a.Z + zr * D + 4 * g), ld4(a.Z + zr * D + 16 + 4 * g)};
-    f32x4 dr = ld4(a.draw + (qc * a.C + c) * 4);
-    if (!ok) dr = zero4();
+    const f32x4 z[2] = {nz[0], nz[1]};
+    f32x4 dr = ok ? ndr : zero4();
+    if (tile + tstep < ntiles) load_tile(tile + tstep);
     f32x4 h[8];
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
