@@ -4,15 +4,19 @@ alpha = gamma = 1, teacher-forced designs)."""
 import pytest
 import torch
 
-from helpers import native_model, to_dev
+from helpers import grad_errors, native_model, to_dev
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["cfg2_location_d32", "cfg1_almix_d1_data", "aux_timetoken_train"])
+@pytest.mark.parametrize("name", ["cfg2_location_d32", "cfg1_almix_d1_data", "aux_timetoken_train",
+                                  "grad_cfg2_d256", "grad_cfg5_d512", "grad_cfg3_split", "grad_cfg4_ces"])
 def test_gradients_match_reference_autograd(golden, name):
     """(aux_timetoken_train: data mode with the time token of model/head.py:342-345 -- the acquisition MLP sees [z | t / T],
-    train_aline.py:80-82 -- incl. the gradient of the time column of its first layer; fixture of oracle/make_golden_r3.py)"""
+    train_aline.py:80-82 -- incl. the gradient of the time column of its first layer; fixture of oracle/make_golden_r3.py.
+    grad_*: round-4 fixtures of oracle/make_golden_r4.py -- d = 256 / F = 1024 / head_dim 32, d = 512 / head_dim 64 with the
+    predefined mask, the cfg3 split mask (103 targets, 304 rows) and CES (dim_x = 6): the widths and masks the training numbers of
+    the bench line and of tools/config_bench.py are quoted on.)"""
     from aline_amd.train import train_step
     fx = golden(name)
     dims, T = fx.meta["dims"], fx.meta["T"]
@@ -22,17 +26,19 @@ def test_gradients_match_reference_autograd(golden, name):
     torch.cuda.synchronize()
     assert abs(float(terms["predict_loss"]) - float(fx.np("train.predict_loss"))) < 1e-4
     assert abs(float(terms["design_loss"]) - float(fx.np("train.design_loss"))) < 5e-3
-    # the batch-normalised rewards themselves (train_aline.py:113-122): z-scores of clamped NLL gains over B = 4 / 8
+    # the batch-normalised rewards themselves (train_aline.py:113-122): z-scores of clamped NLL gains over B = 2 ... 8
     # episodes, so an NLL difference of 1e-5 next to the clamp moves an entry by ~1e-3
     assert float((terms["R"].cpu() - fx.t("train.R")).abs().max()) < 5e-3
-    worst = ("", 0.0)
-    for k, p in model.named_parameters():
-        ref = fx.t("train.grad." + k)
-        got = p.grad.detach().cpu()
-        scale = max(float(ref.abs().max()), 1e-4)
-        err = float((got - ref).abs().max()) / scale
-        if err > worst[1]:
-            worst = (k, err)
+    named = [(k, p.grad) for k, p in model.named_parameters()]
+    if "train64.design_loss" in fx:
+        # round-4 fixtures carry the reference's gradients twice: its fp32 run and the same rollout in fp64.  The reference's own
+        # fp32 rounding is up to 1.2e-3 of a parameter's max |grad| there (CES, d = 256 acquisition head: measured against its
+        # fp64 run), so the fp64 gradients are the 1e-3 target and the fp32 ones are held at 3e-3.
+        worst64 = max(grad_errors(fx, named, "train64").items(), key=lambda kv: kv[1])
+        worst32 = max(grad_errors(fx, named, "train").items(), key=lambda kv: kv[1])
+        assert worst64[1] < 1e-3 and worst32[1] < 3e-3, (worst64, worst32)
+        return
+    worst = max(grad_errors(fx, named).items(), key=lambda kv: kv[1])
     # measured on MI355X: <= 4e-5 of each parameter's max |grad| (the acquisition output bias has a
     # mathematically zero gradient -- softmax shift invariance -- hence the absolute floor in `scale`)
     assert worst[1] < 1e-3, worst

@@ -1,0 +1,120 @@
+"""GPU, round 4: the parity nets VERDICT r3 asked for -- the benchmarked d = 256 launch shape of `x3::layer_kernel` (full tile
+rounds + a tail round of `ktail` < 8 waves + idle-streaming waves) against the CPU oracle, and `eval_boed` (utils/eval.py:142-198)
+end to end on a tape of the reference's own random draws."""
+import pytest
+import torch
+
+import aline_oracle as orc
+from helpers import maxdiff, native_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _d256_model(seed=0):
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    torch.manual_seed(seed)
+    model = Aline(Embedder(2, 1, 256, 1024, 2, "theta"), Encoder(256, 1024, 8, 0.0, 3), OutputHead(2, 1, 256, 1024)).cuda().eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    return model
+
+
+def _x3_round_shape(B, tpe, n_cu=None):
+    """The three-way round structure of x3::layer_kernel for B episodes of `tpe` tiles (x3_impl.h, tile rounds): (full, rem, ktail)."""
+    n_cu = n_cu or torch.cuda.get_device_properties(0).multi_processor_count
+    ntiles, per_round = B * tpe, n_cu * 8
+    full = ntiles // per_round
+    rem = ntiles - full * per_round
+    return full, rem, (rem + n_cu - 1) // n_cu
+
+
+@pytest.mark.parametrize("B,T,take", [
+    # the bench's d256 leg (bench.py: B = 1000, T = 30, n_query = 200: 13 000 tiles = 6 full rounds of 2 048, 712 tail tiles on
+    # 3 waves per workgroup, 5 idle-streaming waves): first / last / spread episodes, incl. episodes whose tiles all fall in the
+    # tail round (tile >= 6 * 2048 = 12 288 <=> episode >= 946)
+    (1000, 30, [0, 1, 157, 158, 314, 472, 473, 630, 787, 945, 946, 947, 970, 997, 998, 999]),
+    # a mid-size case: 170 episodes = 2 210 tiles = 1 full round + 162 tail tiles (ktail = 1 on 256 CUs)
+    (170, 6, [0, 1, 78, 79, 156, 157, 158, 159, 160, 165, 168, 169]),
+])
+def test_fullsize_d256_slice_against_the_cpu_oracle(B, T, take):
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    nq = 200
+    model = _d256_model()
+    torch.manual_seed(1)
+    batch = HiddenLocation(n_query_init=nq).sample_batch(B)
+    model.set_precision("f16x3")
+    ro = Rollout(model, batch, T, select="argmax", keep_zt=True)
+    assert ro.path == "x3::layer_kernel"
+    ro.run()
+    torch.cuda.synchronize()
+    assert ro.range_status() == 0
+    full, rem, ktail = _x3_round_shape(B, 13)
+    assert full >= 1 and rem > 0 and ktail < 8, (full, rem, ktail)        # the branch combination this test is for
+    take = torch.tensor(take)
+    assert int(take.max()) * 13 + 12 >= full * torch.cuda.get_device_properties(0).multi_processor_count * 8   # a tail-round episode is in the slice
+    sd = orc.cast_state_dict(model.state_dict())
+    cpu = {k: v[take].cpu() for k, v in batch.items() if torch.is_tensor(v) and v.dim() >= 2 and v.shape[0] == B}
+    cfg = dict(embedding_type="theta", n_head=8, num_layers=3, num_components=10, std_min=1e-4, n_target_theta=2)
+    ref = orc.rollout(sd, cpu, cfg, T, forced_idx=ro.idx[take].cpu())
+    assert float((ro.target_ll[:, take].cpu() - torch.stack(ref["target_ll"])).abs().max()) < 1e-4
+    assert float((ro.log_prob[take].cpu() - torch.stack(ref["log_prob"], 1)).abs().max()) < 2e-4
+    for t in (0, T // 2, T - 1):
+        assert float((ro.zt[t][take].cpu()[:, :nq - t] - ref["zt"][t]).abs().max()) < 5e-5
+    # every episode of the batch (not only the slice): finite, one new context point per step, probabilities sum to one
+    assert torch.isfinite(ro.target_ll).all() and torch.isfinite(ro.log_prob).all()
+    assert (ro.role.cpu() > 0).sum(1).eq(1 + T).all()
+    assert torch.allclose(ro.zt.sum(-1).cpu(), torch.ones(T, B), atol=1e-5)
+
+
+class _Tape:
+    """Replays the recorded draws of the reference's `eval_boed` call through the product task's `sample_batch` / `sample_theta`."""
+
+    def __init__(self, fx, task):
+        from aline_amd.utils import AttrDict
+        self.fx, self.nb, self.nt, self.AttrDict = fx, 0, 0, AttrDict
+        task.sample_batch, task.sample_theta = self.sample_batch, self.sample_theta
+
+    def sample_batch(self, batch_size):
+        i, fx = self.nb, self.fx
+        self.nb += 1
+        self.nt += 1                  # (the reference's sample_batch draws its theta through sample_theta: that draw is in the batch)
+        b = self.AttrDict({k: fx.t(f"batch{i}.{k}").cuda() for k in ("context_x", "context_y", "query_x", "query_y", "target_theta", "target_all")})
+        assert b.context_x.shape[0] == batch_size
+        b.n_target_theta = 2
+        return b
+
+    def sample_theta(self, shape):
+        th = self.fx.t(f"theta{self.nt}").cuda()
+        self.nt += 1
+        want = [shape] if isinstance(shape, int) else list(shape)
+        assert list(th.shape[:len(want)]) == want
+        return th
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_eval_boed_on_the_reference_tape(golden, precision):
+    """`eval_boed` (utils/eval.py:142-198; stepwise, err_type 'se') against the bounds the REFERENCE's eval_boed returned, on
+    the same model, with every random draw of the reference's call replayed in call order (fixture `eval_boed_loc`,
+    oracle/make_golden_r4.py: M = 12 outer samples in 2 batches of 6, T = 5, L = 64): get_traces -> argmax designs -> histories
+    -> sPCE / sNMC per step -> mean and standard error over the outer samples."""
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd.utils import eval_boed, get_traces
+    fx = golden("eval_boed_loc")
+    m = fx.meta
+    model, _ = native_model(m["dims"], m["wseed"], precision)
+    task = HiddenLocation(n_query_init=m["n_q0"])
+    tape = _Tape(fx, task)
+    out = eval_boed(model, task, T=m["T"], L=m["L"], M=m["M"], batch_size=m["B"], stepwise=True, err_type="se")
+    assert tape.nb == m["n_batch"] and tape.nt == m["n_theta"]               # the product makes the reference's draws, in its order
+    for k in ("pce_mean", "pce_err", "nmc_mean", "nmc_err"):
+        assert out[k].shape == fx.t(k).shape
+        assert maxdiff(out[k], fx.t(k)) < 2e-4, (k, maxdiff(out[k], fx.t(k)))
+    # and the histories themselves: the designs the eval-mode model picked, in order of acquisition (eval.py:8-39)
+    tape = _Tape(fx, task)
+    for i in range(2):
+        th0, x, y = get_traces(model, task, m["T"], m["B"], False)
+        assert torch.equal(x.cpu(), fx.t(f"trace{i}.x")) and torch.equal(y.cpu(), fx.t(f"trace{i}.y"))
+        assert torch.equal(th0.cpu(), fx.t(f"trace{i}.theta0"))
+        tape.nt += 1                                                            # (skip the contrastive draw between two traces)
