@@ -107,8 +107,8 @@ def _load():
         "aline_debug_set_flags": (C.c_uint32, [C.c_uint32]),
         "aline_debug_get_flags": (C.c_uint32, []),
         "aline_debug_set_param": (C.c_int, [C.c_int, C.c_int]),
+        "aline_debug_get_param": (C.c_int, [C.c_int]),
         "aline_debug_stamps_offset": (C.c_size_t, [MP, RP]),
-        "aline_debug_wlog_offset": (C.c_size_t, [MP, RP]),
         "aline_debug_xraw_offset": (C.c_size_t, [MP, RP]),
         "aline_cholesky_upper": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp]),
         "aline_rollout_backward_workspace_bytes": (C.c_size_t, [MP, RP, C.c_int]),
@@ -122,7 +122,7 @@ def _load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.aline_abi_version() != 4:
+    if lib.aline_abi_version() != 5:
         raise RuntimeError("aline_amd: libaline_hip.so ABI version mismatch")
     return lib, sig
 
@@ -130,9 +130,9 @@ def _load():
 lib, SIGNATURES = _load()
 
 # ---- diagnostics: the library never reads the environment; tests and A/B tools set its diagnostic word explicitly -------
-DBG = {"DISABLE_FUSED": 1 << 0, "DISABLE_WIDE": 1 << 1, "DISABLE_X3": 1 << 2, "DISABLE_S3": 1 << 3, "WIDE_BLOCKS": 1 << 4,
+DBG = {"DISABLE_FUSED": 1 << 0, "DISABLE_X3": 1 << 2, "DISABLE_S3": 1 << 3,
        "NO_LAYER_TAIL": 1 << 5, "FULL_QKV": 1 << 6, "VALU_ATTENTION": 1 << 7, "S3_GENERIC_EMBED": 1 << 8, "CES_GENERIC": 1 << 9,
-       "FUSED_STAMPS": 1 << 10, "WIDE_STAMPS": 1 << 11, "BWD_TAIL_PC": 1 << 12, "SELECT_WORKGROUP": 1 << 13,
+       "FUSED_STAMPS": 1 << 10, "SELECT_WORKGROUP": 1 << 13,
        "NO_BWD_TAIL": 1 << 16, "NO_BWD_ATTN_BLOCK": 1 << 17, "NO_BWD_ACQ": 1 << 18, "NO_BWD_LAYER_FWD": 1 << 19,
        "NO_BWD_LAYER_FWD_FLAT": 1 << 20, "NO_BWD_GMM_FUSED": 1 << 21, "NO_BWD_GMM128": 1 << 22, "NO_BWD_GMM_BATCHED": 1 << 23,
        "NO_BWD_ATTN_MFMA": 1 << 24, "NO_BWD_DW_WALK": 1 << 25, "NO_BWD_GMM_WIDE": 1 << 26, "NO_BWD_SAVED_ACTS": 1 << 27, "BWD_RECOMPUTE_F32": 1 << 28, "BWD_DW_TK2": 1 << 29}
@@ -151,6 +151,7 @@ class debug:
 
     def __enter__(self):
         self.old = lib.aline_debug_get_flags()
+        self.old_params = {k: lib.aline_debug_get_param(k) for k in self.params}
         lib.aline_debug_set_flags(self.old | self.bits)
         for k, v in self.params.items():
             check(lib.aline_debug_set_param(k, v), "debug_set_param")
@@ -158,13 +159,18 @@ class debug:
 
     def __exit__(self, *exc):
         lib.aline_debug_set_flags(self.old)
-        for k in self.params:
-            lib.aline_debug_set_param(k, 0)
+        for k, v in self.old_params.items():       # (the values of the enclosing block, not 0: blocks nest)
+            lib.aline_debug_set_param(k, v)
         return False
 
 
+def debug_state():
+    """(flags, knobs) of the library's diagnostic word right now."""
+    return (int(lib.aline_debug_get_flags()), tuple(int(lib.aline_debug_get_param(k)) for k in sorted(DBG_PARAM.values())))
+
+
 def debug_env(env):
-    """The same from a dict keyed like the former environment switches, e.g. {"ALINE_DISABLE_WIDE": "1", "ALINE_S3_WAVES": "16",
+    """The same from a dict keyed like the former environment switches, e.g. {"ALINE_DISABLE_X3": "1", "ALINE_S3_WAVES": "16",
     "ALINE_BWD_TAIL": "0"} (tests / tools keep their tables of variants in this form)."""
     flags, params = [], {}
     for k, v in env.items():

@@ -8,8 +8,7 @@
 #include "fused_rollout.h"
 #include "fused_side.h"
 #include "fused_tail.h"
-#include "wide.h"
-#include "wide_step.h"
+#include "tile_image.h"
 #include "x3.h"
 #include "s3.h"
 #include "attn3.h"
@@ -51,7 +50,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Flag, xKX, xKpos, Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, wX, wX1, wQKV, wA, wLog, wImg, wZt, wZimg, wRaw, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
+  size_t Flag, xKX, xKpos, Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -90,16 +89,6 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
                  (size_t)(ALINE_MAX_COMPONENTS + 2) * fused::SIDE_FRAGS);
   p.Stamps = take(512);   // diagnostic stamps of the fused kernel (8 x 16 x u64)
   p.Ztg = take((size_t)T * B * n_t * d);   // fused rollout: target-row encodings of all steps
-  if (T > 0 && m.d == wide::D && m.precision == ALINE_PREC_BF16) {   // wide path (bf16 rows = half a float)
-    const size_t img = (size_t)wide::tile_rows(M) * d / 2;     // one bf16 tile image, in floats
-    p.wX = take(img); p.wX1 = take(img); p.wQKV = take(3 * img);
-    p.wA = take(img); p.wLog = take(M);
-    p.wImg = take((size_t)m.L * wide::layer_words(m.F) + wide::head_words(m.F) + (size_t)Cc * wide::gmm_words(m.F) +
-                  2 * (size_t)wide::emb_words(m.F));
-    p.wZt = take((size_t)B * n_t * d);
-    p.wZimg = take((size_t)wide::tile_rows((long)T * B * n_t) * d / 2);     // bf16 tile image of all steps' target rows
-    p.wRaw = take((size_t)T * B * n_t * kRawStride);                         // raw GMM head outputs [row][3 c + j]
-  }
   if (T > 0 && (m.d == x3::D || m.d == x5::D) && m.precision == ALINE_PREC_F16X3) {     // x3 / x5 path (x3.h): split-f16 tile images
     const bool w5 = m.d == x5::D;
     auto pieces = [w5](long tiles) { return (size_t)(w5 ? x5::img_pieces(tiles) : x3::img_pieces(tiles)) * 4; };
@@ -421,13 +410,13 @@ static int gmm_heads(const Ctx &c, GemmArgs a, int rows, float *mean, float *sd,
   a.red_nout = 3; a.red_out = raw; a.red_stride = stride; a.red_block_stride = (long)rows * stride;
   TRY(launch_gemm_fwd(c, a, m.C));
   CHECK_LAUNCH();
-  wide::GmmRawArgs f{};
+  img::GmmRawArgs f{};
   f.range_flag = c.flag();
   f.raw = raw; f.raw_stride = stride; f.rows = rows; f.C = m.C; f.std_min = m.std_min;
   f.nblk = gemm_col_blocks(m.F); f.blk_stride = (long)rows * stride;
   f.mean = mean; f.sd = sd; f.wgt = wgt;
   f.value = value; f.ll = (ll && value) ? ll : nullptr; f.value_row0 = value_row0; f.value_mod = value_mod;
-  hipLaunchKernelGGL(wide::gmm_raw_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, c.st, f);
+  hipLaunchKernelGGL(img::gmm_raw_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, c.st, f);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -565,19 +554,6 @@ __global__ void set_scalar_kernel(float *p, float v) { p[0] = v; }
 
 }  // namespace
 
-template <int MODE>
-static int launch_wide_block(const Ctx &c, wide::BlockArgs a) {
-  const int F = c.m->F;
-  const int nprm = MODE == wide::WB_QKV ? 3 * wide::D : MODE == wide::WB_OUT ? 3 * wide::D
-                   : MODE == wide::WB_FFN ? F + 3 * wide::D : MODE == wide::WB_GMM ? 4 * F + 4 : 2 * F + 4;
-  const size_t smem = (size_t)(2 * wide::CHUNK_W + nprm) * 4;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_block_kernel<MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  const unsigned grid = (unsigned)((a.M + wide::WG_TOK - 1) / wide::WG_TOK);
-  hipLaunchKernelGGL(wide::wide_block_kernel<MODE>, dim3(grid), dim3(wide::BTHREADS), smem, c.st, a);
-  CHECK_LAUNCH();
-  return ALINE_OK;
-}
 
 
 // The time token of step t (model.time_token): t / T as the training loop feeds it (train_aline.py:82); time_token_T < 0 selects the
@@ -631,11 +607,7 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
 
 template <int F, int NW, int MAXNKP>
 static int launch_s3_step_v(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a) {
-#ifdef S3_PREFETCH         // (timing experiment, tools/x3_variants.sh: the next tile's rows requested a tile ahead: 2 % SLOWER
-  constexpr bool PF = NW >= 12;      //  at 12 and at 16 waves per workgroup -- three or four waves per SIMD hide the load already)
-#else
   constexpr bool PF = false;
-#endif
   // (set at every launch: the attribute is per device, and a process may drive several)
   if constexpr (F == 128) {      // (the width of the fused backward: the only one whose rollouts are asked to keep their activations)
     if (a.sv) {
@@ -942,186 +914,6 @@ static int rollout_fused(const aline_model *m, const aline_rollout *r, void *ws,
   return ALINE_OK;
 }
 
-// The wide path (wide.h) covers d = 256 / head_dim 32 in bf16: streamed-weight fused blocks.
-static bool wide_eligible(const aline_model &m, const aline_rollout &r) {
-  if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
-  if (dbg(ALINE_DBG_DISABLE_WIDE)) return false;
-  if (m.precision != ALINE_PREC_BF16 || m.d != wide::D || m.H != wide::H || m.F % 64 || m.time_token) return false;
-  if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > wide::WNK) return false;
-  if (m.dim_x > 8 || m.dim_y > 8) return false;      // wide_embed_kernel keeps one input row in 8 registers
-  return true;
-}
-
-static int rollout_wide(const aline_model *m, const aline_rollout *r, void *ws, size_t ws_bytes, void *stream) {
-  Ctx c;
-  TRY(rollout_ctx(m, r, ws, ws_bytes, stream, c));
-  TRY(check_select(r->select_mode, r->uniform, r->forced_idx));
-  TRY(c.clear_flag());
-  const int n_t = c.g.n_td + c.g.n_th, N = c.g.N, M = r->B * N, F = m->F;
-  hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B, r->P, r->n_ctx0);
-  CHECK_LAUNCH();
-  // weights -> streamed bf16 fragment images (once per rollout)
-  wide::PackArgs pa{};
-  pa.L = m->L; pa.F = F;
-  for (int l = 0; l < m->L; ++l) {
-    pa.in_proj_w[l] = m->in_proj_w[l]; pa.in_proj_b[l] = m->in_proj_b[l];
-    pa.out_proj_w[l] = m->out_proj_w[l]; pa.out_proj_b[l] = m->out_proj_b[l];
-    pa.lin1_w[l] = m->lin1_w[l]; pa.lin1_b[l] = m->lin1_b[l];
-    pa.lin2_w[l] = m->lin2_w[l]; pa.lin2_b[l] = m->lin2_b[l];
-    pa.n1w[l] = m->norm1_w[l]; pa.n1b[l] = m->norm1_b[l];
-    pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
-  }
-  pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
-  pa.C = m->C; pa.emb_w2[0] = m->x_w2; pa.emb_w2[1] = m->y_w2;
-  for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
-  unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.wImg));
-  pa.out = img;
-  hipLaunchKernelGGL(wide::pack_kernel, dim3(1024), dim3(256), 0, c.st, pa);
-  CHECK_LAUNCH();
-  {   // point embeddings (step-invariant): Ex over the point (+ target-data) rows, Ey over the point rows
-    const unsigned *ei = img + (long)m->L * wide::layer_words(F) + wide::head_words(F) + (long)m->C * wide::gmm_words(F);
-    wide::EmbedArgs ea{};
-    ea.B = r->B; ea.F = F; ea.out = c.at(c.pl.Ex);
-    ea.src = Src3{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}}; ea.rows_per_ep = r->P + r->n_target_data;
-    ea.K = m->dim_x; ea.w1 = m->x_w1; ea.b1 = m->x_b1; ea.b2 = m->x_b2; ea.wimg = ei;
-    for (int pass = 0; pass < 2; ++pass) {
-      const size_t smem = (size_t)(2 * wide::CHUNK_W + F * ea.K + F + wide::D) * 4;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_embed_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      const long rows = (long)ea.B * ea.rows_per_ep;
-      hipLaunchKernelGGL(wide::wide_embed_kernel, dim3((unsigned)((rows + wide::WG_TOK - 1) / wide::WG_TOK)), dim3(wide::BTHREADS),
-                         smem, c.st, ea);
-      CHECK_LAUNCH();
-      ea.src = Src3{{r->point_y, nullptr, nullptr}, {r->P, 0, 0}}; ea.rows_per_ep = r->P; ea.out = c.at(c.pl.Ey);
-      ea.K = m->dim_y; ea.w1 = m->y_w1; ea.b1 = m->y_b1; ea.b2 = m->y_b2; ea.wimg = ei + wide::emb_words(F);
-    }
-  }
-  using wide::u32x4;
-  u32x4 *X = reinterpret_cast<u32x4 *>(c.at(c.pl.wX)), *X1 = reinterpret_cast<u32x4 *>(c.at(c.pl.wX1));
-  u32x4 *QKV = reinterpret_cast<u32x4 *>(c.at(c.pl.wQKV)), *A = reinterpret_cast<u32x4 *>(c.at(c.pl.wA));
-  const long ipc = wide::tile_rows(M) * (wide::D / 8);          // pieces per image
-  float *logits = c.at(c.pl.wLog), *Zt = c.at(c.pl.wZt);
-  const long lw = wide::layer_words(F);
-  const long nfw = (long)wide::layer_chunks(F) * wide::CHUNK_W;
-  // one fused kernel per step when an episode fits a workgroup (<= 16 token tiles, LDS for the parameters);
-  // otherwise the streamed per-block kernels with activations in HBM
-  const bool fused_step = N <= 256 && wide::step_lds_bytes(F) <= 160 * 1024 && !dbg(ALINE_DBG_WIDE_BLOCKS);
-  if (fused_step) {   // the input image is assembled once (X1 is free in this mode) and patched row-wise between steps
-    hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
-                       c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X1);
-    CHECK_LAUNCH();
-  }
-  for (int t = 0; t < r->T; ++t) {
-    c.g.n_ctx = r->n_ctx0 + t;
-    if (!fused_step) {
-      hipLaunchKernelGGL(wide::assemble_bf16_kernel, grid1d((size_t)ipc), dim3(256), 0, c.st, c.g,
-                         c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, m->theta_tokens, X);
-      CHECK_LAUNCH();
-    }
-    if (fused_step) {
-      wide::StepArgs sa{};
-      sa.g = c.g; sa.XIN = X1; sa.X0 = X; sa.img = img; sa.L = m->L; sa.F = F; sa.logits = logits;
-      // target-row encodings of every step are kept; their GMM heads run once after the loop (large GEMMs)
-      const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
-      sa.zt = nullptr;
-      sa.zimg = want_gmm ? reinterpret_cast<u32x4 *>(c.at(c.pl.wZimg)) : nullptr;
-      sa.zrow0 = (long)t * r->B * n_t;
-      const size_t smem = wide::step_lds_bytes(F);
-      const bool stamped = dbg(ALINE_DBG_WIDE_STAMPS);
-      sa.stamps = stamped ? reinterpret_cast<unsigned long long *>(c.at(c.pl.Stamps)) : nullptr;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_step_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::wide_step_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      const bool timed = (t == r->T - 1);            // bench.py times this launch of the dominant kernel
-      if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
-      if (stamped) hipLaunchKernelGGL(wide::wide_step_kernel<true>, dim3(r->B), dim3(wide::ST), smem, c.st, sa);
-      else hipLaunchKernelGGL(wide::wide_step_kernel<false>, dim3(r->B), dim3(wide::ST), smem, c.st, sa);
-      if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
-      CHECK_LAUNCH();
-    }
-    for (int l = 0; l < m->L && !fused_step; ++l) {
-      const unsigned *li = img + (long)l * lw;
-      const float *prm = reinterpret_cast<const float *>(li + nfw);
-      wide::BlockArgs b{};
-      b.M = M; b.F = F; b.prm = prm;
-      b.X = X; b.Y = QKV; b.wimg = li;
-      TRY(launch_wide_block<wide::WB_QKV>(c, b));
-      wide::AttnArgs aa{c.g, QKV, QKV + ipc, QKV + 2 * ipc, A};
-      hipLaunchKernelGGL(wide::wide_attention_kernel, dim3(r->B), dim3(wide::NTHREADS), 0, c.st, aa);
-      CHECK_LAUNCH();
-      b.X = A; b.Xres = X; b.Y = X1; b.wimg = li + 12 * wide::CHUNK_W;
-      TRY(launch_wide_block<wide::WB_OUT>(c, b));
-      b.X = X1; b.Xres = nullptr; b.Y = X; b.wimg = li + 16 * wide::CHUNK_W;
-      const bool timed = (t == r->T - 1 && l == m->L - 1);     // bench.py times this launch of the dominant kernel
-      if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
-      TRY(launch_wide_block<wide::WB_FFN>(c, b));
-      if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
-    }
-    if (!fused_step) {
-      const unsigned *hi = img + (long)m->L * lw;
-      wide::BlockArgs b{};
-      b.M = M; b.F = F; b.X = X; b.logits = logits; b.wimg = hi;
-      b.prm = reinterpret_cast<const float *>(hi + (long)wide::head_chunks(F) * wide::CHUNK_W);
-      TRY(launch_wide_block<wide::WB_ACQ>(c, b));
-    }
-    SelectArgs sel{};
-    sel.g = c.g; sel.F = F; sel.logits = logits; sel.logit_stride = N;
-    sel.mode = r->select_mode;
-    sel.uniform = r->uniform ? r->uniform + (size_t)t * r->B : nullptr;
-    sel.forced = r->forced_idx ? r->forced_idx + t : nullptr; sel.forced_stride = r->T;
-    sel.idx = r->idx ? r->idx + t : nullptr; sel.idx_stride = r->T;
-    sel.slot = r->slot ? r->slot + t : nullptr; sel.slot_stride = r->T;
-    sel.log_prob = r->log_prob ? r->log_prob + t : nullptr; sel.lp_stride = r->T;
-    const int zw = r->P - r->n_ctx0;
-    sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
-    sel.role_out = r->role;
-    // posterior of this step first (the selection kernel updates the roles afterwards; order is free)
-    if (!fused_step && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
-      const long rows = (long)r->B * n_t;
-      {
-        hipLaunchKernelGGL(wide::image_rows_to_f32_kernel, grid1d((size_t)rows * wide::D / 8), dim3(256), 0, c.st, X, n_t, N,
-                           r->P, rows, Zt);
-        CHECK_LAUNCH();
-      }
-      const size_t po = (size_t)t * r->B * n_t;
-      TRY(do_gmm_rows(c, Zt, (int)rows, r->post_mean ? r->post_mean + po * m->C : nullptr,
-                      r->post_std ? r->post_std + po * m->C : nullptr,
-                      r->post_weight ? r->post_weight + po * m->C : nullptr, r->target_all,
-                      r->target_ll ? r->target_ll + po : nullptr, 0, rows));
-    }
-    TRY(launch_acq_select(c, sel));
-    CHECK_LAUNCH();
-    if (fused_step && t + 1 < r->T) {   // the chosen point enters the context: its input row becomes Ex + Ey
-      hipLaunchKernelGGL(wide::patch_context_row_kernel, dim3(r->B), dim3(64), 0, c.st, c.g, r->n_ctx0 + t + 1,
-                         c.at(c.pl.Ex), c.at(c.pl.Ey), r->P, X1);
-      CHECK_LAUNCH();
-    }
-  }
-  if (fused_step && (r->post_mean || r->post_std || r->post_weight || r->target_ll)) {
-    // GMM heads of all T * B * n_t target rows: one streamed block kernel per head (hidden layer never leaves the
-    // CU), then the parameter maps + mixture log-likelihood on the 3 C raw outputs per row
-    const long per_step = (long)r->B * n_t, total = per_step * r->T;
-    float *raw = c.at(c.pl.wRaw);
-    const unsigned *gi = img + (long)m->L * lw + wide::head_words(F);
-    for (int k = 0; k < m->C; ++k) {
-      wide::BlockArgs b{};
-      b.M = (int)total; b.F = F; b.X = reinterpret_cast<const u32x4 *>(c.at(c.pl.wZimg)); b.logits = raw;
-      b.out_stride = kRawStride; b.out_off = 3 * k;
-      b.wimg = gi + (long)k * wide::gmm_words(F);
-      b.prm = reinterpret_cast<const float *>(b.wimg + (long)wide::head_chunks(F) * wide::CHUNK_W);
-      TRY(launch_wide_block<wide::WB_GMM>(c, b));
-    }
-    wide::GmmRawArgs ga{};
-    ga.range_flag = c.flag();
-    ga.raw = raw; ga.raw_stride = kRawStride; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
-    ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
-    ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
-    hipLaunchKernelGGL(wide::gmm_raw_finish_kernel, grid1d((size_t)total), dim3(256), 0, c.st, ga);
-    CHECK_LAUNCH();
-  }
-  return ALINE_OK;
-}
 
 
 extern "C++" {
@@ -1251,7 +1043,6 @@ int aline_rollout_path(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return ALINE_EINVAL;
   TRY(validate_model(*m));
   if (fused_eligible(*m, *r)) return ALINE_PATH_FUSED;
-  if (wide_eligible(*m, *r)) return ALINE_PATH_WIDE;
   if (x3::eligible(*m, *r)) return ALINE_PATH_X3;
   if (x5::eligible(*m, *r)) return ALINE_PATH_X5;
   if (s3_eligible(*m, *r)) return ALINE_PATH_S3;
@@ -1276,7 +1067,6 @@ int aline_rollout_kernel_name(const aline_model *m, const aline_rollout *r, char
   if (path < 0) return path;
   switch (path) {
     case ALINE_PATH_FUSED: snprintf(buf, n, "fused::rollout_f32_kernel<%s>", dbg(ALINE_DBG_FUSED_STAMPS) ? "true" : "false"); break;
-    case ALINE_PATH_WIDE: snprintf(buf, n, "wide::wide_step_kernel<%s>", dbg(ALINE_DBG_WIDE_STAMPS) ? "true" : "false"); break;
     case ALINE_PATH_X3: snprintf(buf, n, "x3::layer_kernel<true>"); break;      // (the launch the event pair brackets: last layer of the last step)
     case ALINE_PATH_X5: snprintf(buf, n, "x5::layer_kernel<true>"); break;
     case ALINE_PATH_S3: {
@@ -1294,7 +1084,6 @@ int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws
                           void *stream) {
   switch (aline_rollout_path(m, r)) {
     case ALINE_PATH_FUSED: return rollout_fused(m, r, ws, ws_bytes, stream);
-    case ALINE_PATH_WIDE: return rollout_wide(m, r, ws, ws_bytes, stream);
     case ALINE_PATH_X3: return x3::rollout(m, r, ws, ws_bytes, stream);
     case ALINE_PATH_X5: return x5::rollout(m, r, ws, ws_bytes, stream);
     case ALINE_PATH_S3: return rollout_s3(m, r, ws, ws_bytes, stream);
@@ -1392,15 +1181,11 @@ extern "C" size_t aline_debug_stamps_offset(const aline_model *m, const aline_ro
 }
 
 // Diagnostic only: byte offsets of the buffers the stamped diagnostic builds (X3_STAMPS / S3_STAMPS, tools/*_stamps.py) and
-// tools/probes/relu_int_repro.py read back; declared in include/aline_hip.h.
+// read back; declared in include/aline_hip.h.
 extern "C" size_t aline_debug_xraw_offset(const aline_model *m, const aline_rollout *r) {
   if (!m || !r) return 0;
   const Plan pl = make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T);
   return (m->d == s3::D ? pl.sRaw : pl.xRaw) * sizeof(float);
-}
-extern "C" size_t aline_debug_wlog_offset(const aline_model *m, const aline_rollout *r) {
-  if (!m || !r) return 0;
-  return make_plan(*m, r->B, r->P, r->n_target_data, r->P, false, r->T).wLog * sizeof(float);
 }
 
 extern "C" uint32_t aline_debug_set_flags(uint32_t flags) { return g_debug_flags.exchange(flags); }
@@ -1409,6 +1194,10 @@ extern "C" int aline_debug_set_param(int key, int value) {
   if (key < 0 || key >= ALINE_DBG_NPARAMS) return ALINE_EINVAL;
   g_debug_params[key].store(value);
   return ALINE_OK;
+}
+extern "C" int aline_debug_get_param(int key) {
+  if (key < 0 || key >= ALINE_DBG_NPARAMS) return 0;
+  return g_debug_params[key].load();
 }
 
 // f16 range guard (include/aline_hip.h): the status word is the first word of every workspace plan
@@ -1635,10 +1424,6 @@ int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, 
     a.dwo = gr->out_proj_w[l]; a.dbo = gr->out_proj_b[l]; a.dw1 = gr->lin1_w[l]; a.db1 = gr->lin1_b[l];
     a.dw2 = gr->lin2_w[l]; a.db2 = gr->lin2_b[l]; a.dg1 = gr->norm1_w[l]; a.de1 = gr->norm1_b[l];
     a.dg2 = gr->norm2_w[l]; a.de2 = gr->norm2_b[l];
-    if (dbg(ALINE_DBG_BWD_TAIL_PC)) {      // opt-in: measured 3.56 ms per call against 3.65      // producer / consumer wave pairs, 8 waves of 224 registers (tail_bwd_pc_kernel)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail_bwd_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS_PC * (int)sizeof(float));
-      hipLaunchKernelGGL(tailbwd::tail_bwd_pc_kernel, dim3((unsigned)std::min<long>(groups, 256)), dim3(512), tailbwd::LDS_FLOATS_PC * sizeof(float), c.st, a);
-    } else
     hipLaunchKernelGGL(tailbwd::tail_kernel<true>, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);   // 434 registers: one wave per SIMD
   }
   CHECK_LAUNCH();

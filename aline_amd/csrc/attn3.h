@@ -10,8 +10,8 @@
 
 namespace attn3 {
 
-using wide::group_sum4;
-using wide::u32x4;
+using img::group_sum4;
+using img::u32x4;
 using x3::f16x8;
 using x3::group_max4;
 using x3::mfma3;

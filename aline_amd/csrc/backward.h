@@ -54,18 +54,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_block_kernel(GemmTnArgs a) {
   // same XCD, or every one of them streams its rows from HBM again (chunk-fastest order, the first version: the 32 blocks of a [1024 x 256]
   // gradient were up to 1 487 workgroup ids apart and each streamed its rows from HBM: PMC FETCH_SIZE now 1.75 x the operands' size per launch).
   // Ids go round-robin over the 8 XCDs: ids congruent mod 8 inside a group of 8 nby nbz consecutive ones share a chunk.
-#if defined(TNB_OLD_ORDER)      // (timing experiments only)
-  const unsigned nb_all = (unsigned)(a.nby * a.nbz);
-  const long chunk = blockIdx.x % (unsigned)a.gx;
-  const int nb = blockIdx.x / (unsigned)a.gx;
-  if (nb >= (int)nb_all) return;
-#else
   const unsigned nb_all = (unsigned)(a.nby * a.nbz), per = 8u * nb_all;
   const unsigned grp = blockIdx.x / per, within = blockIdx.x - grp * per;
   const long chunk = (long)grp * 8 + (within & 7u);
   const int nb = (int)(within >> 3);
   if (chunk >= a.gx) return;
-#endif
   const int by = nb % a.nby, bz = nb / a.nby;
   const int n0 = by * BN, k0 = bz * BK;
   const long m_lo = chunk * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
@@ -571,25 +564,30 @@ __global__ __launch_bounds__(256) void acq_bwd_kernel(AcqBwdArgs a) {
   dbl = wave_sum(dbl);
   if (lane == 0) atomicAdd(a.db2, dbl);
   __syncthreads();
-  float pw[8], w2r[8];                      // lane owns features lane + 64 n  (F <= 512)
+  // lane owns features f0 + lane + 64 n of one block of 512 features at a time.  (Rounds 1-3 handled the first block only: at
+  // F = 1024 -- the d = 256 roofline variant -- the hidden units 512.. kept their FORWARD values as "gradient"; found by the
+  // round-4 reference-autograd fixture grad_cfg2_d256.)
+  for (int f0 = 0; f0 < F; f0 += 512) {
+    float pw[8], w2r[8];
 #pragma unroll
-  for (int n = 0; n < 8; ++n) { pw[n] = 0.f; w2r[n] = lane + 64 * n < F ? a.w2[lane + 64 * n] : 0.f; }
-  for (int p = wave; p < P; p += 4) {
-    float *hp = a.hid + ((long)i * P + p) * F;
-    const float dl = logit[p];
+    for (int n = 0; n < 8; ++n) { pw[n] = 0.f; w2r[n] = f0 + lane + 64 * n < F ? a.w2[f0 + lane + 64 * n] : 0.f; }
+    for (int p = wave; p < P; p += 4) {
+      float *hp = a.hid + ((long)i * P + p) * F;
+      const float dl = logit[p];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const int f = lane + 64 * n;
-      if (f < F) {
-        const float hv = hp[f];
-        pw[n] = fmaf(dl, hv, pw[n]);
-        hp[f] = hv > 0.f ? dl * w2r[n] : 0.f;
+      for (int n = 0; n < 8; ++n) {
+        const int f = f0 + lane + 64 * n;
+        if (f < F) {
+          const float hv = hp[f];
+          pw[n] = fmaf(dl, hv, pw[n]);
+          hp[f] = hv > 0.f ? dl * w2r[n] : 0.f;
+        }
       }
     }
-  }
 #pragma unroll
-  for (int n = 0; n < 8; ++n)
-    if (lane + 64 * n < F) atomicAdd(&sdw[lane + 64 * n], pw[n]);
+    for (int n = 0; n < 8; ++n)
+      if (f0 + lane + 64 * n < F) atomicAdd(&sdw[f0 + lane + 64 * n], pw[n]);
+  }
   __syncthreads();
   for (int f = tid; f < F; f += 256) atomicAdd(a.dw2 + f, sdw[f]);
 }

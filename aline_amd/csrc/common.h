@@ -55,17 +55,7 @@ __device__ __forceinline__ float softplus_f(float x) {
 }
 
 // ReLU.  NOT the one-instruction integer form max(bits, 0) (it would save the canonicalising v_max_f32 x, x, x that
-// llvm.maxnum emits in IEEE mode): v_max_i32 applied directly to MFMA results made wide_block_kernel<WB_ACQ> return
+// llvm.maxnum emits in IEEE mode): v_max_i32 applied directly to MFMA results made the bf16 block kernel of round 1 return
 // different logits for a token tile in 1 of 3 runs on gfx950 (ROCm 7.2 hipcc) -- an MFMA -> integer-VALU hazard the
 // compiler's wait states do not cover -- while the float form is reproducible (60 of 60 runs).
-// (relu_int: the integer form, for the per-call-site diagnostic builds)
-__device__ __forceinline__ float relu_int(float a) { return __int_as_float(max(__float_as_int(a), 0)); }
-#if defined(ALINE_RELU_INT_NOPS)   // (diagnostic builds of tools/probes/relu_int_repro.py only)
-__device__ __forceinline__ float relu_nn(float a) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a)); return __int_as_float(max(__float_as_int(a), 0)); }
-#elif defined(ALINE_RELU_INT_ASM)
-__device__ __forceinline__ float relu_nn(float a) { float r; asm volatile("v_max_i32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
-#elif defined(ALINE_RELU_INT)
-__device__ __forceinline__ float relu_nn(float a) { return __int_as_float(max(__float_as_int(a), 0)); }
-#else
 __device__ __forceinline__ float relu_nn(float a) { return fmaxf(a, 0.f); }
-#endif

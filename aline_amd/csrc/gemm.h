@@ -81,12 +81,8 @@ __device__ __forceinline__ void lds_store4(typename LdsTile<PREC>::T *base, int 
     // packed pairs: hi = one v_cvt_pk_f16_f32 per pair, residuals one v_fma_mix_f32 each (the f16 operand read straight out
     // of the packed register), lo = one more v_cvt_pk: 4 instructions per pair instead of 8 scalar conversions
     unsigned h0, l0, h1, l1;
-#ifdef GEMM_NO_SPLIT       // (timing experiments only)
-    h0 = __float_as_uint(v.x); l0 = __float_as_uint(v.y); h1 = __float_as_uint(v.z); l1 = __float_as_uint(v.w);
-#else
     split2_f16(v.x * scale, v.y * scale, h0, l0);
     split2_f16(v.z * scale, v.w * scale, h1, l1);
-#endif
     typedef __attribute__((ext_vector_type(2))) unsigned gemm_u32x2;
     *reinterpret_cast<gemm_u32x2 *>(base + gemm_swz(row, k)) = (gemm_u32x2){h0, h1};
     *reinterpret_cast<gemm_u32x2 *>(base + plane_elems + gemm_swz(row, k)) = (gemm_u32x2){l0, l1};
@@ -191,9 +187,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
       lds_store4<PREC>(Bs, B_ELEMS, idx >> 3, (idx & 7) * 4, bv[i], PREC == 3 ? GEMM_F16_WSCALE : 1.f);
     }
     __syncthreads();
-#ifndef GEMM_NO_GLOAD     // (timing experiments only)
     if (k0 + GEMM_BK < a.K) load_step(k0 + GEMM_BK);
-#endif
 
     if constexpr (PREC == 0) {
 #pragma unroll
@@ -210,7 +204,6 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     } else if constexpr (PREC == 3) {
-#ifndef GEMM_NO_MFMA      // (timing experiments only: tools/x3_variants.sh)
       gemm_f16x8 ah[TM], bh[TN], al[TM], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -230,7 +223,6 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-#endif
     } else {
       bf16x8 ah[TM], bh[TN];
 #pragma unroll

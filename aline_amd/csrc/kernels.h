@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void acq_select_wave_kernel(SelectArgs a) {
 
 // (G9/G10: the second layers of the C GMM heads are reduced in the GEMM epilogue, gemm.h `red_*`; the parameter
 // maps mean_c = raw[c][0], std_c = softplus(raw[c][1]) + std_min, weight = softmax_c(raw[c][2]) -- the reference's
-// stack/movedim/flatten/chunk, head.py:264-265, with dim_y == 1 -- and compute_ll are wide::gmm_raw_finish_kernel.)
+// stack/movedim/flatten/chunk, head.py:264-265, with dim_y == 1 -- and compute_ll are img::gmm_raw_finish_kernel.)
 
 // compute_ll on caller-provided GMM parameters (utils/eval.py:200-207).  One wave per row.
 __global__ __launch_bounds__(256) void compute_ll_kernel(const float *__restrict__ value,

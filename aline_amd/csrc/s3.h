@@ -20,9 +20,9 @@
 
 namespace s3 {
 
-using wide::group_sum4;
-using wide::u32x2;
-using wide::u32x4;
+using img::group_sum4;
+using img::u32x2;
+using img::u32x4;
 using x3::f16x8;
 using x3::frag_value;
 using x3::split_frag;
@@ -400,9 +400,8 @@ template <int F, int NW, int MAXNKP, bool PREFETCH, bool SAVE = false>
 __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const Geo &G = a.g;
-  constexpr int NGRP = NW / 4;                     // 256-thread groups: one episode each in the prologue
   const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, hwave = wave & 3, htid = tid & 255;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tpe = a.tpe, n_t = G.n_td + G.n_th, epw = a.epw;
   constexpr int nkp = MAXNKP;                      // key-tile pairs an episode's LDS slot holds
   constexpr int NH = F / 16;                       // hidden tiles (= W1 pairs = W2 pairs)

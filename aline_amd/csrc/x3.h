@@ -5,7 +5,7 @@
 //                 registers) and accumulators (128) do not fit a 256-register wave, so a workgroup is 4 waves -- one per SIMD --
 //                 with the whole 512-entry register file of their SIMD lane (accumulators in the AGPR half).
 #pragma once
-#include "wide.h"
+#include "tile_image.h"
 
 #define X3_NS x3
 #define X3_D 256

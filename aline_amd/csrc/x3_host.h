@@ -144,12 +144,12 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
       ha.out = raw; ha.out_stride = kRawStride; ha.out_off = 3 * k;
       TRY(launch_head<3>(c, ha));
     }
-    wide::GmmRawArgs ga{};
+    img::GmmRawArgs ga{};
     ga.range_flag = c.flag();
     ga.raw = raw; ga.raw_stride = kRawStride; ga.rows = total; ga.C = m->C; ga.std_min = m->std_min;
     ga.mean = r->post_mean; ga.sd = r->post_std; ga.wgt = r->post_weight;
     ga.value = r->target_all; ga.value_mod = per_step; ga.ll = r->target_ll;
-    hipLaunchKernelGGL(wide::gmm_raw_finish_kernel, grid1d((size_t)total), dim3(256), 0, c.st, ga);
+    hipLaunchKernelGGL(img::gmm_raw_finish_kernel, grid1d((size_t)total), dim3(256), 0, c.st, ga);
     CHECK_LAUNCH();
   }
   return ALINE_OK;

@@ -25,9 +25,9 @@
 
 namespace X3_NS {
 
-using wide::u32x4;
-using wide::u32x2;
-using wide::group_sum4;
+using img::u32x4;
+using img::u32x2;
+using img::group_sum4;
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -379,7 +379,6 @@ struct Stream {
   unsigned lane_off, wave_off;
   static constexpr int dma_slot = 0;   // the MFMA batch (0..3) of a chunk with which a wave issues its pieces of the stream
   __device__ __forceinline__ void issue() {
-#ifndef X3_NO_DMA      // (timing experiments only: tools/x3_variants.sh)
     // buffer_load ... lds with the chunk's base in a scalar buffer descriptor and a constant 32-bit lane offset: no per-piece
     // vector address arithmetic (global_load_lds took a 64-bit per-lane address per piece); the whole rollout 80.2 -> 77.3 ms
     // (kv_kernel / head_kernel, which are stream-bound, gain; the layer kernel is unchanged: profiles/r03_x3_timing_experiments.txt)
@@ -390,7 +389,6 @@ struct Stream {
       for (int i = 0; i < PIECES_PER_WAVE; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(d + i * 1024), 16, lane_off, wave_off + i * 1024, 0, 0);
     }
-#endif
     s_issue = s_issue + 1 == seq_len ? 0 : s_issue + 1;
     b_issue = (b_issue + 1) & (NBUF - 1);
   }
@@ -399,13 +397,9 @@ struct Stream {
     for (int i = 0; i < PD; ++i) issue();
   }
   __device__ __forceinline__ void sync() {
-#ifndef X3_NO_WAIT     // (timing experiments only)
     wait_vmcnt<PIECES_PER_WAVE *(PD - 2)>();
-#endif
     X3_LAP(*this, 3);
-#ifndef X3_NO_BARRIER  // (timing experiments only)
     __builtin_amdgcn_s_barrier();
-#endif
     X3_LAP(*this, 4);
   }
   // LDS byte address of this lane's 16 bytes of fragment 0 of the chunk in use / of the next one
@@ -597,7 +591,7 @@ __device__ __forceinline__ void load_tile(const u32x4 *X, long tile, int lane_id
 typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 struct LaneParams {
   unsigned base;          // LDS byte address of prm + 4 g
-  __device__ __forceinline__ f32x4 operator()(int word) const { return *(lds_cf32x4 *)(base + 4u * (unsigned)word); }
+  __device__ __forceinline__ f32x4 operator()(int word) const { return *(lds_cf32x4 *)(uintptr_t)(base + 4u * (unsigned)word); }
 };
 __device__ __forceinline__ LaneParams lane_params(const float *prm, int g) {
   unsigned b = lds_addr(prm) + 16u * (unsigned)g;
@@ -927,7 +921,7 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
   const long per_round = (long)NG * WAVES;
   const int full = (int)(ntiles / per_round);
   const long rem = ntiles - (long)full * per_round;
-  const int ktail = (int)((rem + NG - 1) / NG), rounds = full + (rem > 0 ? 1 : 0);
+  const int ktail = (int)((rem + NG - 1) / NG);
   const bool wg_tail = rem > 0 && (long)blockIdx.x * ktail < rem;              // (workgroup-uniform) a tail round for this workgroup
   const long tail_tile = (long)full * per_round + (long)blockIdx.x * ktail + wave;
   const bool my_tail = wg_tail && wave < ktail && tail_tile < ntiles;

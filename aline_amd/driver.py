@@ -25,7 +25,7 @@ import torch
 from torch import optim
 from torch.optim import lr_scheduler
 
-from .train import optimizer_step, train_step
+from .train import check_range_async, check_training_range, optimizer_step, train_step
 from .utils.target_mask import create_target_mask
 
 
@@ -199,6 +199,9 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
         terms, _ = train_step(model, batch, T, optimizer=None, embedding_type=_get(task_cfg, "embedding_type", "theta"),
                               mask_type=mask_type, gamma=_get(cfg, "gamma", 1.0), alpha=_get(cfg, "alpha", 1.0),
                               burn_in=epoch < burn, clip_grads=_get(cfg, "clip_grads", True), dist=dist, world=world)
+        # f16x3 range guard: stop BEFORE the update is applied or a checkpoint written, on all ranks together (the status went
+        # through the step's gradient all-reduce).  The loop synchronises at float(terms["loss"]) below anyway.
+        check_training_range(terms)
         if epoch == burn:
             # from here on the shared layers learn at lr / 5; this epoch's gradients are applied by the new optimiser
             optimizer, scheduler = set_layerwise_lr(cfg, model, epoch)
@@ -223,4 +226,5 @@ def train(cfg, model, experiment, batch_size=None, min_T=None, max_T=None, max_e
             if rank == 0:
                 save_checkpoint(cfg, model, optimizer, scheduler, epoch + 1, with_epoch=True)
             barrier()
+    check_range_async(block=True)            # (rollouts posted by callers of train_step outside this loop)
     return records

@@ -10,6 +10,9 @@ from . import _lib
 from .model import _native
 
 
+_ACTS_WRITES = {}        # saved_acts buffer address -> number of forwards that wrote it (Rollout._stamp_acts)
+
+
 class Rollout:
     """One batch of episodes rolled out for T design steps.
 
@@ -94,7 +97,7 @@ class Rollout:
         if keep_acts:
             sb = _lib.lib.aline_rollout_saved_acts_bytes(C.byref(self.m), C.byref(r))
             if sb:
-                self.saved_acts = keep_acts(sb) if callable(keep_acts) else torch.empty(sb // 4, dtype=torch.float32, device=dev)
+                self.saved_acts = keep_acts(sb, dev) if callable(keep_acts) else torch.empty(sb // 4, dtype=torch.float32, device=dev)
                 assert self.saved_acts.numel() * 4 >= sb and self.saved_acts.device == dev
                 r.saved_acts = self.saved_acts.data_ptr()
         nbytes = _lib.lib.aline_rollout_workspace_bytes(C.byref(self.m), C.byref(r))
@@ -103,8 +106,9 @@ class Rollout:
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._graph = None
         self.fell_back = False          # run_checked() re-ran the rollout in f32 after an f16 range overflow
+        self._acts_stamp = None         # (write generation of saved_acts, library diagnostic state) of this rollout's last forward
 
-    PATHS = {0: "generic pipeline", 1: "fused::rollout_f32_kernel", 2: "wide::wide_step_kernel",
+    PATHS = {0: "generic pipeline", 1: "fused::rollout_f32_kernel",
              3: "x3::layer_kernel", 4: "s3::step_kernel", 5: "x5::layer_kernel"}
 
     @property
@@ -129,10 +133,29 @@ class Rollout:
         if self.uniform is not None:
             self.uniform.uniform_()
 
+    def _stamp_acts(self):
+        """Records that THIS rollout's forward is the last writer of its `saved_acts` buffer (which may be shared with other
+        rollouts) and under which diagnostic state of the library it ran: `saved_acts_valid()` is what the backward asks before
+        it reads the buffer instead of recomputing the layers."""
+        if self.saved_acts is not None:
+            key = self.saved_acts.data_ptr()
+            gen = _ACTS_WRITES.get(key, 0) + 1
+            _ACTS_WRITES[key] = gen
+            self._acts_stamp = (gen, _lib.debug_state())
+
+    def saved_acts_valid(self):
+        """True iff `saved_acts` holds the activations of this rollout's last forward: nobody wrote the (shared) buffer since, and the
+        library's diagnostic word (which decides whether the forward path writes them and the backward reads them) is unchanged."""
+        if self.saved_acts is None or self._acts_stamp is None:
+            return False
+        gen, state = self._acts_stamp
+        return _ACTS_WRITES.get(self.saved_acts.data_ptr()) == gen and state == _lib.debug_state()
+
     def _enqueue(self):
         st = _lib.stream_ptr(self.device)
         _lib.check(_lib.lib.aline_rollout_forward(C.byref(self.m), C.byref(self.r), self.ws.data_ptr(),
                                                   self.ws.numel(), st), "rollout_forward")
+        self._stamp_acts()
 
     def run(self):
         """init + T steps enqueued on the current stream (no host synchronisation)."""
@@ -185,6 +208,7 @@ class Rollout:
 
     def replay(self):
         self._graph.replay()
+        self._stamp_acts()
         return self
 
     def step(self, t):

@@ -62,7 +62,10 @@ def flat_grads(model):
         except AttributeError:                      # a .grad is None
             pass
     total = sum(p.numel() for p in params)
-    flat = torch.zeros(total, device=params[0].device, dtype=torch.float32)
+    # (one extra element behind the gradients: the f16 range status of the step's rollout rides the gradient all-reduce in it,
+    #  so every rank of a data-parallel job learns of an overflow on any rank from the collective it already makes)
+    store = torch.zeros(total + 1, device=params[0].device, dtype=torch.float32)
+    flat = store[:total]
     off = 0
     for p in params:
         n = p.numel()
@@ -73,6 +76,7 @@ def flat_grads(model):
         off += n
     struct = _grad_struct(model)
     model._aline_flat = (flat, [p.grad.data_ptr() for p in params], struct)
+    model._aline_flat_store = store
     return flat, struct
 
 
@@ -135,17 +139,27 @@ def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30, grads
     m, r = ro.m, ro.r
     if grads is None:
         grads = _grad_struct(model)
-    if t_chunk is None:
-        t_chunk = ro.T
-        while t_chunk > 1 and _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), t_chunk) > max_ws_bytes:
-            t_chunk = (t_chunk + 1) // 2
-    nbytes = _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), t_chunk)
-    if nbytes == 0:
-        raise RuntimeError("aline_amd: unsupported configuration for backward")
-    ws = _bwd_ws.get(nbytes, ro.device)
-    _lib.check(_lib.lib.aline_rollout_backward(C.byref(m), C.byref(r), g_logp.data_ptr(), g_ll.data_ptr(),
-                                               C.byref(grads), t_chunk, ws.data_ptr(), ws.numel(),
-                                               _lib.stream_ptr(ro.device)), "rollout_backward")
+    stale = ro.saved_acts is not None and not ro.saved_acts_valid()
+    kept = r.saved_acts
+    if stale:
+        # the buffer was written by another rollout since this one's forward (a stale `ro`, or a shared buffer), or the library's
+        # diagnostic word changed between forward and backward: the kept activations are not this rollout's -- recompute the layers
+        r.saved_acts = None
+    try:
+        if t_chunk is None:
+            t_chunk = ro.T
+            while t_chunk > 1 and _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), t_chunk) > max_ws_bytes:
+                t_chunk = (t_chunk + 1) // 2
+        nbytes = _lib.lib.aline_rollout_backward_workspace_bytes(C.byref(m), C.byref(r), t_chunk)
+        if nbytes == 0:
+            raise RuntimeError("aline_amd: unsupported configuration for backward")
+        ws = _bwd_ws.get(nbytes, ro.device)
+        _lib.check(_lib.lib.aline_rollout_backward(C.byref(m), C.byref(r), g_logp.data_ptr(), g_ll.data_ptr(),
+                                                   C.byref(grads), t_chunk, ws.data_ptr(), ws.numel(),
+                                                   _lib.stream_ptr(ro.device)), "rollout_backward")
+    finally:
+        if stale:
+            r.saved_acts = kept
     return t_chunk
 
 
@@ -158,7 +172,9 @@ def all_reduce_grads(model, dist, world, flat=None):
     global ALLREDUCE_CALLS
     ALLREDUCE_CALLS += 1
     if flat is not None:
-        dist.all_reduce(flat)
+        store = getattr(model, "_aline_flat_store", None)
+        buf = store if (store is not None and store.data_ptr() == flat.data_ptr()) else flat
+        dist.all_reduce(buf)           # gradients + the range-status slot behind them: ONE collective
         flat /= world
         return
     params = [p for p in model.parameters() if p.grad is not None]
@@ -172,18 +188,22 @@ def all_reduce_grads(model, dist, world, flat=None):
         off += n
 
 
-_SAVED_ACTS = [None]          # one grow-only buffer for the activations the training rollouts keep for their backward
+_SAVED_ACTS = {}              # device -> one grow-only buffer for the activations the training rollouts keep for their backward
 
 
-def _shared_acts(nbytes):
-    """The shared `saved_acts` buffer (Rollout(keep_acts=...)).  Growing it invalidates the captured rollouts, whose graphs hold the
-    old address: the cache is dropped."""
-    buf = _SAVED_ACTS[0]
-    if buf is None or buf.numel() * 4 < nbytes or buf.device != torch.device("cuda", torch.cuda.current_device()):
-        _ROLLOUT_GRAPHS.clear()
-        _SAVED_ACTS[0] = None
+def _shared_acts(nbytes, device=None):
+    """The shared `saved_acts` buffer of `device` (Rollout(keep_acts=...) passes the rollout's device).  Growing it invalidates the
+    captured rollouts of that device, whose graphs hold the old address: they are dropped from the cache."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    buf = _SAVED_ACTS.get(dev)
+    if buf is None or buf.numel() * 4 < nbytes:
+        for k in [k for k, ro in _ROLLOUT_GRAPHS.items() if ro.device == dev]:
+            del _ROLLOUT_GRAPHS[k]
+        _SAVED_ACTS.pop(dev, None)
         buf = None                                   # (free the old one before allocating the new)
-        _SAVED_ACTS[0] = buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device="cuda")
+        _SAVED_ACTS[dev] = buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     return buf
 
 
@@ -232,7 +252,8 @@ def _post_range_status(ro):
         check_range_async(block=True)
     word = _RANGE_WORDS[_RANGE_NEXT:_RANGE_NEXT + 1]
     _RANGE_NEXT = (_RANGE_NEXT + 1) % 64
-    word.copy_(ro.ws[:4].view(torch.int32), non_blocking=True)
+    off = _lib.lib.aline_f16_range_offset()
+    word.copy_(ro.ws[off:off + 4].view(torch.int32), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
     _RANGE_PENDING.append((word, ev))
@@ -326,6 +347,15 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
         else:
             ro = _sampled_rollout(model, batch, T)
         _post_range_status(ro)
+        store = getattr(model, "_aline_flat_store", None)
+        status = None
+        if store is not None and store.data_ptr() == flat.data_ptr():
+            status = store[-1:]                      # rides the gradient all-reduce (all_reduce_grads): > 0 iff ANY rank overflowed
+            if ro.m.precision == _lib.PREC["f16x3"]:
+                off = _lib.lib.aline_f16_range_offset()
+                status.copy_((ro.ws[off:off + 4].view(torch.int32) & 0xFF).ne(0).to(torch.float32))
+            else:
+                status.zero_()
         terms = reinforce_terms(ro, embedding_type, mask_type, gamma, alpha, burn_in,
                                 dist=dist if (global_reward_moments and world > 1) else None, world=world)
         backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=t_chunk, grads=gstruct)
@@ -335,9 +365,22 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
             # torch.nn.utils.clip_grad_norm_(parameters, max_norm=1.0, norm_type="inf") of train_aline.py:138 on the flat buffer:
             # total norm = max |g| over all tensors, coefficient = min(1, max_norm / (total + 1e-6))
             flat.mul_((1.0 / (flat.abs().max() + 1e-6)).clamp(max=1.0))
+        terms["range_status"] = status           # device tensor [1] (or None): see check_training_range
         if optimizer is not None:
             optimizer_step(model, optimizer, burn_in)
     return terms, ro
+
+
+def check_training_range(terms):
+    """Raises -- on EVERY rank of a data-parallel job together -- if the rollout of the training step that produced `terms` left
+    f16's range on any rank: the status slot behind the flat gradient buffer went through the step's gradient all-reduce, so all
+    ranks read the same value.  Host-synchronising (4 bytes): call it where the loop synchronises anyway, BEFORE the optimiser step
+    and before a checkpoint is written (the gradients of such a step are inf / NaN)."""
+    st = terms.get("range_status")
+    if st is not None and float(st) > 0:
+        _RANGE_PENDING.clear()
+        raise RuntimeError("aline_amd: an F16X3 operand left f16's range during a training rollout (on this or another rank); "
+                           "the step's gradients are not applied -- train with precision 'f32'")
 
 
 def step_backward(model, batch, idx, g_logp, g_mean=None, g_std=None, g_weight=None):

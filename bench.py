@@ -201,8 +201,8 @@ def measure_d256(args, device, batch, precision, d=256, F=1024, train=True):
     """Sub-measurement (not `value`): the same workload on a matrix-core-bound model width: d = 256 / F = 1024 / H = 8 (the north
     star's d_model >= 256 variant) or d = 512 / F = 128 / H = 8 (the width and literal FFN size of BASELINE configs[4], psychometric).
     precision f16x3 = the reference-precision x3 / x5 path (every product a 3-term f16 split, posterior NLL within 1e-4 of the
-    reference: tests/test_hip_parity.py, tests/test_r2_gpu.py, tests/test_x5_gpu.py); bf16 = the single-pass wide path (d = 256
-    only; throughput mode, NLL error ~1e-2)."""
+    reference: tests/test_hip_parity.py, tests/test_r2_gpu.py, tests/test_x5_gpu.py, tests/test_r4_gpu.py: oracle slices of this very launch shape); bf16 = the generic pipeline on the
+    single-pass bf16 GEMM policy (throughput mode, NLL error ~1e-2; the bf16 `wide` kernels of rounds 1-3 were removed in round 4)."""
     from aline_amd import Aline, Embedder, Encoder, OutputHead
     from aline_amd.rollout import Rollout
     H, L = 8, args.layers
@@ -497,7 +497,6 @@ def main():
     fl_ep = algorithmic_flops_per_episode(2, 1, args.d_model, args.d_ff, args.heads, args.layers, 10,
                                           1, args.n_query, 0, 2, 2, args.T, with_query_gmm=False)
     fused = path == "fused::rollout_f32_kernel" and kernel_ms > 0.0
-    wide = path == "wide::wide_step_kernel" and kernel_ms > 0.0
     x3 = path == "x3::layer_kernel" and kernel_ms > 0.0
     s3 = path == "s3::step_kernel" and kernel_ms > 0.0
     extra = {}
@@ -526,33 +525,6 @@ def main():
             extra["traffic_source"] = "rocprofv3 PMC (profiles/r01_fused_f32_d32_pmc_traffic.json), not re-measured in this run"
         except Exception:
             traffic = None
-    elif wide:
-        # dominant kernel of the wide path: wide::wide_step_kernel -- one launch = the whole encoder stack + the
-        # acquisition head of ONE rollout step for all B episodes (T launches per rollout); the events bracket
-        # the launch of the last step (t = T-1).
-        fl_all = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
-        fl_last = fl_all - fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2,
-                                                          args.T - 1)
-        # the T launches of a rollout take the same time (the kernel always runs 16 token tiles per episode) while the
-        # algorithmic FLOPs shrink with the query set: `achieved` pairs the AVERAGE launch (total / T) with the
-        # launch duration; the last step alone (fewest queries) is reported beside it
-        per_launch = fl_all / args.T * args.batch
-        achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
-        kname, peak, traffic = ro.kernel_name, PEAK_BF16_DENSE_TFLOPS, None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_wide_bf16_d256_pmc_traffic.json")))
-            traffic = tr["hbm_bytes_per_launch"] if args.batch == 1000 and args.T == 30 and args.d_ff == 1024 else None
-        except Exception:
-            traffic = None
-        extra = {"launches_per_rollout": args.T,
-                 "last_step": {"algorithmic_flops": fl_last * args.batch,
-                               "achieved": fl_last * args.batch / (kernel_ms * 1e-3) / 1e12,
-                               "frac": fl_last * args.batch / (kernel_ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS},
-                 "traffic_source": "rocprofv3 PMC (profiles/r01_wide_bf16_d256_pmc_traffic.json), average step, not re-measured in this run",
-                 "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
-                 "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md).  Algorithmic FLOPs as the reference "
-                              "computes them (K/V for the visible keys only, SURVEY 8-d); the kernel spends MFMA "
-                              "slots on 16 token tiles per episode for 203 tokens (13 tiles used)"}
     elif x3:
         # dominant kernel of the x3 path: x3::layer_kernel -- one launch = one encoder layer of one step for all B episodes
         # (L * T launches per rollout); the events bracket the last layer of the last step
@@ -679,8 +651,6 @@ def main():
         log(f"f32 [{out['f32']['path']}]: {out['f32']['ms_per_rollout']:.2f} ms per rollout")
     if world == 1 and not args.no_d256 and args.d_model != 256:
         out["d256"] = {}
-        # (the single-pass bf16 `wide` path of round 1 -- 0.26 of peak at an NLL error of 2e-2 -- is neither parity-grade nor near
-        #  its roofline target and is no longer reported here; `--d256-precs f16x3,bf16` times it on request)
         for prec in args.d256_precs.split(","):
             out["d256"][prec] = measure_d256(args, device, batch, prec)
             log(f"d256 [{prec}]: {out['d256'][prec]['ms_per_rollout']:.2f} ms per rollout")

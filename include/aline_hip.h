@@ -28,7 +28,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define ALINE_ABI_VERSION 4
+#define ALINE_ABI_VERSION 5
 #define ALINE_MAX_LAYERS 8
 #define ALINE_MAX_COMPONENTS 16
 #define ALINE_MAX_POINTS 4096     /* P = n_ctx0 + n_query0 of a rollout / n_ctx + n_query of a step (README.md:45,50 evaluate at n_query = 2000) */
@@ -181,7 +181,7 @@ int aline_rollout_forward(const aline_model *m, const aline_rollout *r, void *ws
  * paths.  Negative: error code. */
 enum { ALINE_PATH_GENERIC = 0,   /* stage kernels + GEMMs, any configuration */
        ALINE_PATH_FUSED = 1,     /* fused_rollout.h: d = 32, theta mode, F32, whole rollout in one launch */
-       ALINE_PATH_WIDE = 2,      /* wide.h: d = 256, BF16 */
+       /* 2: the bf16 `wide` path of rounds 1-3 (NLL error 2e-2; removed in ABI 5: BF16 models run the generic pipeline) */
        ALINE_PATH_X3 = 3,        /* x3.h: d = 256, F16X3 (reference precision on the f16 matrix pipe) */
        ALINE_PATH_S3 = 4,        /* s3.h: d = 32, F16X3, any embedding mode, one launch per design step */
        ALINE_PATH_X5 = 5 };      /* x3.h, namespace x5: d = 512 / 8 heads of 64, F16X3 (the psychometric configuration's width) */
@@ -293,18 +293,14 @@ int aline_f16_range_status(const void *ws, void *stream);
 /* Process-wide diagnostic word, 0 in normal operation.  Tests and A/B measurements use it to force the path a fused kernel
  * replaces (every fused kernel is cross-checked against that path) or to opt into an experiment.  Returns the old word. */
 enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off -> generic pipeline */
-       ALINE_DBG_DISABLE_WIDE = 1u << 1,       /* wide path off */
        ALINE_DBG_DISABLE_X3 = 1u << 2,         /* x3 path off -> generic pipeline on the F16X3 GEMM policy */
        ALINE_DBG_DISABLE_S3 = 1u << 3,         /* s3 path off */
-       ALINE_DBG_WIDE_BLOCKS = 1u << 4,        /* wide path on per-block kernels */
        ALINE_DBG_NO_LAYER_TAIL = 1u << 5,      /* generic d = 32 pipeline on per-op kernels */
        ALINE_DBG_FULL_QKV = 1u << 6,           /* generic pipeline: K / V of every row (as the reference) */
        ALINE_DBG_VALU_ATTENTION = 1u << 7,     /* generic pipeline: fp32 VALU attention instead of attn3 */
        ALINE_DBG_S3_GENERIC_EMBED = 1u << 8,   /* s3: point embedders on the generic kernels */
        ALINE_DBG_CES_GENERIC = 1u << 9,        /* CES likelihood: powf formulation */
        ALINE_DBG_FUSED_STAMPS = 1u << 10,      /* in-kernel phase stamps (diagnostic instantiations) */
-       ALINE_DBG_WIDE_STAMPS = 1u << 11,
-       ALINE_DBG_BWD_TAIL_PC = 1u << 12,       /* producer / consumer tail backward */
        ALINE_DBG_SELECT_WORKGROUP = 1u << 13,  /* design selection: the workgroup-per-episode kernel also where one wave per episode would do */
        /* backward: switch ONE fused kernel back to the per-op pipeline it replaces */
        ALINE_DBG_NO_BWD_TAIL = 1u << 16, ALINE_DBG_NO_BWD_ATTN_BLOCK = 1u << 17, ALINE_DBG_NO_BWD_ACQ = 1u << 18,
@@ -321,13 +317,12 @@ uint32_t aline_debug_get_flags(void);
 /* Integer knobs of the same kind (0 = automatic): launch shape of the s3 step kernel, precision of the backward GEMMs. */
 enum { ALINE_DBG_S3_WAVES = 0, ALINE_DBG_S3_EPW = 1, ALINE_DBG_BWD_PREC = 2, ALINE_DBG_NPARAMS = 3 };
 int aline_debug_set_param(int key, int value);
+int aline_debug_get_param(int key);      /* the knob's current value (0 for an unknown key) */
 /* Byte offset, inside a rollout workspace, of the per-phase cycle stamps the fused rollout kernel
  * writes under ALINE_DBG_FUSED_STAMPS (diagnostic instantiation only). */
 size_t aline_debug_stamps_offset(const aline_model *m, const aline_rollout *r);
-/* Same for the buffers the stamped diagnostic builds of the x3 / s3 kernels (tools/x3_stamps.py, tools/s3_stamps.py) and
- * tools/probes/relu_int_repro.py (acquisition logits of the wide path) read back. */
+/* Same for the buffer the stamped diagnostic builds of the x3 / s3 kernels (tools/x3_stamps.py, tools/s3_stamps.py) read back. */
 size_t aline_debug_xraw_offset(const aline_model *m, const aline_rollout *r);
-size_t aline_debug_wlog_offset(const aline_model *m, const aline_rollout *r);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

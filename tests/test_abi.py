@@ -37,7 +37,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_errors(lib):
     lib.aline_abi_version.restype = ctypes.c_int
-    assert lib.aline_abi_version() == 4
+    assert lib.aline_abi_version() == 5
     lib.aline_error_string.restype = ctypes.c_char_p
     assert lib.aline_error_string(0) == b"ok"
     assert b"workspace" in lib.aline_error_string(-3)
@@ -217,7 +217,7 @@ def test_rollout_path_selection_is_pure_host(lib):
     from aline_amd import _lib
     L = _lib.lib
     byref = ctypes.byref
-    GENERIC, FUSED, WIDE, X3, S3 = 0, 1, 2, 3, 4
+    GENERIC, FUSED, X3, S3 = 0, 1, 3, 4
 
     def rollout(B=1000, P=201, n_ctx0=1, n_td=0, T=30):
         r = _lib.AlineRollout()
@@ -246,7 +246,7 @@ def test_rollout_path_selection_is_pure_host(lib):
     w.precision = _lib.PREC["f16x3"]
     assert L.aline_rollout_path(byref(w), byref(rollout())) == X3
     w.precision = _lib.PREC["bf16"]
-    assert L.aline_rollout_path(byref(w), byref(rollout())) == WIDE
+    assert L.aline_rollout_path(byref(w), byref(rollout())) == GENERIC           # (ABI 5: the bf16 `wide` kernels are gone)
     assert L.aline_rollout_path(byref(w), byref(rollout(T=70))) == GENERIC    # 72 keys > 64
     w.d, w.F, w.precision = 512, 128, _lib.PREC["f16x3"]                      # the psychometric configuration's width (cfg5)
     assert L.aline_rollout_path(byref(w), byref(rollout(B=256))) == 5         # ALINE_PATH_X5

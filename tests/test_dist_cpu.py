@@ -168,6 +168,47 @@ def _flat_grad_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _status_worker(rank, world, port, out):
+    """The f16 range status of a training step rides the gradient all-reduce: train.flat_grads puts one slot behind the gradients,
+    all_reduce_grads reduces gradients + slot in ONE collective, check_training_range raises on every rank if ANY rank set it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import aline_amd.train as tr
+    model = torch.nn.Linear(3, 2)
+    flat, store = None, None
+    params = list(model.parameters())
+    store = torch.zeros(sum(p.numel() for p in params) + 1)
+    flat = store[:-1]
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        p.grad.fill_(float(rank + 1))
+        off += p.numel()
+    model._aline_flat_store = store
+    before = tr.ALLREDUCE_CALLS
+    store[-1] = 1.0 if rank == 1 else 0.0               # only rank 1 overflowed
+    tr.all_reduce_grads(model, dist, world, flat=flat)
+    raised = False
+    try:
+        tr.check_training_range({"range_status": store[-1:]})
+    except RuntimeError:
+        raised = True
+    out.put((rank, raised, float(flat.mean()), tr.ALLREDUCE_CALLS - before))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_range_status_rides_the_gradient_all_reduce_and_stops_every_rank():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_status_worker, args=(r, world, port, out)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(out.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert res == [(0, True, 1.5, 1), (1, True, 1.5, 1)]       # both ranks stop; gradients averaged; one collective
+
+
 def test_flat_buffer_all_reduce_keeps_the_gradient_views():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()

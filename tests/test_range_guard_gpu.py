@@ -103,3 +103,24 @@ def test_training_step_stops_on_overflow():
     tr.train_step(model, batch, 4, optimizer=None)
     with pytest.raises(RuntimeError, match="f16's range"):
         tr.check_range_async(block=True)
+
+
+def test_driver_train_stops_before_the_update_and_the_checkpoint(tmp_path):
+    """`driver.train` must stop in the epoch whose rollout overflowed -- before optimizer.step() turns every weight
+    into NaN (inf-norm clip of a NaN gradient) and before a checkpoint of them is written."""
+    import os
+    import random
+    from aline_amd.driver import train
+    from aline_amd.tasks import HiddenLocation
+    from test_driver import _Cfg, _cfg
+    torch.manual_seed(0); random.seed(0)
+    model, _ = native_model(D32, 7, "f16x3")
+    task = HiddenLocation(n_query_init=40, device=torch.device("cuda"))
+    cfg = _cfg(tmp_path, max_epoch=3, burning_epoch=0, checkpoint=1, T=4, min_T=4, batch_size=8,
+               task=_Cfg(mask_type=["all"], embedding_type="theta", n_target_data=0, n_target_theta=2, n_query_init=40))
+    _scaled(model, "embedder.x_embedder.2.weight", 3e5)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with pytest.raises(RuntimeError, match="f16's range"):
+        train(cfg, model, task)
+    assert all(torch.equal(v, before[k]) for k, v in model.state_dict().items())      # no update was applied
+    assert not os.path.exists(tmp_path / "ckpt_1.tar")                                   # and nothing was saved

@@ -28,8 +28,8 @@ def _run(fxname, prec, env, fill):
 @pytest.mark.parametrize("name,fxname,prec,env", [
     ("fused d=32", "cfg2_location_d32", "f32", {}),
     ("generic d=32", "cfg2_location_d32", "f32", {"ALINE_DISABLE_FUSED": "1"}),
-    ("wide step d=256", "cfg2_location_d256", "bf16", {}),
-    ("generic bf16 d=256", "cfg2_location_d256", "bf16", {"ALINE_DISABLE_WIDE": "1"}),
+    ("x3 d=256", "cfg2_location_d256", "f16x3", {}),
+    ("generic bf16 d=256", "cfg2_location_d256", "bf16", {}),
     ("generic mix-mode", "cfg3_almix_d2", "f32", {}),
 ])
 def test_outputs_do_not_depend_on_workspace_contents(name, fxname, prec, env):
@@ -42,12 +42,13 @@ def test_outputs_do_not_depend_on_workspace_contents(name, fxname, prec, env):
 
 @pytest.mark.parametrize("name,fxname,prec,env", [
     ("fused d=32", "cfg2_location_d32", "f32", {}),
-    ("wide step d=256", "cfg2_location_d256", "bf16", {}),
-    ("wide blocks d=256", "cfg2_location_d256", "bf16", {"ALINE_WIDE_BLOCKS": "1"}),
+    ("s3 d=32", "cfg2_location_d32", "f16x3", {}),
+    ("x3 d=256", "cfg2_location_d256", "f16x3", {}),
+    ("generic bf16 d=256", "cfg2_location_d256", "bf16", {}),
 ])
 def test_paths_are_bit_reproducible(name, fxname, prec, env):
     """Twelve identical rollouts, identical bits.  (An integer ReLU applied directly to MFMA results once made the
-    block kernels' logits differ in 1 of 3 runs -- common.h: relu_nn.)"""
+    bf16 block kernels of rounds 1-3 differ in 1 of 3 runs -- common.h: relu_nn.)"""
     ref = _run(fxname, prec, env, 0)
     for _ in range(11):
         out = _run(fxname, prec, env, 0)

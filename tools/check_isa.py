@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Build-time audit of the gfx950 code object (python tools/check_isa.py; exits non-zero on a finding).
 
-1. Hand-managed MFMA -> VALU hazards.  wide_step_kernel keeps its accumulators in AGPRs through opaque inline-asm
-   `v_accvgpr_read_b32` (wide_step.h: acc_rd), which the compiler's hazard recogniser cannot see; the source guards every
-   such read with mfma_drain().  MEASURED requirement (tools/probes/mfma_valu_hazard.hip on MI355X): 7 wait states between a
+1. Hand-managed MFMA -> VALU hazards.  A kernel that keeps accumulators in AGPRs through opaque inline-asm
+   `v_accvgpr_read_b32` (the bf16 step kernel of rounds 1-3 did; none does since round 4, the audit stays for the next one)
+   hides those reads from the compiler's hazard recogniser and must pad them itself.  MEASURED requirement (tools/probes/mfma_valu_hazard.hip on MI355X): 7 wait states between a
    v_mfma_f32_16x16x32_* and ANY VALU reader of its result -- v_max_i32, v_max_f32 and v_accvgpr_read_b32 alike -- and hipcc
    itself pads 8.  This script walks the disassembly of every kernel and fails if an inline-asm v_accvgpr_read_b32 (between
    ;;#ASMSTART / ;;#ASMEND) can be reached from a v_mfma with fewer than REQUIRED wait states in between (straight-line

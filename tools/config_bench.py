@@ -31,8 +31,6 @@ def build(dx, d, F, H, n_theta, emb, precision):
 def path_of(d, F, H, emb, precision, keys):
     if precision == "f32" and (d, F, H) == (32, 128, 4) and emb == "theta":
         return "fused::rollout_f32_kernel"
-    if precision == "bf16" and d == 256 and H == 8 and F % 64 == 0 and keys <= 64:
-        return "wide::wide_step_kernel"
     if precision == "f16x3" and d == 256 and H == 8 and keys <= 64:
         return "x3::layer_kernel"
     if precision == "f16x3" and d == 512 and H == 8 and keys <= 64:

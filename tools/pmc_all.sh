@@ -1,7 +1,6 @@
 #!/bin/bash
 # PMC passes (separate runs, kernel-trace only) for the two dominant kernels: run on the GPU box from the repo root.
 #   tools/pmc_all.sh d32   -> fused::rollout_f32_kernel   (default bench config)
-#   tools/pmc_all.sh d256  -> wide::wide_step_kernel      (--d-model 256 --d-ff 1024 --heads 8 --precision bf16)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 #   tools/pmc_all.sh x3    -> x3::layer_kernel            (--d-model 256 --d-ff 1024 --heads 8 --precision f16x3)

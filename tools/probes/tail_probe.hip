@@ -1,7 +1,7 @@
 // Stand-alone timing of tailbwd::tail_kernel (forward / backward) on random data, for remove-one-part experiments:
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I aline_amd/csrc [-DTAIL_NO_MFMA] -o tail_probe tools/probes/tail_probe.hip
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I aline_amd/csrc -o tail_probe tools/probes/tail_probe.hip
 //   ./tail_probe [rows] [fwd_grid] [bwd_grid]
-#include "tail_bwd.h"
+#include "tail_bwd_pc.h"     // (tail_bwd.h + the archived producer / consumer experiment)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

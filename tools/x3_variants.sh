@@ -1,7 +1,9 @@
 #!/bin/bash
 # Timing experiments on the x3 layer kernel: builds variants of the library with parts of the kernel removed
 # (results are garbage, only the time is read) into aline_amd/csrc/variants/, to be run with ALINE_HIP_LIB=<variant>.
-#   tools/x3_variants.sh build "NAME:-DFLAG -DFLAG" ...      (here, cross-compiling)
+#   python tools/probes/timing_variants.py build NAME ...    (here, cross-compiling: a variant is a set of text edits applied to
+#                                                              a scratch copy of the sources -- the shipped headers carry no switches)
+#   tools/x3_variants.sh build "NAME:-DFLAG -DFLAG" ...      (macro-selected builds, e.g. the stamped diagnostic instantiations)
 #   tools/x3_variants.sh run NAME ...                        (on the GPU box: prints ms per rollout and the layer kernel time)
 cd "$(dirname "$0")/.." || exit 1
 mode=$1; shift
