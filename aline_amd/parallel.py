@@ -13,9 +13,10 @@ def world_info():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def aggregate_throughput(local_units: float, local_seconds: float, dist=None, device="cpu"):
-    """Whole-job rate = units of all ranks / max-over-ranks time (the bench.py contract)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def aggregate_throughput(local_units: float, local_seconds: float, dist=None, device="cpu", always=False):
+    """Whole-job rate = units of all ranks / max-over-ranks time (the bench.py contract).  always: reduce also in a world of one
+    (bench.py's single-GPU rehearsal of the RCCL path)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return local_units / local_seconds, local_seconds, local_units
     t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
     u = torch.tensor([local_units], dtype=torch.float64, device=device)

@@ -328,7 +328,8 @@ def optimizer_step(model, optimizer, burn_in=False):
 
 
 def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_type="all", gamma=1.0, alpha=1.0,
-               burn_in=False, forced_idx=None, clip_grads=True, dist=None, world=1, t_chunk=None, global_reward_moments=False):
+               burn_in=False, forced_idx=None, clip_grads=True, dist=None, world=1, t_chunk=None, global_reward_moments=False,
+               force_collective=False):
     """One epoch body of train_aline.py:55-152 (without the hydra / logging shell).
 
     The returned `ro` is the step's rollout; when it came from the graph cache its outputs (log_prob, target_ll, idx, ...) are
@@ -336,7 +337,8 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
     The activations it kept for the backward (`ro.saved_acts`) live in ONE buffer shared by all training rollouts of the process and
     are overwritten by the next step's rollout whatever its shape.
     global_reward_moments (N > 1): z-score the rewards with the moments of the WHOLE data-parallel batch (one extra all-reduce
-    of [3, T - 1] floats before the backward; SURVEY 8-e option ii) instead of the rank-local moments (option i)."""
+    of [3, T - 1] floats before the backward; SURVEY 8-e option ii) instead of the rank-local moments (option i).
+    force_collective: issue the gradient all-reduce also at world == 1 (bench.py's single-GPU rehearsal of the RCCL path)."""
     model.train()
     check_range_async()                   # (f16x3 rollouts of earlier steps: raises if an operand left f16's range)
     with torch.no_grad():
@@ -359,7 +361,7 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
         terms = reinforce_terms(ro, embedding_type, mask_type, gamma, alpha, burn_in,
                                 dist=dist if (global_reward_moments and world > 1) else None, world=world)
         backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=t_chunk, grads=gstruct)
-        if dist is not None and world > 1:
+        if dist is not None and (world > 1 or force_collective):
             all_reduce_grads(model, dist, world, flat=flat)
         if clip_grads:
             # torch.nn.utils.clip_grad_norm_(parameters, max_norm=1.0, norm_type="inf") of train_aline.py:138 on the flat buffer:

@@ -385,6 +385,13 @@ def main():
             raise SystemExit(0)
         raise SystemExit(subprocess.call(cmd))
 
+    # ONE JSON line on stdout is the contract, and libraries write there too (RCCL prints a version banner at communicator creation,
+    # gloo its "connected to N peer ranks" lines: seen in the round-4 rehearsals): from here on file descriptor 1 is stderr, and the
+    # result line goes to the descriptor the process was started with.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from aline_amd.parallel import aggregate_throughput, world_info
     rank, local_rank, world = world_info()
     if args.gpus != world:
@@ -395,8 +402,17 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    # ALINE_BENCH_FORCE_DIST=1 (N = 1): initialise the process group, run the joined-ranks all-reduce, the barriers, the max-over-ranks
+    # reductions and the flat-buffer gradient all-reduce in a world of ONE rank -- the single-GPU rehearsal of the RCCL code path
+    # (the nccl branch had never executed anywhere); results equal the plain N = 1 run.
+    force_dist = os.environ.get("ALINE_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:          # (forced world of one without a launcher)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -457,7 +473,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     designs_per_rollout = args.batch * args.T * args.n_query
     # whole job = the designs of all ranks / the slowest rank's time
-    value, dt, _ = aggregate_throughput(float(designs_per_rollout * args.steps), dt, dist, device)
+    value, dt, _ = aggregate_throughput(float(designs_per_rollout * args.steps), dt, dist, device, always=force_dist)
 
     # sustained leg: the same replay back to back for >= --sustain-s seconds (so that SMI sampling sees the GPU busy)
     sustained_ms = None
@@ -469,7 +485,7 @@ def main():
             ro.refresh_uniform()
             run()
         barrier()
-        _, sdt, _ = aggregate_throughput(1.0, time.perf_counter() - t1, dist, device)
+        _, sdt, _ = aggregate_throughput(1.0, time.perf_counter() - t1, dist, device, always=force_dist)
         sustained_ms = sdt / n_sus * 1e3
         log(f"sustained leg: {n_sus} rollouts in {sdt:.2f} s = {sustained_ms:.3f} ms each")
 
@@ -587,7 +603,7 @@ def main():
                    "heads": args.heads, "layers": args.layers, "components": 10,
                    "posterior_out_query": "lazy (not computed; same in the CPU baseline)",
                    "hip_graph": bool(args.graph), "exact_designs_per_rollout": exact, "path": path,
-                   "f16_range_status": range_status, "backend": backend if world > 1 else None, "prewarm_s": args.prewarm_s,
+                   "f16_range_status": range_status, "backend": backend if (world > 1 or force_dist) else None, "forced_world_of_one": force_dist, "prewarm_s": args.prewarm_s,
                    "precision": args.precision,
                    "parallelism": f"episode-dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
@@ -607,7 +623,7 @@ def main():
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
         err = None
         try:
-            train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)        # warm-up
+            train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world, force_collective=force_dist)        # warm-up
         except Exception as e:      # a secondary leg must not take the headline line with it ...
             err = e
             log(f"train step leg failed: {e!r}")
@@ -625,21 +641,21 @@ def main():
             ar0 = train_mod.ALLREDUCE_CALLS
             t1 = time.perf_counter()
             for _ in range(args.train_steps):
-                train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world)
+                train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world, force_collective=force_dist)
             barrier()
-            tval, tdt, _ = aggregate_throughput(float(designs_per_rollout * args.train_steps), time.perf_counter() - t1, dist, device)
+            tval, tdt, _ = aggregate_throughput(float(designs_per_rollout * args.train_steps), time.perf_counter() - t1, dist, device, always=force_dist)
             train_mod.check_range_async(block=True)
             out["train_step"] = {"value": tval, "unit": "designs/s",
                                  "ms_per_step": tdt / args.train_steps * 1e3, "steps": args.train_steps,
                                  "includes": f"forward rollout ({path}) + fused exact-fp32 backward of all T steps (layer_fwd / tail / attention-block / acquisition-head kernels) + "
                                              "flat-bucket gradient all-reduce (N>1) + inf-norm clip + AdamW",
-                                 "collective": "1 all-reduce / optimiser step" if world > 1 else "none (N=1)",
+                                 "collective": "1 all-reduce / optimiser step" if (world > 1 or force_dist) else "none (N=1)",
                                  "rccl_allreduce_calls": train_mod.ALLREDUCE_CALLS - ar0,
                                  "rccl_allreduce_per_step": (train_mod.ALLREDUCE_CALLS - ar0) / args.train_steps}
             log(f"train step: {tdt / args.train_steps * 1e3:.1f} ms")
     if not args.no_query_gmm and args.precision in ("f32", "f16x3"):
         qms, qpath = rollout_ms_with_query_gmm(args, model, batch, device)
-        out["value_with_query_gmm"], qsec, _ = aggregate_throughput(float(designs_per_rollout), qms * 1e-3, dist, device)
+        out["value_with_query_gmm"], qsec, _ = aggregate_throughput(float(designs_per_rollout), qms * 1e-3, dist, device, always=force_dist)
         qms = qsec * 1e3
         out["query_gmm"] = {"ms_per_rollout": qms, "path": qpath,
                             "note": "posterior_out_query (model/head.py:366) is lazy in the step API and is NOT part of `value`; this "
@@ -664,7 +680,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, model)
         log("cpu baseline done")
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -118,3 +118,25 @@ def test_eval_boed_on_the_reference_tape(golden, precision):
         assert torch.equal(x.cpu(), fx.t(f"trace{i}.x")) and torch.equal(y.cpu(), fx.t(f"trace{i}.y"))
         assert torch.equal(th0.cpu(), fx.t(f"trace{i}.theta0"))
         tape.nt += 1                                                            # (skip the contrastive draw between two traces)
+
+
+def test_bench_runs_its_rccl_branch_in_a_world_of_one():
+    """The `nccl` (= RCCL) branch of bench.py -- init_process_group(device_id=...), the joined-ranks all-reduce, the barriers, the
+    max-over-ranks reductions and the flat-buffer gradient all-reduce on a device tensor -- executed on the one GPU of this box
+    (ALINE_BENCH_FORCE_DIST=1, a world of one rank), and stdout carries exactly ONE JSON line although RCCL prints its version banner."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ALINE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "64", "--steps", "2", "--warmup", "1",
+                          "--train-steps", "1", "--sustain-s", "0", "--prewarm-s", "0", "--no-d256", "--no-d512", "--no-f32",
+                          "--no-query-gmm", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["config"]["backend"] == "nccl" and j["config"]["forced_world_of_one"] is True
+    assert j["train_step"]["rccl_allreduce_per_step"] == 1.0 and j["train_step"]["collective"].startswith("1 all-reduce")
