@@ -68,6 +68,7 @@ class AlineRollout(C.Structure):
         + [("time_token_T", C.c_int32)]
         + [(n, _fp) for n in ("idx", "slot", "log_prob", "target_ll", "zt", "post_mean", "post_std",
                               "post_weight", "ev_kernel_start", "ev_kernel_stop", "postq_mean", "postq_std", "postq_weight", "saved_acts")]
+        + [("ev_kernel_step", C.c_int32)]
     )
 
 
@@ -135,7 +136,7 @@ DBG = {"DISABLE_FUSED": 1 << 0, "DISABLE_X3": 1 << 2, "DISABLE_S3": 1 << 3,
        "FUSED_STAMPS": 1 << 10, "SELECT_WORKGROUP": 1 << 13,
        "NO_BWD_TAIL": 1 << 16, "NO_BWD_ATTN_BLOCK": 1 << 17, "NO_BWD_ACQ": 1 << 18, "NO_BWD_LAYER_FWD": 1 << 19,
        "NO_BWD_LAYER_FWD_FLAT": 1 << 20, "NO_BWD_GMM_FUSED": 1 << 21, "NO_BWD_GMM128": 1 << 22, "NO_BWD_GMM_BATCHED": 1 << 23,
-       "NO_BWD_ATTN_MFMA": 1 << 24, "NO_BWD_DW_WALK": 1 << 25, "NO_BWD_GMM_WIDE": 1 << 26, "NO_BWD_SAVED_ACTS": 1 << 27, "BWD_RECOMPUTE_F32": 1 << 28, "BWD_DW_TK2": 1 << 29}
+       "NO_BWD_ATTN_MFMA": 1 << 24, "NO_BWD_DW_WALK": 1 << 25, "NO_BWD_GMM_WIDE": 1 << 26, "NO_BWD_SAVED_ACTS": 1 << 27, "BWD_RECOMPUTE_F32": 1 << 28, "BWD_DW_TK2": 1 << 29, "BWD_GRAD_F32": 1 << 30}
 DBG_PARAM = {"S3_WAVES": 0, "S3_EPW": 1, "BWD_PREC": 2}
 
 

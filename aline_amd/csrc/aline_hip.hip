@@ -1000,7 +1000,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
 #ifdef S3_STAMPS
     sa.stamps = want_gmm ? nullptr : reinterpret_cast<unsigned long long *>(c.at(c.pl.sRaw));
 #endif
-    const bool timed = t == r->T - 1;                          // bench.py times this launch of the dominant kernel
+    const bool timed = t == (r->ev_kernel_step > 0 ? r->ev_kernel_step - 1 : r->T - 1);      // bench.py times this launch of the dominant kernel
     if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
     TRY(launch_s3_step(c, sh, sa));
     if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
@@ -1229,11 +1229,18 @@ static int bwd_prec() {
 static int recompute_prec(const aline_model &m) {
   return (m.precision == ALINE_PREC_F16X3 && m.d >= 64 && !dbg(ALINE_DBG_BWD_RECOMPUTE_F32)) ? ALINE_PREC_F16X3 : bwd_prec();
 }
+// Round 4: the GRADIENT products of the per-op backward (dX = dY W, dW = dY^T X) of an F16X3 model at d >= 64 run the 3-term f16
+// split too, with the gradient operand scaled by a per-tensor power of two (max |dY| -> [2^14, 2^15); gemm.h: xmax_bits) -- unscaled,
+// gradients of 1e-8 .. 1e-5 sit in f16's subnormals (round 3 kept these products on the 157 TFLOP/s fp32 pipe for that reason).
+// ALINE_DBG_BWD_GRAD_F32: exact fp32 as before (A/B runs, parity tests).
+static bool bwd_grad_f16(const aline_model &m) {
+  return m.precision == ALINE_PREC_F16X3 && m.d >= 64 && !dbg(ALINE_DBG_BWD_GRAD_F32) && dbg_param(ALINE_DBG_BWD_PREC) == 0;
+}
 
 namespace {
 
 struct BwdPlan {
-  size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt, KeyIdx, Kcnt, Tvec,
+  size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt, KeyIdx, Kcnt, Tvec, Scale,
       total;
 };
 
@@ -1284,6 +1291,7 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   p.Wt = take(std::max({(size_t)3 * d * d, F * d, (size_t)m.C * F * d}));
   p.KeyIdx = take(M);      // (ints) key rows of every instance: K / V of the forward recompute on these rows only
   p.Kcnt = take(I * 2);
+  p.Scale = take(16 * 16);      // (unsigned) ring of 16 max-|dY| words (one per 16-word line) of the scaled f16 gradient products
   p.total = off;
   return p;
 }
@@ -1303,23 +1311,87 @@ int transpose_to(const BCtx &c, const float *W, int rows, int cols, float *dst, 
   return ALINE_OK;
 }
 
+// Scale words of the F16X3 gradient products (gemm.h: xmax_bits): max |dY| of a gradient tensor, as bits.  A word is taken from a ring
+// of 16 (cleared by a kernel node in stream order), filled either by the PRODUCER of the tensor -- LayerNorm backward and the GEMM
+// epilogue reduce what they store (one atomicMax per wave) -- or by a reduction pass over the stored tensor (grad_absmax: 190 us per
+// call at the d = 256 headline chunk, 11 % of the step when every product ran its own), and handed to the products that read the tensor.
+// A word lives until the ring comes round: 16 producers later (every consumer follows its producer within three calls).
+static int g_scale_next = 0;
+unsigned *new_scale_word(const BCtx &c) {
+  unsigned *w = reinterpret_cast<unsigned *>(c.at(c.pl.Scale)) + 16 * (g_scale_next++ & 15);
+  hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(16), 0, c.st, w);
+  return w;
+}
+unsigned *grad_absmax(const BCtx &c, const float *dY, long rows, int cols, int ld) {
+  unsigned *w = new_scale_word(c);
+  const long n4 = rows * (cols / 4);
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, c.st, dY, rows, cols, ld, w);
+  return w;
+}
+
+// A gradient product Y = dY . Wt^T of the per-op backward: the scaled f16 split (bwd_grad_f16) or the exact-fp32 policy.
+// scale: the word of dY (null: reduce dY here); out_max: a cleared word that receives max |Y| (Y is itself a gradient operand), or null
+int launch_grad_gemm(const BCtx &c, GemmArgs a, const unsigned *scale = nullptr, unsigned *out_max = nullptr) {
+  a.out_absmax = out_max;
+  if (bwd_grad_f16(*c.m) && a.K % 4 == 0 && !a.row_index && a.R_in == a.G_in) {
+    a.xmax_bits = scale ? scale : grad_absmax(c, a.X, a.M, a.K, a.ldx);
+    a.range_flag = nullptr;
+    return launch_gemm(ALINE_PREC_F16X3, a, 1, c.st);
+  }
+  return launch_gemm(bwd_prec(), a, 1, c.st);
+}
+
 // dX[M, K] (+)= dY[M, N] . W[N, K]   (W in PyTorch layout [N, K]); Wt scratch holds W^T [K, N]
 int gemm_dx(const BCtx &c, const float *dY, int ldy, const float *W, int N, int K, float *dX, int ldx, int M,
-            bool accum, const float *relu_of = nullptr) {
+            bool accum, const float *relu_of = nullptr, const unsigned *scale = nullptr, unsigned *out_max = nullptr) {
   float *Wt = c.at(c.pl.Wt);
   TRY(transpose_to(c, W, N, K, Wt));
   GemmArgs a = gemm_args(dY, ldy, Wt, nullptr, N, dX, ldx, M, K, N, false);
   a.accum = accum ? 1 : 0;
   a.mask = relu_of; a.ldmask = ldx;      // gradient through the ReLU whose output is `relu_of` [M, K]
-  TRY(launch_gemm(bwd_prec(), a, 1, c.st));
+  TRY(launch_grad_gemm(c, a, scale, out_max));
   CHECK_LAUNCH();
   return ALINE_OK;
 }
 
 // dW[N, K] += dY^T X, db[N] += colsum(dY)
 int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, long M,
-            int N, int K, int Ry = 1, int Gy = 1, int offy = 0, int Rx = 1, int Gx = 1, int offx = 0, int ldw = 0) {
+            int N, int K, int Ry = 1, int Gy = 1, int offy = 0, int Rx = 1, int Gx = 1, int offx = 0, int ldw = 0,
+            const unsigned *scale = nullptr) {
   if (N % 32 || K % 32) return ALINE_EUNSUPPORTED;
+  if (bwd_grad_f16(*c.m) && Ry == Gy && Rx == Gx && N % 256 == 0 && K % 256 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && M < (1l << 40)) {
+    // the scaled 3-term f16 split on 256 x 256 blocks (backward.h: gemm_tn_f16_kernel); the wider operand indexes the block rows
+    const float *pY = dY + (long)offy * ldy, *pX = X + (long)offx * ldx;
+    if (!(reinterpret_cast<uintptr_t>(pY) & 15) && !(reinterpret_cast<uintptr_t>(pX) & 15)) {
+      GemmTnF16Args f{};
+      f.xmax_bits = scale ? scale : grad_absmax(c, pY, M, N, ldy);
+      const long ldo = ldw > 0 ? ldw : K;
+      f.P = pY; f.ldp = ldy; f.Q = pX; f.ldq = ldx; f.out = dW; f.sa = ldo; f.sb = 1; f.grad_is_p = 1;
+      f.nba = N / 256; f.nbb = K / 256;
+      f.colsum = db; f.M = M;
+      // rows per workgroup: one workgroup per CU at a time, so the launch is whole rounds of n_cu workgroups -- the row chunk is sized
+      // so that chunks x blocks fills r rounds (r the smallest that keeps a chunk <= 4096 rows: 400 workgroups of 4096 rows on 256 CUs
+      // were 1.56 rounds that cost 2)
+      {
+        int dev = 0, n_cu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        const long nblk = (long)f.nba * f.nbb;
+        long r = 1;
+        while ((M * nblk + n_cu * r - 1) / (n_cu * r) > 4096) ++r;
+        long per = (M * nblk + n_cu * r - 1) / (n_cu * r);          // rows per workgroup for exactly r rounds
+        per = std::max<long>(256, (per + 31) / 32 * 32);
+        f.mchunk = per;
+      }
+      f.gx = (int)((M + f.mchunk - 1) / f.mchunk);
+      const unsigned grid = (unsigned)((f.gx + 7) / 8 * 8) * (unsigned)(f.nba * f.nbb);
+      constexpr int TN16_LDS = 2 * 2 * 512 * 32 * 2;      // two images x (hi | lo) x [512 columns][32 rows] f16 = 128 KB
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN16_LDS);
+      hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3(grid), dim3(512), TN16_LDS, c.st, f);
+      CHECK_LAUNCH();
+      return ALINE_OK;
+    }
+  }
   GemmTnArgs a{};
   a.dY = dY; a.ldy = ldy; a.Ry = Ry; a.Gy = Gy; a.offy = offy;
   a.X = X; a.ldx = ldx; a.Rx = Rx; a.Gx = Gx; a.offx = offx;
@@ -1355,8 +1427,9 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
 }
 
 int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float *dU, float *dw, float *db,
-           long rows) {
+           long rows, unsigned **out_max = nullptr) {
   const int d = c.m->d;
+  if (out_max) *out_max = nullptr;
   if (d == 32 || d == 64) {
     const int rows_per_pass = d == 32 ? 32 : 16;
     const unsigned grid = (unsigned)std::min<long>((rows + rows_per_pass - 1) / rows_per_pass, 256 * 8);
@@ -1366,8 +1439,10 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
     return ALINE_OK;
   }
   const int rpb = 64;
+  unsigned *mw = (out_max && bwd_grad_f16(*c.m)) ? new_scale_word(c) : nullptr;      // max |dU| for the F16X3 products that read dU
+  if (out_max) *out_max = mw;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
-                     (size_t)2 * c.m->d * sizeof(float), c.st, dY, U, w, dU, dw, db, rows, c.m->d, rpb);
+                     (size_t)2 * c.m->d * sizeof(float), c.st, dY, U, w, dU, dw, db, rows, c.m->d, rpb, mw);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
@@ -1685,7 +1760,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       TRY(transpose_to(c, m->acq_w1, F, d, Wt, ldw1));
       GemmArgs ga = gemm_args(HidA, F, Wt, nullptr, F, dX, d, I * P, d, F, false);
       ga.R_out = P; ga.G_out = N; ga.off_out = 0;
-      TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
+      TRY(launch_grad_gemm(c, ga));
       CHECK_LAUNCH();
     }
     if (fgmm) {
@@ -1748,7 +1823,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         CHECK_LAUNCH();
         GemmArgs ga = gemm_args(HidG, C * F, Wt, nullptr, C * F, dX, d, I * n_t, d, C * F, false);
         ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
-        TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
+        TRY(launch_grad_gemm(c, ga));
       } else {
       for (int k = 0; k < C; ++k) {
         TRY(gemm_dw(c, HidG + (size_t)k * F, C * F, Z, d, gr->gmm_w1[k], gr->gmm_b1[k], (long)I * n_t, F, d, 1, 1, 0,
@@ -1762,7 +1837,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       for (int k = 0; k < C; ++k) {
         GemmArgs ga = gemm_args(HidG + (size_t)k * F, C * F, Wt + (size_t)k * F * d, nullptr, F, dX, d, I * n_t, d, F, false);
         ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
-        TRY(launch_gemm(bwd_prec(), ga, 1, c.st));
+        TRY(launch_grad_gemm(c, ga));
       }
       }
       CHECK_LAUNCH();
@@ -1778,17 +1853,20 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         TRY(launch_tail(c, l, Xs(l), Al(l), nullptr, dX, dTmp, dXn, gr, M));
       } else {
       // LN2
-      TRY(ln_bwd(c, dX, U2l(l), m->norm2_w[l], dTmp, gr->norm2_w[l], gr->norm2_b[l], M));   // dTmp = dU2
+      // (sw_*: the scale words of the F16X3 gradient products -- the producer of a gradient tensor leaves max |.| for its readers)
+      unsigned *sw_u2 = nullptr, *sw_u1 = nullptr;
+      TRY(ln_bwd(c, dX, U2l(l), m->norm2_w[l], dTmp, gr->norm2_w[l], gr->norm2_b[l], M, &sw_u2));   // dTmp = dU2
       // FFN
-      TRY(gemm_dw(c, dTmp, d, Hidl(l), F, gr->lin2_w[l], gr->lin2_b[l], M, d, F));
-      TRY(gemm_dx(c, dTmp, d, m->lin2_w[l], d, F, dHid, F, (int)M, false, Hidl(l)));
-      TRY(gemm_dw(c, dHid, F, X1l(l), d, gr->lin1_w[l], gr->lin1_b[l], M, F, d));
-      TRY(gemm_dx(c, dHid, F, m->lin1_w[l], F, d, dTmp, d, (int)M, true));                      // dTmp = dX1
+      unsigned *sw_hid = bwd_grad_f16(*m) ? new_scale_word(c) : nullptr;
+      TRY(gemm_dw(c, dTmp, d, Hidl(l), F, gr->lin2_w[l], gr->lin2_b[l], M, d, F, 1, 1, 0, 1, 1, 0, 0, sw_u2));
+      TRY(gemm_dx(c, dTmp, d, m->lin2_w[l], d, F, dHid, F, (int)M, false, Hidl(l), sw_u2, sw_hid));
+      TRY(gemm_dw(c, dHid, F, X1l(l), d, gr->lin1_w[l], gr->lin1_b[l], M, F, d, 1, 1, 0, 1, 1, 0, 0, sw_hid));
+      TRY(gemm_dx(c, dHid, F, m->lin1_w[l], F, d, dTmp, d, (int)M, true, nullptr, sw_hid));     // dTmp = dX1
       // LN1
-      TRY(ln_bwd(c, dTmp, U1l(l), m->norm1_w[l], dXn, gr->norm1_w[l], gr->norm1_b[l], M));   // dXn = dU1
+      TRY(ln_bwd(c, dTmp, U1l(l), m->norm1_w[l], dXn, gr->norm1_w[l], gr->norm1_b[l], M, &sw_u1));   // dXn = dU1
       // out-proj
-      TRY(gemm_dw(c, dXn, d, Al(l), d, gr->out_proj_w[l], gr->out_proj_b[l], M, d, d));
-      TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false));                  // dTmp = dA
+      TRY(gemm_dw(c, dXn, d, Al(l), d, gr->out_proj_w[l], gr->out_proj_b[l], M, d, d, 1, 1, 0, 1, 1, 0, 0, sw_u1));
+      TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false, nullptr, sw_u1));  // dTmp = dA
       }
       // attention block: in-projection + attention in one kernel (attn_bwd_mfma.h), dXn = dU1 -> dX_l
       if (ckv) {
@@ -1814,8 +1892,9 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         default: return ALINE_EUNSUPPORTED;
       }
       // in-proj
-      TRY(gemm_dw(c, dQKV, 3 * d, Xs(l), d, gr->in_proj_w[l], gr->in_proj_b[l], M, 3 * d, d));
-      TRY(gemm_dx(c, dQKV, 3 * d, m->in_proj_w[l], 3 * d, d, dXn, d, (int)M, true));             // dXn = dX_l
+      const unsigned *sw_qkv = bwd_grad_f16(*m) ? grad_absmax(c, dQKV, M, 3 * d, 3 * d) : nullptr;      // (the attention backward does not reduce its output)
+      TRY(gemm_dw(c, dQKV, 3 * d, Xs(l), d, gr->in_proj_w[l], gr->in_proj_b[l], M, 3 * d, d, 1, 1, 0, 1, 1, 0, 0, sw_qkv));
+      TRY(gemm_dx(c, dQKV, 3 * d, m->in_proj_w[l], 3 * d, d, dXn, d, (int)M, true, nullptr, sw_qkv));   // dXn = dX_l
       std::swap(dX, dXn);
     }
     if (!do_emb) {                  // encoder (+ head) without the embedder: dLoss / dx is the result

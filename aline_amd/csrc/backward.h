@@ -5,6 +5,7 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#include "gemm.h"
 
 // dW[n, k] += sum_m dY[m, n] * X[m, k]   and (optionally) db[n] += sum_m dY[m, n]
 // "TN" product over a very tall M.  One workgroup = one block of dW x one chunk of rows; its 4 waves take
@@ -202,6 +203,141 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_block_kernel(GemmTnArgs a) {
   }
 }
 
+// ---- weight-gradient product on the f16 matrix pipe (round 4) ---------------------------------------------------------------------
+// out[a, b] += sum_m P[m, a0 + a] * Q[m, b0 + b] for a 256 x 256 block of (P columns) x (Q columns) and a chunk of rows, every product
+// the 3-term f16 split of the forward (hi * hi + hi * lo + lo * hi, fp32 accumulate).  One of the operands is a gradient (1e-8 .. 1e-5):
+// it is multiplied by the per-tensor power of two of gemm.h (xmax_bits) on its way into LDS and the block is divided by it at the end.
+// 8 waves; a slab of 32 rows of both tiles (64 KB of fp32) is loaded as float4 (a wave reads 1 KB of one row per instruction), split and
+// stored COLUMN-major -- [column][32 rows] f16, hi and lo planes, the 16-byte chunks swizzled as in gemm.h -- so that the fragment of a
+// 16x16x32 MFMA (8 consecutive rows of one column per lane) is one ds_read_b128: the same LDS image and MFMA loop as the NT kernel.
+// Wave (wi, wj) owns 64 x 128 of the block (32 accumulator tiles).  Two LDS images (128 KB): while the 768 MFMAs of slab s run out of
+// one, slab s + 1 (loaded during slab s - 1) is split and stored into the other and the loads of slab s + 2 are issued -- one barrier
+// per slab, no phase in which the matrix pipe waits for the staging (single-buffered: 0.76 ms per call, 25 % of the f16 peak).
+// The exact-fp32 kernel above needs 8 MFMAs of 32 cycles where this one needs 3 of 16.
+struct GemmTnF16Args {
+  const float *P; int ldp;            // [M, ldp]: the operand whose columns index the ROWS of the block (a)
+  const float *Q; int ldq;            // [M, ldq]: ... the COLUMNS of the block (b)
+  float *out; long sa, sb;            // out[a * sa + b * sb] += ...   (dW [N, K]: P = dY gives sa = ldw, sb = 1; P = X gives sa = 1, sb = ldw)
+  float *colsum;                      // += column sums of the GRADIENT operand (the bias gradient), or null
+  int grad_is_p;                      // which operand is the gradient (scaled; its column sums go to colsum)
+  const unsigned *xmax_bits;          // bits of max |gradient operand| (absmax_bits_kernel)
+  long M, mchunk; int gx, nba, nbb;   // rows, rows per workgroup, row chunks, blocks along a / b
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_f16_kernel(GemmTnF16Args a) {
+  constexpr int TILE = 256, COLS = 2 * TILE, PLANE = COLS * 32;          // f16 elements per plane
+  extern __shared__ __attribute__((aligned(16))) unsigned short tn_smem[];     // 2 images x (hi | lo) x 32 KB = 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  // workgroup order: the nba x nbb blocks of one row chunk get ids congruent mod 8 inside a group of 8 nba nbb consecutive ones: same XCD,
+  // about the same time -- the rows they share come out of that L2 (as gemm_tn_block_kernel)
+  const unsigned nb_all = (unsigned)(a.nba * a.nbb), per = 8u * nb_all;
+  const unsigned grp = blockIdx.x / per, within = blockIdx.x - grp * per;
+  const long chunk = (long)grp * 8 + (within & 7u);
+  const int nb = (int)(within >> 3);
+  if (chunk >= a.gx) return;
+  const int ba = nb % a.nba, bb = nb / a.nba;
+  const long m_lo = chunk * a.mchunk, m_hi = min(a.M, m_lo + a.mchunk);
+  float xinv = 1.f;
+  const float xscale = f16_operand_scale(*a.xmax_bits, xinv);
+  // staging task of this thread: 4 consecutive columns x 8 rows of the combined [32 x 512] slab; waves 0, 2, 4, 6 load P, the others Q
+  const int rg = wave >> 1;                                   // row group 0 .. 3 (rows 8 rg .. 8 rg + 7 of the slab)
+  const bool is_p = (wave & 1) == 0;
+  const int c4 = 4 * lane;                                    // first of the 4 columns inside the operand's tile
+  const float *src = is_p ? a.P + (long)ba * TILE + c4 : a.Q + (long)bb * TILE + c4;
+  const int ld = is_p ? a.ldp : a.ldq;
+  const bool is_grad = is_p == (a.grad_is_p != 0);
+  const float sc = is_grad ? xscale : 1.f;
+  const int ccol = (is_p ? 0 : TILE) + c4;                    // column of the LDS image
+  float4 v[8];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load_slab = [&](long m0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long m = m0 + 8 * rg + e;
+      v[e] = m < m_hi ? *reinterpret_cast<const float4 *>(src + m * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_slab = [&](unsigned short *smem) {
+    if (is_grad) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs[0] += v[e].x; cs[1] += v[e].y; cs[2] += v[e].z; cs[3] += v[e].w; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      typedef __attribute__((ext_vector_type(4))) unsigned tn_u32x4;
+      tn_u32x4 h, l;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const float x0 = (q == 0 ? v[2 * e2].x : q == 1 ? v[2 * e2].y : q == 2 ? v[2 * e2].z : v[2 * e2].w) * sc;
+        const float x1 = (q == 0 ? v[2 * e2 + 1].x : q == 1 ? v[2 * e2 + 1].y : q == 2 ? v[2 * e2 + 1].z : v[2 * e2 + 1].w) * sc;
+        unsigned hh, ll;
+        split2_f16(x0, x1, hh, ll);
+        h[e2] = hh; l[e2] = ll;
+      }
+      const int off = gemm_swz(ccol + q, 8 * rg);
+      *reinterpret_cast<tn_u32x4 *>(smem + off) = h;
+      *reinterpret_cast<tn_u32x4 *>(smem + PLANE + off) = l;
+    }
+  };
+  // MFMA tiles of this wave: P tiles 4 wi .. 4 wi + 3 (rows of the block), Q tiles 8 wj .. 8 wj + 7 (columns)
+  const int wi = wave & 3, wj = wave >> 2;
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  load_slab(m_lo);
+  store_slab(tn_smem);
+  __syncthreads();
+  if (m_lo + 32 < m_hi) load_slab(m_lo + 32);
+  int buf = 0;
+  for (long m0 = m_lo; m0 < m_hi; m0 += 32, buf ^= 1) {
+    const unsigned short *smem = tn_smem + buf * 2 * PLANE;
+    gemm_f16x8 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = gemm_swz(64 * wi + 16 * i + fr, 8 * fg);
+      ah[i] = *reinterpret_cast<const gemm_f16x8 *>(smem + off);
+      al[i] = *reinterpret_cast<const gemm_f16x8 *>(smem + PLANE + off);
+    }
+    auto mul = [&](int j) {
+      const int off = gemm_swz(TILE + 128 * wj + 16 * j + fr, 8 * fg);
+      const gemm_f16x8 bh = *reinterpret_cast<const gemm_f16x8 *>(smem + off);
+      const gemm_f16x8 bl = *reinterpret_cast<const gemm_f16x8 *>(smem + PLANE + off);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) mul(j);
+    // the next slab (its loads were issued a slab ago) goes into the other image -- every wave left it at the last barrier --,
+    // then the loads of the slab after it
+    if (m0 + 32 < m_hi) store_slab(tn_smem + (buf ^ 1) * 2 * PLANE);
+    if (m0 + 64 < m_hi) load_slab(m0 + 64);
+#pragma unroll
+    for (int j = 2; j < 8; ++j) mul(j);
+    __syncthreads();
+  }
+  // every element of the block belongs to one lane of one wave: acc[i][j][r] is (a, b) = (64 wi + 16 i + 4 fg + r, 128 wj + 16 j + fr)
+  float *o = a.out + ((long)ba * TILE + 64 * wi + 4 * fg) * a.sa + ((long)bb * TILE + 128 * wj + fr) * a.sb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(o + (long)(16 * i + r) * a.sa + (long)(16 * j) * a.sb, acc[i][j][r] * xinv);
+  // bias gradient: column sums of the gradient operand, once per row chunk (by the blocks with index 0 along the other operand)
+  if (a.colsum && is_grad && (is_p ? bb == 0 : ba == 0)) {
+    float *dst = a.colsum + (long)(is_p ? ba : bb) * TILE + c4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(dst + q, cs[q]);
+  }
+}
+
 // LayerNorm backward (post-norm block): y = LN(u) * w + b.
 //   dU = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dY * w;  dw += dY * xhat;  db += dY
 // One wave per row; per-workgroup partial dw/db through LDS, then one atomic per feature.
@@ -209,7 +345,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                                                             const float *__restrict__ U,
                                                             const float *__restrict__ w, float *__restrict__ dU,
                                                             float *dw, float *db, long rows, int d,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, unsigned *out_absmax = nullptr) {
   extern __shared__ float sm[];   // [2][d]
   float *sdw = sm, *sdb = sm + d;
   for (int i = threadIdx.x; i < 2 * d; i += 256) sm[i] = 0.f;
@@ -217,6 +353,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.x * rows_per_block;
   float pdw[8], pdb[8];
+  unsigned omax = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { pdw[i] = 0.f; pdb[i] = 0.f; }
   for (long row = r0 + wave; row < min(rows, r0 + rows_per_block); row += 4) {
@@ -241,7 +378,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
     }
     const float mg = wave_sum(sg) / d, mgx = wave_sum(sgx) / d;
     n = 0;
-    for (int c = lane; c < d; c += 64, ++n) dU[row * d + c] = rstd * (gy[n] - mg - u[n] * mgx);
+    for (int c = lane; c < d; c += 64, ++n) {
+      const float du = rstd * (gy[n] - mg - u[n] * mgx);
+      dU[row * d + c] = du;
+      omax = max(omax, __float_as_uint(du) & 0x7fffffffu);
+    }
+  }
+  if (out_absmax) {      // max |dU| of this launch: the scale of the F16X3 gradient products that read dU (gemm.h: xmax_bits)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+    if (lane == 0 && omax) atomicMax(out_absmax, omax);
   }
   int n = 0;
   for (int c = lane; c < d; c += 64, ++n) { atomicAdd(&sdw[c], pdw[n]); atomicAdd(&sdb[c], pdb[n]); }

@@ -37,7 +37,39 @@ struct GemmArgs {
   const float *red_w[GEMM_MAX_GROUPS]; const float *red_b[GEMM_MAX_GROUPS]; int red_nout; float *red_out; int red_stride;
   long red_block_stride;
   unsigned *range_flag;            // F16X3: raised when an accumulator is not finite (an operand left f16's range); may be null
+  // F16X3 only, optional: per-tensor power-of-two scaling of the X operand.  *xmax_bits = the bits of max |X| (absmax_bits_kernel);
+  // the kernel multiplies X by 2^k on its way into LDS, k chosen so that the maximum lands in [2^14, 2^15) -- gradients of
+  // 1e-8 .. 1e-5 would otherwise sit in f16's subnormals -- and the epilogue divides by it (exact: powers of two).  Null: no scaling.
+  const unsigned *xmax_bits;
+  // optional: max |Y| of what this launch stores (bits, atomicMax per wave) -- Y is the gradient operand of a following F16X3 product
+  unsigned *out_absmax;
 };
+
+// max |x| over a [rows, cols] matrix of pitch ld, as the bit pattern of the non-negative float (unsigned order = float order; a NaN
+// compares above every finite value and is reported as such): one atomicMax per wave into *out, which the caller zeroed.
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float *__restrict__ x, long rows, int cols, int ld, unsigned *out) {
+  const long n4 = rows * (cols / 4);
+  unsigned m = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (cols / 4);
+    const int c = (int)(i - r * (cols / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4 *>(x + r * ld + c);
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+// the scale 2^k for an operand whose max |x| has the bits `b`: max * 2^k in [2^14, 2^15); 1 for an all-zero or non-finite operand
+// (a non-finite one shows up in the accumulators and raises the range flag there)
+__device__ __forceinline__ float f16_operand_scale(unsigned b, float &inv) {
+  const int e = (int)(b >> 23);                       // biased exponent of max |x|
+  if (b == 0 || e >= 255) { inv = 1.f; return 1.f; }
+  int k = 14 + 127 - e;                               // 2^(e - 127) <= max < 2^(e - 126)
+  k = k > 126 ? 126 : (k < -126 ? -126 : k);
+  inv = __uint_as_float((unsigned)(127 - k) << 23);
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
 
 constexpr int GEMM_BK = 32;
 
@@ -133,6 +165,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
   }
   const int m0 = mb * BM, n0 = nb * BN, grp = blockIdx.z;
   const float *__restrict__ W = a.W[grp];
+  float xscale = 1.f, xinv = 1.f;
+  if constexpr (PREC == 3) {
+    if (a.xmax_bits) xscale = f16_operand_scale(*a.xmax_bits, xinv);
+  }
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -179,7 +215,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int idx = tid + i * 256;
-      lds_store4<PREC>(As, A_ELEMS, idx >> 3, (idx & 7) * 4, av[i]);
+      lds_store4<PREC>(As, A_ELEMS, idx >> 3, (idx & 7) * 4, av[i], xscale);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -272,6 +308,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
   }
   const float *bias = a.bias[grp];
   const float tsc = a.tscalar ? a.tscalar[0] : 0.f;
+  unsigned omax = 0;
   constexpr int C4 = BN / 4, PER_T = RP * C4 / 256;       // float4 per thread and pass (BN = 32: 1, 64: 2, 128: 4)
   static_assert(RP * C4 % 256 == 0, "whole float4 rounds per pass");
 #pragma unroll
@@ -285,7 +322,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            Cs[(rbase % RP + fg * 4 + r) * LDC + wn * WN + 16 * j + fr] = PREC == 3 ? acc[i][j][r] * (1.f / GEMM_F16_WSCALE) : acc[i][j][r];
+            Cs[(rbase % RP + fg * 4 + r) * LDC + wn * WN + 16 * j + fr] = PREC == 3 ? acc[i][j][r] * ((1.f / GEMM_F16_WSCALE) * xinv) : acc[i][j][r];
       }
     }
     __syncthreads();
@@ -350,7 +387,13 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
       float4 *yp = reinterpret_cast<float4 *>(a.Y + dst * a.ldy + grp * a.col_per_group + n);
       if (a.accum) { const float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       *yp = v;
+      omax = max(max(omax, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
     }
+  }
+  if (a.out_absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+    if (lane == 0 && omax) atomicMax(a.out_absmax, omax);
   }
 }
 

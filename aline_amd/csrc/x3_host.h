@@ -101,7 +101,7 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
 #ifdef X3_STAMPS
       la.stamps = want_gmm ? nullptr : reinterpret_cast<unsigned long long *>(c.at(c.pl.xRaw));
 #endif
-      const bool timed = (t == r->T - 1 && last);              // bench.py times this launch of the dominant kernel
+      const bool timed = (t == (r->ev_kernel_step > 0 ? r->ev_kernel_step - 1 : r->T - 1) && last);      // bench.py times this launch of the dominant kernel
       if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
       if (last) hipLaunchKernelGGL(layer_kernel<true>, dim3((unsigned)std::min(la.ngroups, cus)), dim3(THREADS), smem_layer, c.st, la);
       else hipLaunchKernelGGL(layer_kernel<false>, dim3((unsigned)std::min(la.ngroups, cus)), dim3(THREADS), smem_layer, c.st, la);

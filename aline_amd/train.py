@@ -134,8 +134,24 @@ def reinforce_terms(ro, embedding_type, mask_type="all", gamma=1.0, alpha=1.0, b
                 g_ll=g_ll.contiguous(), R=R)
 
 
-def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=24 << 30, grads=None):
+def _default_bwd_ws_bytes(device):
+    """Workspace budget of the per-op backward (which chunks the T steps to fit it): half of the card's memory -- 144 GB of the 288 GB
+    of an MI355X (the d = 256 headline step then runs 10 steps per chunk instead of 2: fewer, longer launches) -- overridable by
+    ALINE_BWD_WS_GB."""
+    import os
+    gb = os.environ.get("ALINE_BWD_WS_GB")
+    if gb:
+        return int(float(gb) * (1 << 30))
+    try:
+        return int(0.5 * torch.cuda.get_device_properties(device).total_memory)
+    except Exception:
+        return 24 << 30
+
+
+def backward(model, ro, g_logp, g_ll, t_chunk=None, max_ws_bytes=None, grads=None):
     """Accumulates dLoss/dW into param.grad of every weight of `model` (C ABI aline_rollout_backward)."""
+    if max_ws_bytes is None:
+        max_ws_bytes = _default_bwd_ws_bytes(ro.device)
     m, r = ro.m, ro.r
     if grads is None:
         grads = _grad_struct(model)

@@ -101,6 +101,42 @@ class HipEvents:
         return float(ms.value)
 
 
+def dominant_kernel_ms(ro, device):
+    """Launch durations of the path's dominant kernel at EVERY step t of a rollout (dict t -> ms): HIP events recorded by the C ABI on
+    the launch stream around that launch (aline_rollout.ev_kernel_start / _stop / _step), one eager rollout per timed step.  The
+    roofline figure pairs the SUM of the algorithmic FLOPs of the timed launches with the SUM of their durations, i.e. the average
+    launch -- what a rocprofv3 --kernel-trace --stats average of the same command measures (profiles/, cross-checked there).
+    Empty when the library never recorded the pair (a path without a dominant kernel)."""
+    ev = HipEvents()
+    ro.r.ev_kernel_start, ro.r.ev_kernel_stop = ev.a, ev.b
+    per = {}
+    try:
+        for t in range(ro.T):
+            ro.r.ev_kernel_step = t + 1
+            ro.refresh_uniform()
+            ro.run()
+            torch.cuda.synchronize(device)
+            ms = ev.elapsed_ms()
+            if ms is None:
+                return {}
+            per[t] = ms
+    finally:
+        ro.r.ev_kernel_start, ro.r.ev_kernel_stop, ro.r.ev_kernel_step = None, None, 0
+    return per
+
+
+def profile_avg_launch_us(csv_name, kernel_prefix):
+    """Average launch duration (us) of a kernel in a committed rocprofv3 --kernel-trace --stats summary (profiles/<csv_name>), or None."""
+    import csv
+    try:
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", csv_name))):
+            if r["Name"].replace("void ", "").startswith(kernel_prefix):
+                return float(r["AverageNs"]) / 1e3
+    except Exception:
+        pass
+    return None
+
+
 def host_cores():
     """Threads this process may really use: min(affinity, cgroup cpu quota)."""
     n = os.cpu_count() or 1
@@ -220,16 +256,8 @@ def measure_d256(args, device, batch, precision, d=256, F=1024, train=True):
         ro.refresh_uniform(); ro.replay()
     e1.record(); torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / steps
-    ev = HipEvents()
-    ro.r.ev_kernel_start, ro.r.ev_kernel_stop = ev.a, ev.b
-    kms = []
-    for _ in range(3):
-        ro.refresh_uniform(); ro.run(); torch.cuda.synchronize(device)
-        k = ev.elapsed_ms()
-        if k is not None:
-            kms.append(k)
-    ro.r.ev_kernel_start, ro.r.ev_kernel_stop = None, None
-    kernel_ms = sum(kms) / len(kms) if kms else None
+    per_step = dominant_kernel_ms(ro, device)                      # the last layer's launch of every step t
+    kernel_ms = sum(per_step.values()) / len(per_step) if per_step else None
     fl_ep = algorithmic_flops_per_episode(2, 1, d, F, H, L, 10, 1, args.n_query, 0, 2, 2, args.T, with_query_gmm=False)
     whole = fl_ep * args.batch / (ms * 1e-3) / 1e12
     out = {"model": f"d={d} F={F} H={H} L={L}", "precision": precision, "ms_per_rollout": ms,
@@ -237,11 +265,10 @@ def measure_d256(args, device, batch, precision, d=256, F=1024, train=True):
            "whole_rollout": {"achieved": whole, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_BF16_DENSE_TFLOPS,
                              "algorithmic_flops_per_rollout": fl_ep * args.batch}}
     if kernel_ms:
-        t = args.T - 1                                             # the events bracket the last layer of the last step
         passes = 3 if precision == "f16x3" else 1
         kname = ro.kernel_name
-        if precision == "f16x3":
-            per_launch = x3_layer_flops(d, F, 1 + t, args.n_query - t, 2, 2) * args.batch
+        if precision == "f16x3":           # average launch: the timed launches' algorithmic FLOPs / their durations
+            per_launch = sum(x3_layer_flops(d, F, 1 + t, args.n_query - t, 2, 2) for t in per_step) / len(per_step) * args.batch
         else:
             fl_all = fused_kernel_flops_per_episode(d, F, L, 1, args.n_query, 2, 2, args.T)
             per_launch = fl_all / args.T * args.batch
@@ -251,8 +278,9 @@ def measure_d256(args, device, batch, precision, d=256, F=1024, train=True):
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_DENSE_TFLOPS, "mfma_passes_per_product": passes,
                            "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / passes,
                            "frac_vs_instruction_mix_peak": ach * passes / PEAK_BF16_DENSE_TFLOPS,
-                           **profile_traffic("r03_x3_f16x3_d256_pmc_traffic.json" if precision == "f16x3" and (d, F) == (256, 1024) else None,
-                                             args.batch == 1000 and args.T == 30 and args.n_query == 200),
+                           "timed_launches": len(per_step),
+                           **profile_traffic(("x3_f16x3_d256_pmc_traffic.json" if (d, F) == (256, 1024) else "x5_f16x3_d512_pmc_traffic.json" if (d, F) == (512, 128) else None)
+                                             if precision == "f16x3" else None, args.batch == 1000 and args.T == 30 and args.n_query == 200),
                            "peak_note": "dense f16/bf16 MFMA peak (MI355X_MICROARCH.md).  A reference-precision product costs "
                                         "3 MFMA passes (hi*hi + hi*lo + lo*hi), so the pipe can deliver at most peak / 3 of "
                                         "algorithmic FLOP/s in this mode: instruction_mix_peak; frac_vs_instruction_mix_peak is "
@@ -280,13 +308,56 @@ def profile_traffic(fname, same_shape):
     profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md; collected by tools/pmc_*.sh on the same kernel and shape,
     not re-measured inside bench.py: PMC collection serialises the kernels).  null when the shape differs or no profile exists."""
     if fname and same_shape:
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", fname)))
-            return {"traffic": tr["hbm_bytes_per_launch"],
-                    "traffic_source": f"rocprofv3 PMC passes of this kernel at this shape (profiles/{fname}); not re-measured in this run"}
-        except Exception:
-            pass
+        for rnd in ("r04_", "r03_", "r02_", ""):       # the newest round's collection (tools/collect_r04.sh writes the r04_ files) first
+            cand = fname if fname.startswith(("r0", "r1")) else rnd + fname
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                return {"traffic": tr["hbm_bytes_per_launch"],
+                        "traffic_source": f"rocprofv3 PMC passes of this kernel at this shape, average launch (profiles/{cand}, written by the "
+                                          f"collection script that also ran this bench command: tools/collect_r04.sh); PMC collection serialises "
+                                          f"the kernels, so it is a separate pass, not this run"}
+            except Exception:
+                pass
     return {"traffic": None, "traffic_source": "no PMC profile of this kernel at this shape under profiles/"}
+
+
+def measure_eig(device, n=10):
+    """Sub-measurement (not `value`): the sequential-EIG step kernels (loss/eig.py:174-209 through the task likelihoods,
+    tasks/location_finding.py:110-164, tasks/ces.py:169-210) at the README evaluation sizes -- location finding L = 1e6 contrastive
+    samples x B = 200, CES L = 1e6 x B = 20 (BASELINE configs[3]).  HBM-bound: algorithmic bytes per (l, b) and step =
+    theta read (dim_theta x 4 B) + the running log-likelihood sum S read + written (8 B); the logsumexp finalisation reads S (4 B)."""
+    from aline_amd.loss.eig import EIGStepLoss
+    from aline_amd.tasks import CESTask, HiddenLocation
+    out = {"peak": PEAK_HBM_GBS, "unit": "GB/s", "bound": "hbm"}
+    for name, task, L, B, dth in (("location", HiddenLocation(device=device), 1_000_000, 200, 2), ("ces", CESTask(device=device), 1_000_000, 20, 5)):
+        torch.manual_seed(0)
+        if name == "location":
+            theta = torch.rand(L + 1, B, 1, 2, device=device)
+            xi, y = torch.rand(B, 2, device=device), torch.randn(B, 1, device=device)
+        else:
+            theta = torch.stack([0.01 + 0.99 * torch.rand(L + 1, B, device=device), *(torch.rand(3, L + 1, B, device=device) / 3 + 0.1),
+                                 torch.randn(L + 1, B, device=device)], -1).contiguous()
+            xi, y = torch.rand(B, 6, device=device) * 100, torch.rand(B, 1, device=device) * 0.9 + 0.05
+        crit = EIGStepLoss(L, B, task, device=device)
+        for _ in range(2):
+            crit.step(y, xi, theta)
+        torch.cuda.synchronize(device)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(n):
+            crit.step(y, xi, theta)
+        e1.record()
+        for _ in range(n):
+            crit.forward(y, xi, theta)
+        e2.record()
+        torch.cuda.synchronize(device)
+        dt, dtf = e0.elapsed_time(e1) / n * 1e-3, max(e1.elapsed_time(e2) - e0.elapsed_time(e1), 1e-6) / n * 1e-3
+        step_bytes = (L + 1) * B * (dth * 4 + 8)
+        out[name] = {"L": L, "B": B, "step_ms": dt * 1e3, "algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / dt / 1e9,
+                     "frac": step_bytes / dt / 1e9 / PEAK_HBM_GBS, "finalize_ms": dtf * 1e3, "finalize_GBps": (L + 1) * B * 4 / dtf / 1e9}
+        del theta, crit
+        torch.cuda.empty_cache()
+    return out
 
 
 def measure_alt(args, device, batch, precision):
@@ -365,6 +436,7 @@ def main():
                          "so that the K timed steps run at the clock / cache state of a job in progress (0 = none)")
     ap.add_argument("--no-d256", action="store_true", help="skip the d_model = 256 sub-measurement (N = 1 only)")
     ap.add_argument("--no-d512", action="store_true", help="skip the d_model = 512 / F = 128 sub-measurement (N = 1 only)")
+    ap.add_argument("--no-eig", action="store_true", help="skip the sequential-EIG kernels' HBM-roofline sub-measurement (N = 1 only)")
     ap.add_argument("--no-query-gmm", action="store_true", help="skip the value_with_query_gmm figure")
     ap.add_argument("--d256-precs", default="f16x3", help="arithmetic modes of the d_model = 256 sub-measurement (comma separated)")
     args = ap.parse_args()
@@ -494,22 +566,11 @@ def main():
     # dominant kernel: HIP events recorded by the C ABI on the launch stream around the fused rollout
     # kernel, in an eager leg of the same process right after the timed region (same inputs, same
     # launches; the graph replays above launch exactly this kernel)
-    ev = HipEvents()
-    ro.r.ev_kernel_start, ro.r.ev_kernel_stop = ev.a, ev.b
-    kms = []
     path = ro.path
-    has_kernel_events = path != "generic pipeline"
-    for _ in range(max(3, args.steps) if has_kernel_events else 0):
-        ro.refresh_uniform()
-        ro.run()
-        torch.cuda.synchronize(device)
-        ms = ev.elapsed_ms()
-        if ms is None:
-            kms = []
-            break
-        kms.append(ms)
-    ro.r.ev_kernel_start, ro.r.ev_kernel_stop = None, None
-    kernel_ms = sum(kms) / len(kms) if kms else 0.0
+    per_step = dominant_kernel_ms(ro, device) if path != "generic pipeline" else {}
+    if path == "fused::rollout_f32_kernel" and per_step:      # (one launch per rollout: every "step" timed the same launch)
+        per_step = {0: sum(per_step.values()) / len(per_step)}
+    kernel_ms = sum(per_step.values()) / len(per_step) if per_step else 0.0
     fl_ep = algorithmic_flops_per_episode(2, 1, args.d_model, args.d_ff, args.heads, args.layers, 10,
                                           1, args.n_query, 0, 2, 2, args.T, with_query_gmm=False)
     fused = path == "fused::rollout_f32_kernel" and kernel_ms > 0.0
@@ -543,12 +604,11 @@ def main():
             traffic = None
     elif x3:
         # dominant kernel of the x3 path: x3::layer_kernel -- one launch = one encoder layer of one step for all B episodes
-        # (L * T launches per rollout); the events bracket the last layer of the last step
-        t = args.T - 1
-        per_launch = x3_layer_flops(args.d_model, args.d_ff, 1 + t, args.n_query - t, 2, 2) * args.batch
+        # (L * T launches per rollout); the events bracket the last layer of every step in turn: average launch
+        per_launch = sum(x3_layer_flops(args.d_model, args.d_ff, 1 + t, args.n_query - t, 2, 2) for t in per_step) / len(per_step) * args.batch
         achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
         kname, peak = ro.kernel_name, PEAK_BF16_DENSE_TFLOPS
-        tr = profile_traffic("r03_x3_f16x3_d256_pmc_traffic.json", args.batch == 1000 and args.T == 30 and args.n_query == 200 and args.d_ff == 1024)
+        tr = profile_traffic("x3_f16x3_d256_pmc_traffic.json", args.batch == 1000 and args.T == 30 and args.n_query == 200 and args.d_ff == 1024)
         traffic = tr["traffic"]
         extra = {"traffic_source": tr["traffic_source"], "launches_per_rollout": args.T * args.layers, "mfma_passes_per_product": 3,
                  "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / 3,
@@ -559,14 +619,19 @@ def main():
                               "peak / 3 in this mode (instruction_mix_peak); frac_vs_instruction_mix_peak = matrix-pipe utilisation"}
     elif s3:
         # dominant kernel of the s3 path: s3::step_kernel -- one launch = every encoder layer + the acquisition logits of ONE
-        # design step for all B episodes (T launches per rollout); the events bracket the launch of the last step
+        # design step for all B episodes (T launches per rollout); the events bracket the launch of every step in turn, and the
+        # figure pairs the AVERAGE launch's algorithmic FLOPs (all T launches / T) with the average of the T durations
         fl_all = fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2, args.T)
-        fl_last = fl_all - fused_kernel_flops_per_episode(args.d_model, args.d_ff, args.layers, 1, args.n_query, 2, 2,
-                                                          args.T - 1)
-        per_launch = fl_last * args.batch
+        per_launch = fl_all / args.T * args.batch
         achieved_tflops = per_launch / (kernel_ms * 1e-3) / 1e12
         kname, peak, traffic = ro.kernel_name, PEAK_BF16_DENSE_TFLOPS, None
-        extra = {"launches_per_rollout": args.T, "mfma_passes_per_product": 3,
+        prof_us = profile_avg_launch_us("r04_bench_kernel_stats.csv", "s3::step_kernel") if args.batch == 1000 and args.T == 30 and args.n_query == 200 else None
+        extra = {"launches_per_rollout": args.T, "timed_launches": len(per_step), "mfma_passes_per_product": 3,
+                 "kernel_us_first_last_step": [per_step[0] * 1e3, per_step[args.T - 1] * 1e3],
+                 # the same figure from the committed rocprofv3 --kernel-trace --stats summary of this command (graph launches: no
+                 # eager-dispatch gap inside the event pair), when one exists for this shape
+                 "profile_avg_launch_us": prof_us,
+                 "frac_from_profile_avg": (per_launch / (prof_us * 1e-6) / 1e12 / PEAK_BF16_DENSE_TFLOPS) if prof_us else None,
                  "instruction_mix_peak": PEAK_BF16_DENSE_TFLOPS / 3,
                  "frac_vs_instruction_mix_peak": achieved_tflops * 3 / PEAK_BF16_DENSE_TFLOPS,
                  "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
@@ -578,8 +643,7 @@ def main():
                               "precision): the pipe can deliver at most peak / 3 in this mode (instruction_mix_peak).  "
                               "achieved_vs_fp32_mfma_peak: the same fp32-grade FLOP rate against the 157 TFLOP/s of the fp32 "
                               "matrix pipe, the roof of round 1's kernel for this workload"}
-        tr = profile_traffic("r03_s3_f16x3_d32_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_s3_f16x3_d32_pmc_traffic.json"))
-                             else "r02_s3_f16x3_d32_pmc_traffic.json", args.batch == 1000 and args.T == 30 and args.n_query == 200)
+        tr = profile_traffic("s3_f16x3_d32_pmc_traffic.json", args.batch == 1000 and args.T == 30 and args.n_query == 200)
         traffic = tr["traffic"]
         extra["traffic_source"] = tr["traffic_source"]
     else:   # generic pipeline: many kernels per step; report the whole graph as a lower bound
@@ -673,6 +737,12 @@ def main():
     if world == 1 and not args.no_d512 and args.d_model != 512:
         out["d512"] = {"f16x3": measure_d256(args, device, batch, "f16x3", d=512, F=128, train=False)}
         log(f"d512 [f16x3]: {out['d512']['f16x3']['ms_per_rollout']:.2f} ms per rollout ({out['d512']['f16x3']['roofline']['kernel']})")
+    if world == 1 and not args.no_eig:
+        try:
+            out["eig"] = measure_eig(device)
+            log(f"eig step kernels: location {out['eig']['location']['frac']:.2f}, ces {out['eig']['ces']['frac']:.2f} of the HBM peak")
+        except Exception as e:      # a secondary leg must not take the headline line with it
+            out["eig"] = {"error": repr(e)}
     if dist is not None:          # every collective is behind us: the ranks part here, rank 0 goes on to the CPU baseline
         dist.barrier()
         dist.destroy_process_group()

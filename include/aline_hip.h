@@ -146,6 +146,9 @@ typedef struct aline_rollout {
    * backward; the caller passes the struct the forward ran with).  aline_rollout_saved_acts_bytes sizes it (0: this (m, r) cannot
    * use it).  NULL: the backward recomputes. */
   float *saved_acts;
+  /* Which launch of the dominant kernel the ev_kernel_* pair brackets: 0 = the one of the last step (t = T - 1; the default),
+   * k > 0 = the one of step t = k - 1 (bench.py walks all T steps for the AVERAGE launch duration its roofline figure uses). */
+  int32_t ev_kernel_step;
 } aline_rollout;
 
 /* ABI / build info. */
@@ -311,7 +314,8 @@ enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off 
        ALINE_DBG_NO_BWD_GMM_WIDE = 1u << 26,   /* GMM head backward at F > 128: the per-row-atomics kernel instead of gmm_bwd_wide_kernel */
        ALINE_DBG_NO_BWD_SAVED_ACTS = 1u << 27,  /* backward: recompute the layers even when aline_rollout.saved_acts is given */
        ALINE_DBG_BWD_RECOMPUTE_F32 = 1u << 28,  /* per-op backward of an F16X3 model: forward recompute GEMMs in exact fp32 too */
-       ALINE_DBG_BWD_DW_TK2 = 1u << 29 };       /* weight-gradient products: 32 (not 64) columns of the narrow operand per workgroup */
+       ALINE_DBG_BWD_DW_TK2 = 1u << 29,         /* weight-gradient products: 32 (not 64) columns of the narrow operand per workgroup */
+       ALINE_DBG_BWD_GRAD_F32 = 1u << 30 };     /* per-op backward of an F16X3 model: gradient products (dX, dW) in exact fp32 instead of the scaled f16 split */
 uint32_t aline_debug_set_flags(uint32_t flags);
 uint32_t aline_debug_get_flags(void);
 /* Integer knobs of the same kind (0 = automatic): launch shape of the s3 step kernel, precision of the backward GEMMs. */

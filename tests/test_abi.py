@@ -118,7 +118,7 @@ int main(void) {{
   printf("%zu %zu %zu\\n", offsetof(aline_step, select_mode), offsetof(aline_step, idx),
          offsetof(aline_step, encoding));
   printf("%zu %zu %zu %zu\\n", offsetof(aline_rollout, select_mode), offsetof(aline_rollout, time_token_T),
-         offsetof(aline_rollout, ev_kernel_stop), offsetof(aline_rollout, postq_weight));
+         offsetof(aline_rollout, ev_kernel_stop), offsetof(aline_rollout, ev_kernel_step));
   return 0;
 }}''')
     exe = tmp_path / "layout"
@@ -129,7 +129,7 @@ int main(void) {{
     exp = [ctypes.sizeof(M), ctypes.sizeof(S), ctypes.sizeof(R),
            M.x_w1.offset, M.in_proj_w.offset, M.acq_w1.offset, M.gmm_b2.offset,
            S.select_mode.offset, S.idx.offset, S.encoding.offset,
-           R.select_mode.offset, R.time_token_T.offset, R.ev_kernel_stop.offset, R.postq_weight.offset]
+           R.select_mode.offset, R.time_token_T.offset, R.ev_kernel_stop.offset, R.ev_kernel_step.offset]
     assert got == exp
 
 
