@@ -397,6 +397,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
   }
 }
 
+// (Round 4 measured a 256 x 256-block variant of this product -- 8 waves, wave tiles of 64 x 128, two LDS images, one barrier per
+//  k-step: the structure of gemm_tn_f16_kernel in backward.h -- against this kernel on the d = 256 training step: 765 ms with it on
+//  every eligible GEMM, 738 ms with it on the K >= 512 ones only, 712 - 719 ms without it.  One workgroup of 8 waves per CU whose
+//  waves meet at a barrier every 768 MFMAs loses to three independent 4-wave workgroups at K = 256 .. 1024 (8 .. 32 k-steps per
+//  block: prologue and the strided epilogue are not amortised as they are over the 100+ slabs of a weight-gradient block).  Not kept.)
+
 // column blocks per output row for N outputs (tile width 128 / 64 / 32 by divisibility): a fused second layer
 // (red_*) leaves that many partial sums per output
 static inline int gemm_col_blocks(int N) { return N / (N % 128 == 0 ? 128 : N % 64 == 0 ? 64 : 32); }
