@@ -305,6 +305,124 @@ __global__ __launch_bounds__(256) void eig_lse_combine_kernel(const float *__res
 }
 
 
+// ---- all T steps of a design history in ONE pass over theta (round 4) --------------------------------------------------------------
+// compute_EIG_from_history (utils/eval.py:42-80) calls the step T times: every call reads theta (dim_theta x 4 B per (l, b)) and reads and
+// writes the running sum S (8 B), and -- stepwise -- a logsumexp pass reads S again: 20 B per (l, b) and step, 3.2 - 4 GB per step at
+// L = 1e6, B = 200.  The steps of a history are known up front, so one kernel reads theta ONCE, walks the T designs of its episode
+// (xi, y of its episode from L1), carries S in a register and keeps one online (max, sum-exp) pair per step:
+// 8 B per (l, b) for all T steps, the bound moves from HBM to the transcendental units (1 log + 1.25 exp + 1 rcp per (l, b, t)).
+// part[chunk x row group][t][b] = (m, s) over that group's rows l >= 1;  s0[t][b] = S_t of row l = 0 (the "true" theta).
+template <int K1D2>
+__global__ __launch_bounds__(256) void eig_location_history_kernel(const float *__restrict__ theta, const float *__restrict__ xi,
+                                                                   const float *__restrict__ y, long L1, int B, int T, int K, int D,
+                                                                   float noise, float base, float msig, long chunk,
+                                                                   float *__restrict__ part, float *__restrict__ s0) {
+  // A thread owns column b and the rows l0 + ty, l0 + ty + rows, ... of its chunk; the (max, sum-exp) pairs of up to 32 steps live in
+  // its registers (static indices: the step loop is unrolled), the designs / outcomes of its episode come from L1 (T x 12 B per
+  // episode, the same addresses for every row).  No LDS, no barrier: occupancy is set by the ~110 registers alone.  (First version:
+  // accumulators and designs in LDS, 133 KB per workgroup = one wave per SIMD: 13.2 ms at L = 1e6, B = 200, T = 30, latency-bound.)
+  const int cols = min(B, 256), rows = 256 / cols;
+  const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+  const int b = blockIdx.y * cols + tx;
+  if (b >= B || ty >= rows) return;
+  const float inv2n2 = 1.f / (2.f * noise * noise), cst = logf(noise) + LOG_SQRT_2PI;
+  const long l0 = 1 + (long)blockIdx.x * chunk, l1 = min(L1, l0 + chunk);
+  // xi [T, D, B], y [T, B]: step-major, so the lanes of a wave (consecutive episodes b) read consecutive addresses (episode-major
+  // [B, T, D] made every lane touch its own cache line twice per step: 9.9 ms instead of the issue-bound time)
+  const float *xb = xi + b, *yb = y + b;
+  auto ll_of = [&](const float *th, const float *x, float yv) -> float {
+    float inv_sum = 0.f;
+    for (int k = 0; k < (K1D2 ? 1 : K); ++k) {
+      float sq = 0.f;
+      for (int d = 0; d < (K1D2 ? 2 : D); ++d) { const float df = x[d] - th[k * D + d]; sq = fmaf(df, df, sq); }
+      inv_sum += __builtin_amdgcn_rcpf(msig + sq);      // (v_rcp_f32, 1 ulp: the IEEE division sequence is 10 instructions)
+    }
+    // v_log_f32 (log2, 1 ulp) x ln 2 instead of the ~20-instruction logf: the kernel is bound by instruction issue, and the bounds
+    // agree with the step kernels' (logf, IEEE division) to 1e-5 at L = 1e5 .. 1e6 (tests/test_r4_gpu.py)
+    const float z = yv - __log2f(base + inv_sum) * 0.69314718055994530942f;
+    return -(z * z) * inv2n2 - cst;
+  };
+  auto load_x = [&](int t, float *x) {
+    for (int d = 0; d < (K1D2 ? 2 : D); ++d) x[d] = xb[((size_t)t * D + d) * B];
+  };
+  auto load_theta = [&](long l, float *th) {
+    if (K1D2) { const float2 t2 = reinterpret_cast<const float2 *>(theta)[l * B + b]; th[0] = t2.x; th[1] = t2.y; }
+    else for (int e = 0; e < K * D; ++e) th[e] = theta[(l * B + b) * K * D + e];
+  };
+  if (blockIdx.x == 0 && ty == 0) {            // row l = 0 (the true theta): its running sums go to s0, not into the logsumexp over l >= 1
+    float th[8], x[8];
+    load_theta(0, th);
+    float S = 0.f;
+    for (int t = 0; t < T; ++t) { load_x(t, x); S += ll_of(th, x, yb[(size_t)t * B]); s0[(size_t)t * B + b] = S; }
+  }
+  constexpr int TM = 32;                       // steps per register block (T <= 32: one pass over theta; longer histories: one per 32 steps)
+  for (int t0 = 0; t0 < T; t0 += TM) {
+    const int nt = min(TM, T - t0);
+    float m[TM], sacc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { m[t] = -INFINITY; sacc[t] = 0.f; }
+    // four rows of theta per thread and pass: four independent S chains, one rescale of the step's (max, sum) per group
+    long l = l0 + ty;
+    const long r1 = rows;
+    for (; l < l1; l += 4 * r1) {
+      float th[4][8], S[4] = {0.f, 0.f, 0.f, 0.f};
+      bool on[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { on[q] = l + q * r1 < l1; load_theta(on[q] ? l + q * r1 : l, th[q]); }
+      for (int t = 0; t < t0; ++t) {           // (second and later passes: the steps before t0 only advance S)
+        float x[8];
+        load_x(t, x);
+        const float yv = yb[(size_t)t * B];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[q] += ll_of(th[q], x, yv);
+      }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (t < nt) {
+          float x[8];
+          load_x(t0 + t, x);
+          const float yv = yb[(size_t)(t0 + t) * B];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { S[q] += ll_of(th[q], x, yv); if (!on[q]) S[q] = -INFINITY; }
+          const float mn = fmaxf(fmaxf(m[t], fmaxf(S[0], S[1])), fmaxf(S[2], S[3]));      // (S[0] is always a live row: finite)
+          sacc[t] = sacc[t] * __expf(m[t] - mn) + ((__expf(S[0] - mn) + __expf(S[1] - mn)) + (__expf(S[2] - mn) + __expf(S[3] - mn)));
+          m[t] = mn;
+          asm volatile("" ::: "memory");       // (keeps the loads of step t + 1 behind step t: hoisted, they cost 150 registers)
+        }
+      }
+    }
+    // every (chunk, row group) writes its own partial: part[(chunk * rows + ty)][t][b]
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+      if (t < nt) {
+        float *pp = part + ((((size_t)blockIdx.x * rows + ty) * T + (t0 + t)) * B + b) * 2;
+        pp[0] = m[t]; pp[1] = sacc[t];
+      }
+  }
+}
+// combine the chunks: one thread per (t, b); bounds of utils/eval.py:77-78 per step
+__global__ __launch_bounds__(256) void eig_history_combine_kernel(const float *__restrict__ part, const float *__restrict__ s0, int nchunk,
+                                                                  long L1, int B, int T, float *pce, float *nmc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)T * B) return;
+  const int t = (int)(i / B), b = (int)(i % B);
+  float m = -INFINITY, s = 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    const float *pp = part + (((size_t)c * T + t) * B + b) * 2;
+    const float m2 = pp[0], s2 = pp[1];
+    const float mn = fmaxf(m, m2);
+    if (mn != -INFINITY) s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+  }
+  const float sv = s0[(size_t)t * B + b];
+  const float lse1 = m + logf(s);                 // l >= 1
+  const float mx = fmaxf(lse1, sv);
+  const float lse0 = mx + logf(__expf(lse1 - mx) + __expf(sv - mx));   // l >= 0
+  const float L = (float)(L1 - 1);
+  if (pce) pce[(size_t)b * T + t] = logf(L + 1.f) - (lse0 - sv);      // [B, T] as torch.stack(..., dim=-1)
+  if (nmc) nmc[(size_t)b * T + t] = logf(L) - (lse1 - sv);
+}
+
 // ---- batched Cholesky for the GP task sampler (tasks/gaussian_process.py:391-415) ------
 // A = U^T U, U upper triangular, in place on the upper triangle of each [n, n] matrix (the strict lower
 // triangle is zeroed).  One workgroup per matrix, left-looking by rows of U:

@@ -58,6 +58,25 @@ class HiddenLocation(Task):
             self.noise_scale, self.base_signal, self.max_signal, _lib.stream_ptr(S.device)),
             "eig_location_step")
 
+    _hist_ws = _lib.Workspace()
+
+    def native_eig_history(self, thetas, x, y):
+        """Stepwise sPCE / sNMC bounds of a whole design history in ONE pass over the contrastive samples (C ABI
+        aline_eig_location_history): thetas [L + 1, B, K, D] with row 0 the true parameter, x [B, T, D] unnormalised designs in
+        order of acquisition, y [B, T(, 1)] -> (pce [B, T], nmc [B, T]) = what utils/eval.py:64-78 returns with stepwise=True."""
+        L1, B = thetas.shape[0], thetas.shape[1]
+        T = x.shape[1]
+        th = _lib.f32(thetas)
+        xx = _lib.f32(x).reshape(B, T, -1).permute(1, 2, 0).contiguous()          # [T, D, B]: step-major for the kernel
+        yy = _lib.f32(y).reshape(B, T).t().contiguous()                            # [T, B]
+        pce, nmc = torch.empty(B, T, device=th.device), torch.empty(B, T, device=th.device)
+        nb = _lib.lib.aline_eig_history_workspace_bytes(L1, B, T)
+        ws = self._hist_ws.get(nb, th.device)
+        _lib.check(_lib.lib.aline_eig_location_history(th.data_ptr(), xx.data_ptr(), yy.data_ptr(), L1, B, T, self.K, self.dim_x,
+                                                       self.noise_scale, self.base_signal, self.max_signal, pce.data_ptr(), nmc.data_ptr(),
+                                                       ws.data_ptr(), ws.numel(), _lib.stream_ptr(th.device)), "eig_location_history")
+        return pce, nmc
+
     @torch.no_grad()
     def sample_batch(self, batch_size, with_query=True):
         theta = self.sample_theta(batch_size)

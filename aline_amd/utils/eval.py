@@ -44,14 +44,19 @@ def get_traces(model, experiment, T=30, batch_size=40, time_token=False):
 
 
 @torch.no_grad()
-def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=40, stepwise=False, thetas=None):
+def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=40, stepwise=False, thetas=None, fused=True):
     """sPCE / sNMC bounds from a design history (eval.py:42-80).  `thetas` [L, B, ...] replaces the contrastive draw of
-    eval.py:61 (tests pin the function to the reference's bounds on the reference's own draw)."""
+    eval.py:61 (tests pin the function to the reference's bounds on the reference's own draw).  fused=False: the reference's own
+    structure, one `EIGStepLoss` step per design (what tasks without a whole-history kernel use)."""
     T = x.shape[1]
-    criterion = EIGStepLoss(L, batch_size, experiment, reduction="none", device=x.device)
     if thetas is None:
         thetas = experiment.sample_theta((L, batch_size))
     thetas = torch.concat([theta_0.unsqueeze(0), thetas], dim=0).contiguous()
+    if fused and hasattr(experiment, "native_eig_history"):
+        # all T steps in one pass over thetas (the T step launches read thetas and the running sums T times: eig.h)
+        pce, nmc = experiment.native_eig_history(thetas, x, y)
+        return (pce, nmc) if stepwise else (pce[:, -1], nmc[:, -1])
+    criterion = EIGStepLoss(L, batch_size, experiment, reduction="none", device=x.device)
     pce_l, nmc_l = [], []
     for t in range(T):
         last = t == T - 1

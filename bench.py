@@ -355,6 +355,28 @@ def measure_eig(device, n=10):
         step_bytes = (L + 1) * B * (dth * 4 + 8)
         out[name] = {"L": L, "B": B, "step_ms": dt * 1e3, "algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / dt / 1e9,
                      "frac": step_bytes / dt / 1e9 / PEAK_HBM_GBS, "finalize_ms": dtf * 1e3, "finalize_GBps": (L + 1) * B * 4 / dtf / 1e9}
+        if name == "location":
+            # the whole history of T = 30 designs: T step + logsumexp launches (the reference's structure) against ONE pass over theta
+            # (aline_eig_location_history, round 4).  Algorithmic bytes of the fused pass: theta once (8 B per (l, b)).
+            from aline_amd.utils import compute_EIG_from_history
+            T = 30
+            xs, ys = torch.rand(B, T, 2, device=device), torch.randn(B, T, 1, device=device)
+            th0, thl = theta[0], theta[1:]
+            res = {}
+            for fused in (True, False):
+                compute_EIG_from_history(task, th0, xs, ys, L=L, batch_size=B, stepwise=True, thetas=thl, fused=fused)
+                torch.cuda.synchronize(device)
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                f0.record()
+                for _ in range(3):
+                    compute_EIG_from_history(task, th0, xs, ys, L=L, batch_size=B, stepwise=True, thetas=thl, fused=fused)
+                f1.record()
+                torch.cuda.synchronize(device)
+                res[fused] = f0.elapsed_time(f1) / 3
+            out["location_history"] = {"T": T, "L": L, "B": B, "fused_ms": res[True], "stepwise_ms": res[False], "speedup": res[False] / res[True],
+                                       "fused_algorithmic_bytes": (L + 1) * B * 8, "fused_GBps": (L + 1) * B * 8 / (res[True] * 1e-3) / 1e9,
+                                       "note": "fused: one pass over theta for all T steps (bound: transcendental units, not HBM); stepwise: "
+                                               "T x (step kernel + streaming logsumexp), 20 B per (l, b) and step"}
         del theta, crit
         torch.cuda.empty_cache()
     return out

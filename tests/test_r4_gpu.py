@@ -140,3 +140,27 @@ def test_bench_runs_its_rccl_branch_in_a_world_of_one():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["config"]["backend"] == "nccl" and j["config"]["forced_world_of_one"] is True
     assert j["train_step"]["rccl_allreduce_per_step"] == 1.0 and j["train_step"]["collective"].startswith("1 all-reduce")
+
+
+@pytest.mark.parametrize("B,L,T,K", [(200, 120_000, 31, 1), (20, 300_000, 11, 1), (7, 5_000, 36, 1), (33, 20_000, 6, 2)])
+def test_fused_eig_history_equals_the_step_by_step_bounds(B, L, T, K):
+    """`aline_eig_location_history` (all T steps of a design history in one pass over the contrastive samples, eig.h) against the
+    reference's own structure -- one `EIGStepLoss` step + logsumexp per design (loss/eig.py:174-209, utils/eval.py:64-78) on the step
+    kernels -- on the same draw: stepwise sPCE / sNMC of every step.  Shapes: the evaluation protocol's outer batch of 200 and of 20
+    (several row groups per workgroup), a history longer than 32 steps, K = 2 sources (the general likelihood loop).  The fixture
+    test test_compute_eig_from_history_on_reference_draw holds the same entry point to the reference's bounds."""
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd.utils import compute_EIG_from_history
+    torch.manual_seed(B + T)
+    task = HiddenLocation(K=K, n_target_theta=2 * K, device=torch.device("cuda"))
+    theta0 = task.sample_theta(B)
+    x = torch.rand(B, T, 2, device="cuda")
+    y = torch.stack([task.forward(x[:, t], theta0) for t in range(T)], 1)
+    thetas = task.sample_theta((L, B))
+    pf, nf = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=True, thetas=thetas)
+    ps, ns = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=True, thetas=thetas, fused=False)
+    assert pf.shape == ps.shape == (B, T)
+    assert torch.isfinite(pf).all() and torch.isfinite(nf).all()
+    assert maxdiff(pf, ps.cpu()) < 2e-4 and maxdiff(nf, ns.cpu()) < 2e-4, (maxdiff(pf, ps.cpu()), maxdiff(nf, ns.cpu()))
+    p1, n1 = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=False, thetas=thetas)
+    assert maxdiff(p1, ps[:, -1].cpu()) < 2e-4 and maxdiff(n1, ns[:, -1].cpu()) < 2e-4
