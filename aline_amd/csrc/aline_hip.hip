@@ -50,7 +50,7 @@ constexpr size_t kGmmChunkRows = 32768;   // rows per post-loop GMM chunk (hidde
 
 // Workspace plan (offsets in floats).  One plan serves the step API and the rollout API.
 struct Plan {
-  size_t Flag, xKX, xKpos, Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
+  size_t Flag, xKX, xKpos, Ex, Ey, Hid, X, X1, QKV, A, Tm, Wacq, scalar, Wpack, Stamps, Ztg, xImg, xIn, xA, xB, xKV, xKeys, xKcnt, xLog, xZimg, xRaw, xRawQ, sImg, sX0, sXW, sLog, sZimg, sZq, sRaw, KeyIdx, Kcnt, X0, total;
   int qgmm_chunk;  // episodes per query-GMM chunk
 };
 
@@ -102,6 +102,7 @@ Plan make_plan(const aline_model &m, int B, int P, int n_td, int ey_rows, bool q
     p.xLog = take((size_t)B * tpe * 16);
     p.xZimg = take(pieces(((long)T * B * n_t + 15) / 16));
     p.xRaw = take((size_t)T * B * n_t * kRawStride);
+    p.xRawQ = take(query_gmm ? (size_t)B * tpe * 16 * kRawStride : 0);       // raw GMM outputs of every token row of ONE step (posterior_out_query)
   }
   if (T > 0 && m.d == s3::D && m.precision == ALINE_PREC_F16X3) {           // s3 path (s3.h): d = 32 split-f16 tile images
     const size_t tpe = (N + 15) / 16, img = (size_t)s3::img_pieces((long)B * tpe) * 4;

@@ -27,10 +27,20 @@ struct GmmRawArgs {
   long value_row0;
   float *ll;                                     // [rows] or null
   unsigned *range_flag;                          // f16 range guard (common.h): raised when a log-likelihood is not finite; may be null
+  // optional row map of the outputs: raw row i is token row i % map_np of episode i / map_np of a tile image; rows >= map_p (targets,
+  // padding) are skipped, the others go to output row out_row0 + episode * map_p + token row (posterior_out_query by slot)
+  int map_np, map_p; long out_row0;
 };
 __global__ void gmm_raw_finish_kernel(GmmRawArgs a) {
   const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= a.rows) return;
+  long orow = row;
+  if (a.map_np > 0) {
+    const long ep = row / a.map_np;
+    const int tr = (int)(row - ep * a.map_np);
+    if (tr >= a.map_p) return;
+    orow = a.out_row0 + ep * a.map_p + tr;
+  }
   float r[48];
   for (int e = 0; e < 3 * a.C; ++e) {
     float s = a.raw[row * a.raw_stride + e];
@@ -45,9 +55,9 @@ __global__ void gmm_raw_finish_kernel(GmmRawArgs a) {
   float mx2 = -INFINITY, lps[16];
   for (int c = 0; c < a.C; ++c) {
     const float mean = r[3 * c], sd = softplus_f(r[3 * c + 1]) + a.std_min, w = __expf(r[3 * c + 2] - mxw) / sw;
-    if (a.mean) a.mean[row * a.C + c] = mean;
-    if (a.sd) a.sd[row * a.C + c] = sd;
-    if (a.wgt) a.wgt[row * a.C + c] = w;
+    if (a.mean) a.mean[orow * a.C + c] = mean;
+    if (a.sd) a.sd[orow * a.C + c] = sd;
+    if (a.wgt) a.wgt[orow * a.C + c] = w;
     const float zz = (v - mean) / sd;
     lps[c] = -0.5f * zz * zz - logf(sd) - 0.91893853320467274178f + logf(w);
     mx2 = fmaxf(mx2, lps[c]);

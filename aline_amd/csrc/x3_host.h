@@ -15,7 +15,6 @@ static int launch_head(const Ctx &c, HeadArgs a) {
 // Eligibility of the tile-image path of this width (x3: d = 256 / 8 heads of 32, x5: d = 512 / 8 heads of 64) at reference
 // precision -- every product a 3-term f16 split on the matrix pipe.
 static bool eligible(const aline_model &m, const aline_rollout &r) {
-  if (wants_postq(r)) return false;     // posterior_out_query of every step: the s3 and generic paths
   if (dbg(ALINE_DBG_DISABLE_X3)) return false;
   if (m.precision != ALINE_PREC_F16X3 || m.d != D || m.H != H || m.F % 32) return false;
   if (r.n_ctx0 + r.T - 1 + r.n_target_data + m.n_theta > WNK) return false;
@@ -115,6 +114,23 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
       ha.out = logits; ha.out_stride = 1; ha.out_off = 0;
       ha.tau = m->time_token ? step_time_token(*r, t) : 0.f;
       TRY(launch_head<1>(c, ha));
+    }
+    if (wants_postq(*r)) {
+      // posterior_out_query of this step (model/head.py:366), by slot: the C GMM heads over the WHOLE output image of the last layer
+      // (every token row of every episode; the finish kernel keeps the P point rows), before the selection moves a role
+      float *rawq = c.at(c.pl.xRawQ);
+      for (int k = 0; k < m->C; ++k) {
+        HeadArgs hq{};
+        hq.X = xin; hq.ntiles = tiles; hq.M = tiles * 16; hq.img = img + (long)m->L * lw + (long)(1 + k) * head_words(F); hq.F = F;
+        hq.out = rawq; hq.out_stride = kRawStride; hq.out_off = 3 * k;
+        TRY(launch_head<3>(c, hq));
+      }
+      img::GmmRawArgs gq{};
+      gq.raw = rawq; gq.raw_stride = kRawStride; gq.rows = tiles * 16; gq.C = m->C; gq.std_min = m->std_min;
+      gq.mean = r->postq_mean; gq.sd = r->postq_std; gq.wgt = r->postq_weight;
+      gq.map_np = NP; gq.map_p = r->P; gq.out_row0 = (long)t * r->B * r->P;
+      hipLaunchKernelGGL(img::gmm_raw_finish_kernel, grid1d((size_t)tiles * 16), dim3(256), 0, c.st, gq);
+      CHECK_LAUNCH();
     }
     SelectArgs sel{};
     sel.g = c.g; sel.F = F; sel.logits = logits; sel.logit_stride = NP;

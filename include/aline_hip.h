@@ -138,7 +138,8 @@ typedef struct aline_rollout {
   void *ev_kernel_start, *ev_kernel_stop;
   /* posterior_out_query (model/head.py:366) of every step, by slot: [T,B,P,C]; the slots that are context points at
    * a step hold unspecified values there.  NULL = not computed (no caller in train_aline.py / utils/eval.py reads
-   * it).  Served by the s3 and generic paths (a request routes the rollout to one of them). */
+   * it).  Served by the s3, x3 / x5 and generic paths (the exact-fp32 fused kernel does not: a request routes its rollouts to the
+   * generic pipeline). */
   float *postq_mean, *postq_std, *postq_weight;
   /* Training rollouts: [2 L + 1][T * B * N * d] floats -- the encoder layers' inputs X_0 .. X_L, then their attention outputs
    * A_0 .. A_{L-1}, row (t * B + b) * N + token row -- written by aline_rollout_forward when non-NULL (s3 path; other paths leave it
