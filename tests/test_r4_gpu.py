@@ -164,3 +164,23 @@ def test_fused_eig_history_equals_the_step_by_step_bounds(B, L, T, K):
     assert maxdiff(pf, ps.cpu()) < 2e-4 and maxdiff(nf, ns.cpu()) < 2e-4, (maxdiff(pf, ps.cpu()), maxdiff(nf, ns.cpu()))
     p1, n1 = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=False, thetas=thetas)
     assert maxdiff(p1, ps[:, -1].cpu()) < 2e-4 and maxdiff(n1, ns[:, -1].cpu()) < 2e-4
+
+
+def test_range_status_word_survives_graph_replays_with_eager_launches_in_between():
+    """The status word of the f16 range guard (first word of the workspace) is cleared by a KERNEL node of the captured rollout
+    (aline_hip.hip: clear_words_kernel): a captured hipMemsetAsync was seen to fill its bytes with the arguments of the eager launch
+    enqueued right behind a replay (round 3, tools/ws_debug.py; the stand-alone check is tools/probes/graph_memset_repro.hip).  Refresh
+    (an eager torch kernel with seed / offset arguments) + replay, unsynchronised, many times: the word and its line stay zero."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    torch.manual_seed(123)
+    model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128)).cuda().set_precision("f16x3").train()
+    batch = HiddenLocation(n_query_init=100).sample_batch(128)
+    ro = Rollout(model, batch, 8, select="sample").capture()
+    for i in range(300):
+        ro.refresh_uniform()
+        ro.replay()
+        if i % 100 == 99:
+            torch.cuda.synchronize()
+            assert ro.ws[:64].view(torch.int32).abs().sum().item() == 0 and ro.range_status() == 0, i
