@@ -1173,12 +1173,16 @@ int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc
   return ALINE_OK;
 }
 
-// All T steps of a design history in one pass over theta (eig.h: eig_location_history_kernel).  xi [T, D, B], y [T, B] (the history in
-// order of acquisition, step-major), theta [L1, B, K, D] with row 0 the true parameter; pce / nmc [B, T]: the stepwise bounds of utils/eval.py:64-78.
+// All T steps of a design history in one pass over theta (eig.h: eig_location_history_kernel).  xi [B, T, D], y [B, T] (the history in
+// order of acquisition), theta [L1, B, K, D] with row 0 the true parameter; pce / nmc [B, T]: the stepwise bounds of utils/eval.py:64-78.
+// row groups of the history kernel: about 12 waves per CU worth of threads (three per SIMD), each with at least four rows
+static long eig_history_groups(int64_t L1, int B) {
+  const long want = (256l * 12 * 64 + B - 1) / B;
+  return std::max<long>(1, std::min<long>(want, (L1 - 1 + 3) / 4));
+}
 size_t aline_eig_history_workspace_bytes(int64_t L1, int B, int T) {
   if (L1 < 2 || B <= 0 || T <= 0) return 0;
-  const long ch = eig_chunk_rows(L1), nchunk = std::max<long>((L1 - 1 + ch - 1) / ch, 1), rows = 256 / std::min(B, 256);
-  return ((size_t)nchunk * rows * T * B * 2 + (size_t)T * B) * sizeof(float);
+  return ((size_t)eig_history_groups(L1, B) * T * B * 2 + (size_t)T * B) * sizeof(float);
 }
 
 int aline_eig_location_history(const float *theta, const float *xi, const float *y, int64_t L1, int B, int T, int K, int D,
@@ -1186,21 +1190,19 @@ int aline_eig_location_history(const float *theta, const float *xi, const float 
                                size_t ws_bytes, void *stream) {
   if (!theta || !xi || !y || L1 < 2 || B <= 0 || T <= 0 || K <= 0 || D <= 0 || K * D > 8 || !ws) return ALINE_EINVAL;
   if (ws_bytes < aline_eig_history_workspace_bytes(L1, B, T)) return ALINE_EWORKSPACE;
-  const long ch = eig_chunk_rows(L1);
-  const int nchunk = (int)std::max<long>((L1 - 1 + ch - 1) / ch, 1);
-  const int rows = 256 / std::min(B, 256);
+  const long R = eig_history_groups(L1, B);
   const size_t smem = 0;
-  float *part = static_cast<float *>(ws), *s0 = part + (size_t)nchunk * rows * T * B * 2;
+  float *part = static_cast<float *>(ws), *s0 = part + (size_t)R * T * B * 2;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(nchunk, (B + 255) / 256);
+  const dim3 grid((unsigned)(((long)B * R + 255) / 256));
   if (K == 1 && D == 2)
     hipLaunchKernelGGL(eig_location_history_kernel<1>, grid, dim3(256), smem, st, theta, xi, y, (long)L1, B, T, K, D, noise_scale,
-                       base_signal, max_signal, ch, part, s0);
+                       base_signal, max_signal, R, part, s0);
   else
     hipLaunchKernelGGL(eig_location_history_kernel<0>, grid, dim3(256), smem, st, theta, xi, y, (long)L1, B, T, K, D, noise_scale,
-                       base_signal, max_signal, ch, part, s0);
+                       base_signal, max_signal, R, part, s0);
   CHECK_LAUNCH();
-  hipLaunchKernelGGL(eig_history_combine_kernel, grid1d((size_t)T * B), dim3(256), 0, st, part, s0, nchunk * rows, (long)L1, B, T, pce, nmc);
+  hipLaunchKernelGGL(eig_history_combine_kernel, grid1d((size_t)T * B), dim3(256), 0, st, part, s0, (int)R, (long)L1, B, T, pce, nmc);
   CHECK_LAUNCH();
   return ALINE_OK;
 }

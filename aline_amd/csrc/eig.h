@@ -311,25 +311,28 @@ __global__ __launch_bounds__(256) void eig_lse_combine_kernel(const float *__res
 // L = 1e6, B = 200.  The steps of a history are known up front, so one kernel reads theta ONCE, walks the T designs of its episode
 // (xi, y of its episode from L1), carries S in a register and keeps one online (max, sum-exp) pair per step:
 // 8 B per (l, b) for all T steps, the bound moves from HBM to the transcendental units (1 log + 1.25 exp + 1 rcp per (l, b, t)).
-// part[chunk x row group][t][b] = (m, s) over that group's rows l >= 1;  s0[t][b] = S_t of row l = 0 (the "true" theta).
+// part[row group][t][b] = (m, s) over that group's rows l >= 1;  s0[t][b] = S_t of row l = 0 (the "true" theta).
 template <int K1D2>
 __global__ __launch_bounds__(256) void eig_location_history_kernel(const float *__restrict__ theta, const float *__restrict__ xi,
                                                                    const float *__restrict__ y, long L1, int B, int T, int K, int D,
-                                                                   float noise, float base, float msig, long chunk,
+                                                                   float noise, float base, float msig, long R,
                                                                    float *__restrict__ part, float *__restrict__ s0) {
   // A thread owns column b and the rows l0 + ty, l0 + ty + rows, ... of its chunk; the (max, sum-exp) pairs of up to 32 steps live in
   // its registers (static indices: the step loop is unrolled), the designs / outcomes of its episode come from L1 (T x 12 B per
   // episode, the same addresses for every row).  No LDS, no barrier: occupancy is set by the ~110 registers alone.  (First version:
   // accumulators and designs in LDS, 133 KB per workgroup = one wave per SIMD: 13.2 ms at L = 1e6, B = 200, T = 30, latency-bound.)
-  const int cols = min(B, 256), rows = 256 / cols;
-  const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
-  const int b = blockIdx.y * cols + tx;
-  if (b >= B || ty >= rows) return;
+  // flat mapping: thread gid owns episode b = gid % B and the rows 1 + rg, 1 + rg + R, ... with rg = gid / B (R row groups in all): every
+  // lane of every wave works whatever B is (a [min(B, 256) columns] x [256 / columns rows] tiling left 56 of 256 lanes idle at B = 200)
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)B * R) return;
+  const int b = (int)(gid % B);
+  const long rg = gid / B;
   const float inv2n2 = 1.f / (2.f * noise * noise), cst = logf(noise) + LOG_SQRT_2PI;
-  const long l0 = 1 + (long)blockIdx.x * chunk, l1 = min(L1, l0 + chunk);
-  // xi [T, D, B], y [T, B]: step-major, so the lanes of a wave (consecutive episodes b) read consecutive addresses (episode-major
-  // [B, T, D] made every lane touch its own cache line twice per step: 9.9 ms instead of the issue-bound time)
-  const float *xb = xi + b, *yb = y + b;
+  const long l1 = L1;
+  // xi [B, T, D], y [B, T] episode-major: a lane's loads of the unrolled steps are ONE base register + immediate offsets (136 registers,
+  // three waves per SIMD).  Step-major [T, D, B] (coalesced across lanes) was measured: runtime strides make the compiler precompute the 90
+  // addresses of the unrolled steps (256 + 70 registers, one wave per SIMD) for the same 9.9 ms -- the lines stay in L1 either way.
+  const float *xb = xi + (size_t)b * T * D, *yb = y + (size_t)b * T;
   auto ll_of = [&](const float *th, const float *x, float yv) -> float {
     float inv_sum = 0.f;
     for (int k = 0; k < (K1D2 ? 1 : K); ++k) {
@@ -343,17 +346,18 @@ __global__ __launch_bounds__(256) void eig_location_history_kernel(const float *
     return -(z * z) * inv2n2 - cst;
   };
   auto load_x = [&](int t, float *x) {
-    for (int d = 0; d < (K1D2 ? 2 : D); ++d) x[d] = xb[((size_t)t * D + d) * B];
+    if (K1D2) { const float2 v = reinterpret_cast<const float2 *>(xb)[t]; x[0] = v.x; x[1] = v.y; }
+    else for (int d = 0; d < D; ++d) x[d] = xb[(size_t)t * D + d];
   };
   auto load_theta = [&](long l, float *th) {
     if (K1D2) { const float2 t2 = reinterpret_cast<const float2 *>(theta)[l * B + b]; th[0] = t2.x; th[1] = t2.y; }
     else for (int e = 0; e < K * D; ++e) th[e] = theta[(l * B + b) * K * D + e];
   };
-  if (blockIdx.x == 0 && ty == 0) {            // row l = 0 (the true theta): its running sums go to s0, not into the logsumexp over l >= 1
+  if (rg == 0) {                               // row l = 0 (the true theta): its running sums go to s0, not into the logsumexp over l >= 1
     float th[8], x[8];
     load_theta(0, th);
     float S = 0.f;
-    for (int t = 0; t < T; ++t) { load_x(t, x); S += ll_of(th, x, yb[(size_t)t * B]); s0[(size_t)t * B + b] = S; }
+    for (int t = 0; t < T; ++t) { load_x(t, x); S += ll_of(th, x, yb[t]); s0[(size_t)t * B + b] = S; }
   }
   constexpr int TM = 32;                       // steps per register block (T <= 32: one pass over theta; longer histories: one per 32 steps)
   for (int t0 = 0; t0 < T; t0 += TM) {
@@ -362,8 +366,8 @@ __global__ __launch_bounds__(256) void eig_location_history_kernel(const float *
 #pragma unroll
     for (int t = 0; t < TM; ++t) { m[t] = -INFINITY; sacc[t] = 0.f; }
     // four rows of theta per thread and pass: four independent S chains, one rescale of the step's (max, sum) per group
-    long l = l0 + ty;
-    const long r1 = rows;
+    long l = 1 + rg;
+    const long r1 = R;
     for (; l < l1; l += 4 * r1) {
       float th[4][8], S[4] = {0.f, 0.f, 0.f, 0.f};
       bool on[4];
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void eig_location_history_kernel(const float *
       for (int t = 0; t < t0; ++t) {           // (second and later passes: the steps before t0 only advance S)
         float x[8];
         load_x(t, x);
-        const float yv = yb[(size_t)t * B];
+        const float yv = yb[t];
 #pragma unroll
         for (int q = 0; q < 4; ++q) S[q] += ll_of(th[q], x, yv);
       }
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256) void eig_location_history_kernel(const float *
         if (t < nt) {
           float x[8];
           load_x(t0 + t, x);
-          const float yv = yb[(size_t)(t0 + t) * B];
+          const float yv = yb[t0 + t];
 #pragma unroll
           for (int q = 0; q < 4; ++q) { S[q] += ll_of(th[q], x, yv); if (!on[q]) S[q] = -INFINITY; }
           const float mn = fmaxf(fmaxf(m[t], fmaxf(S[0], S[1])), fmaxf(S[2], S[3]));      // (S[0] is always a live row: finite)
@@ -391,11 +395,11 @@ __global__ __launch_bounds__(256) void eig_location_history_kernel(const float *
         }
       }
     }
-    // every (chunk, row group) writes its own partial: part[(chunk * rows + ty)][t][b]
+    // every row group writes its own partial: part[rg][t][b]
 #pragma unroll
     for (int t = 0; t < TM; ++t)
       if (t < nt) {
-        float *pp = part + ((((size_t)blockIdx.x * rows + ty) * T + (t0 + t)) * B + b) * 2;
+        float *pp = part + (((size_t)rg * T + (t0 + t)) * B + b) * 2;
         pp[0] = m[t]; pp[1] = sacc[t];
       }
   }

@@ -66,9 +66,7 @@ class HiddenLocation(Task):
         order of acquisition, y [B, T(, 1)] -> (pce [B, T], nmc [B, T]) = what utils/eval.py:64-78 returns with stepwise=True."""
         L1, B = thetas.shape[0], thetas.shape[1]
         T = x.shape[1]
-        th = _lib.f32(thetas)
-        xx = _lib.f32(x).reshape(B, T, -1).permute(1, 2, 0).contiguous()          # [T, D, B]: step-major for the kernel
-        yy = _lib.f32(y).reshape(B, T).t().contiguous()                            # [T, B]
+        th, xx, yy = _lib.f32(thetas), _lib.f32(x).reshape(B, T, -1).contiguous(), _lib.f32(y).reshape(B, T).contiguous()
         pce, nmc = torch.empty(B, T, device=th.device), torch.empty(B, T, device=th.device)
         nb = _lib.lib.aline_eig_history_workspace_bytes(L1, B, T)
         ws = self._hist_ws.get(nb, th.device)

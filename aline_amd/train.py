@@ -143,7 +143,9 @@ def _default_bwd_ws_bytes(device):
     if gb:
         return int(float(gb) * (1 << 30))
     try:
-        return int(0.5 * torch.cuda.get_device_properties(device).total_memory)
+        free, total = torch.cuda.mem_get_info(device)
+        held = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # (cached by torch: reusable)
+        return int(max(min(0.5 * total, 0.8 * (free + held)), 8 << 30))      # (ranks sharing a card in a rehearsal see less free memory)
     except Exception:
         return 24 << 30
 

@@ -222,8 +222,7 @@ int aline_eig_finalize(const float *S, int64_t L1, int B, float *pce, float *nmc
                        size_t ws_bytes, void *stream);
 /* All T steps of a design history in ONE pass over theta (compute_EIG_from_history, utils/eval.py:42-80, stepwise: the criterion of
  * loss/eig.py:174-209 applied to y[:, t], x[:, t] for t = 0 .. T - 1 on the same contrastive draw).  theta [L1, B, K, D] with row 0 the
- * true parameter of each episode, xi [T, D, B] and y [T, B] (unnormalised designs / outcomes in order of acquisition, STEP-major: the
- * lanes of a wave are consecutive episodes); pce / nmc [B, T] receive the
+ * true parameter of each episode, xi [B, T, D] (unnormalised designs in order of acquisition), y [B, T]; pce / nmc [B, T] receive the
  * sPCE / sNMC bounds after every step (either may be NULL).  Location-finding likelihood (tasks/location_finding.py:110-164). */
 size_t aline_eig_history_workspace_bytes(int64_t L1, int B, int T);
 int aline_eig_location_history(const float *theta, const float *xi, const float *y, int64_t L1, int B, int T, int K, int D,
