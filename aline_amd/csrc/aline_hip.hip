@@ -13,6 +13,7 @@
 #include "s3.h"
 #include "attn3.h"
 #include "backward.h"
+#include "attn_bwd_wide.h"
 #include "tail_bwd.h"
 #include "attn_bwd_mfma.h"
 #include "acq_head_bwd.h"
@@ -1394,11 +1395,13 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
             int N, int K, int Ry = 1, int Gy = 1, int offy = 0, int Rx = 1, int Gx = 1, int offx = 0, int ldw = 0,
             const unsigned *scale = nullptr) {
   if (N % 32 || K % 32) return ALINE_EUNSUPPORTED;
-  if (bwd_grad_f16(*c.m) && Ry == Gy && Rx == Gx && N % 256 == 0 && K % 256 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && M < (1l << 40)) {
-    // the scaled 3-term f16 split on 256 x 256 blocks (backward.h: gemm_tn_f16_kernel); the wider operand indexes the block rows
-    const float *pY = dY + (long)offy * ldy, *pX = X + (long)offx * ldx;
+  if (bwd_grad_f16(*c.m) && Ry == Gy && N % 256 == 0 && K % 256 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && M < (1l << 40)) {
+    // the scaled 3-term f16 split on 256 x 256 blocks (backward.h: gemm_tn_f16_kernel); X may be row-mapped (the point rows of every
+    // instance: the acquisition head's first layer), dY is dense
+    const float *pY = dY + (long)offy * ldy, *pX = X;
     if (!(reinterpret_cast<uintptr_t>(pY) & 15) && !(reinterpret_cast<uintptr_t>(pX) & 15)) {
       GemmTnF16Args f{};
+      f.Rp = 1; f.Gp = 1; f.offp = 0; f.Rq = Rx; f.Gq = Gx; f.offq = offx;
       f.xmax_bits = scale ? scale : grad_absmax(c, pY, M, N, ldy);
       const long ldo = ldw > 0 ? ldw : K;
       f.P = pY; f.ldp = ldy; f.Q = pX; f.ldq = ldx; f.out = dW; f.sa = ldo; f.sb = 1; f.grad_is_p = 1;
@@ -1482,9 +1485,40 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
   return ALINE_OK;
 }
 
+// head_dim 32 / 64 on the fp32 matrix pipe (attn_bwd_wide.h); *out_max (when asked for) receives the scale word of dQKV
+template <int HD, int NKT>
+static int launch_attention_bwd_wide(const BCtx &c, const float *qkv, const float *dA, const float *aout, float *dqkv, unsigned *mw) {
+  const int H = c.m->d / HD, waves = std::min(H, HD == 64 ? 4 : abww::MAXW);
+  const size_t smem = abww::lds_bytes(HD, NKT, c.g.N, waves);
+  if (smem > 160 * 1024) return ALINE_EUNSUPPORTED;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abww::attention_bwd_wide_kernel<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((abww::attention_bwd_wide_kernel<HD, NKT>), dim3((unsigned)c.g.B), dim3(64 * waves), smem, c.st, c.g, c.m->d, qkv, dA, aout, dqkv, mw);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
 template <int HD>
-int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys, const float *aout = nullptr) {
+int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys, const float *aout = nullptr,
+                         unsigned **out_max = nullptr) {
   const bool mfma_on = !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA);      // 0: the VALU kernel (A/B measurements)
+  if (out_max) *out_max = nullptr;
+  if constexpr (HD == 32 || HD == 64) {
+    const int nkt = (max_keys + 15) / 16;
+    if (mfma_on && aout && nkt <= (HD == 32 ? 3 : 2) && c.m->d % HD == 0) {      // (<32, 4> spills 64 registers: beyond 48 keys the VALU kernel)
+      unsigned *mw = (out_max && bwd_grad_f16(*c.m)) ? new_scale_word(c) : nullptr;
+      if (out_max) *out_max = mw;
+      if constexpr (HD == 32) {
+        switch (nkt) {
+          case 1: return launch_attention_bwd_wide<32, 1>(c, qkv, dA, aout, dqkv, mw);
+          case 2: return launch_attention_bwd_wide<32, 2>(c, qkv, dA, aout, dqkv, mw);
+          default: return launch_attention_bwd_wide<32, 3>(c, qkv, dA, aout, dqkv, mw);
+        }
+      } else {
+        if (nkt == 1) return launch_attention_bwd_wide<64, 1>(c, qkv, dA, aout, dqkv, mw);
+        return launch_attention_bwd_wide<64, 2>(c, qkv, dA, aout, dqkv, mw);
+      }
+    }
+  }
   if (mfma_on && HD == abwd::HD && c.m->d == abwd::D && max_keys <= abwd::MAXK) {
     hipLaunchKernelGGL(abwd::attention_bwd_mfma_kernel, dim3((unsigned)c.g.B), dim3(abwd::THREADS), 0, c.st, c.g, qkv, dA, dqkv);
     CHECK_LAUNCH();
@@ -1918,16 +1952,17 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         continue;
       }
       // attention
+      unsigned *sw_att = nullptr;
       switch (hd) {
         case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
         case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
         case 16: TRY(launch_attention_bwd<16>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
-        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
-        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
+        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att)); break;
+        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att)); break;
         default: return ALINE_EUNSUPPORTED;
       }
-      // in-proj
-      const unsigned *sw_qkv = bwd_grad_f16(*m) ? grad_absmax(c, dQKV, M, 3 * d, 3 * d) : nullptr;      // (the attention backward does not reduce its output)
+      // in-proj (the matrix-pipe attention backward leaves max |dQKV|; the VALU kernels do not: a reduction pass)
+      const unsigned *sw_qkv = !bwd_grad_f16(*m) ? nullptr : sw_att ? sw_att : grad_absmax(c, dQKV, M, 3 * d, 3 * d);
       TRY(gemm_dw(c, dQKV, 3 * d, Xs(l), d, gr->in_proj_w[l], gr->in_proj_b[l], M, 3 * d, d, 1, 1, 0, 1, 1, 0, 0, sw_qkv));
       TRY(gemm_dx(c, dQKV, 3 * d, m->in_proj_w[l], 3 * d, d, dXn, d, (int)M, true, nullptr, sw_qkv));   // dXn = dX_l
       std::swap(dX, dXn);

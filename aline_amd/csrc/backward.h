@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_block_kernel(GemmTnArgs a) {
 struct GemmTnF16Args {
   const float *P; int ldp;            // [M, ldp]: the operand whose columns index the ROWS of the block (a)
   const float *Q; int ldq;            // [M, ldq]: ... the COLUMNS of the block (b)
+  int Rp, Gp, offp, Rq, Gq, offq;     // row maps as in gemm.h: product row m is row (m / R) * G + off + m % R of the operand (R == G: m + off)
   float *out; long sa, sb;            // out[a * sa + b * sb] += ...   (dW [N, K]: P = dY gives sa = ldw, sb = 1; P = X gives sa = 1, sb = ldw)
   float *colsum;                      // += column sums of the GRADIENT operand (the bias gradient), or null
   int grad_is_p;                      // which operand is the gradient (scaled; its column sums go to colsum)
@@ -251,11 +252,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f16_kernel(GemmTnF16Args a) {
   const int ccol = (is_p ? 0 : TILE) + c4;                    // column of the LDS image
   float4 v[8];
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  const int mapR = is_p ? a.Rp : a.Rq, mapG = is_p ? a.Gp : a.Gq, mapOff = is_p ? a.offp : a.offq;
   auto load_slab = [&](long m0) {
+    const long first = m0 + 8 * rg;
+    long q = 0;
+    int r = 0;
+    if (mapR != mapG) { q = first / mapR; r = (int)(first - q * mapR); }      // one division per 8 rows, then a walked remainder
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const long m = m0 + 8 * rg + e;
-      v[e] = m < m_hi ? *reinterpret_cast<const float4 *>(src + m * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const long m = first + e;
+      const long row = mapR == mapG ? m + mapOff : q * mapG + mapOff + r;
+      v[e] = m < m_hi ? *reinterpret_cast<const float4 *>(src + row * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (++r == mapR) { r = 0; ++q; }
     }
   };
   auto store_slab = [&](unsigned short *smem) {

@@ -649,3 +649,43 @@ def test_scaled_f16_gradient_products_match_the_exact_fp32_products(d, F, H, B, 
         if err > worst[1]:
             worst = (k, err)
     assert worst[1] < 2e-4, worst
+
+
+@pytest.mark.parametrize("d,F,H,B,T,nq", [(256, 256, 8, 6, 4, 50), (256, 256, 8, 5, 20, 40), (256, 256, 8, 3, 36, 60), (128, 192, 4, 7, 18, 30),
+                                          (512, 128, 8, 4, 3, 40), (512, 128, 8, 3, 28, 50)])
+def test_matrix_pipe_attention_backward_at_head_dim_32_and_64_matches_the_valu_kernel(d, F, H, B, T, nq):
+    """`abww::attention_bwd_wide_kernel<32 | 64, NKT>` (attn_bwd_wide.h, round 4: the attention backward of the wide models on the fp32
+    matrix pipe, one wave per head, dK / dV resident over the row tiles) against the fp32 VALU `attention_bwd_kernel` it replaces
+    (`ALINE_DBG_NO_BWD_ATTN_MFMA`): every parameter gradient of the same rollout, exact-fp32 model (precision f32: no f16 scaling in the
+    way), 1 / 2 / 3 key tiles at head_dim 32 (6, 22 and 38 keys; 4 heads too) and 1 / 2 at head_dim 64; token counts that are not
+    multiples of 16 (ragged last row tile)."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.tasks import HiddenLocation
+    from aline_amd.train import backward, reinforce_terms
+    torch.manual_seed(d + T)
+    model = Aline(Embedder(2, 1, d, F, 2, "theta"), Encoder(d, F, H, 0.0, 2), OutputHead(2, 1, d, F)).cuda().set_precision("f32").train()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    batch = HiddenLocation(n_query_init=nq).sample_batch(B)
+    grads = []
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        terms = reinforce_terms(ro, "theta", "all")
+        for flags in ([], ["NO_BWD_ATTN_MFMA"]):
+            with _lib.debug(*flags):
+                for p in model.parameters():
+                    p.grad = None
+                backward(model, ro, terms["g_logp"], terms["g_ll"])
+                torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    worst = ("", 0.0)
+    floor = 1e-2 * max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[0]:
+        ref = grads[1][k]
+        assert torch.isfinite(grads[0][k]).all(), k
+        err = float((grads[0][k] - ref).abs().max()) / max(float(ref.abs().max()), floor)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 5e-5, worst       # the same fp32 products in another summation order
