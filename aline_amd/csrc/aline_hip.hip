@@ -1479,6 +1479,13 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
   const int rpb = 64;
   unsigned *mw = (out_max && bwd_grad_f16(*c.m)) ? new_scale_word(c) : nullptr;      // max |dU| for the F16X3 products that read dU
   if (out_max) *out_max = mw;
+  if (d == 256 || d == 512) {      // 16 B per lane (backward.h: layernorm_bwd_wide_kernel)
+    const unsigned grid = (unsigned)std::min<long>((rows + 3) / 4, 256 * 8);
+    if (d == 256) hipLaunchKernelGGL(layernorm_bwd_wide_kernel<1>, dim3(grid), dim3(256), 0, c.st, dY, U, w, dU, dw, db, rows, mw);
+    else hipLaunchKernelGGL(layernorm_bwd_wide_kernel<2>, dim3(grid), dim3(256), 0, c.st, dY, U, w, dU, dw, db, rows, mw);
+    CHECK_LAUNCH();
+    return ALINE_OK;
+  }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
                      (size_t)2 * c.m->d * sizeof(float), c.st, dY, U, w, dU, dw, db, rows, c.m->d, rpb, mw);
   CHECK_LAUNCH();

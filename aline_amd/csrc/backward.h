@@ -203,6 +203,82 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_block_kernel(GemmTnArgs a) {
   }
 }
 
+// Wide-row LayerNorm backward (d = 256 NV: 256, 512): one wave per row, NV float4 per lane -- 16 B / lane loads and stores where the
+// kernel above moves 4 B / lane (it ran at 2.4 TB/s on the d = 256 training step; this one is HBM-bound like add_layernorm_wide_kernel).
+// Same arithmetic; dw / db partials per lane, summed per workgroup through LDS, one atomic per feature and workgroup.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float *__restrict__ dY, const float *__restrict__ U,
+                                                                 const float *__restrict__ w, float *__restrict__ dU, float *dw, float *db,
+                                                                 long rows, unsigned *out_absmax) {
+  constexpr int d = 256 * NV;
+  __shared__ float sdw[d], sdb[d];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < d; i += 256) { sdw[i] = 0.f; sdb[i] = 0.f; }
+  __syncthreads();
+  float4 wv[NV], pdw[NV], pdb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    wv[i] = *reinterpret_cast<const float4 *>(w + 4 * (lane + 64 * i));
+    pdw[i] = make_float4(0.f, 0.f, 0.f, 0.f); pdb[i] = pdw[i];
+  }
+  unsigned omax = 0;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float4 u[NV], gy[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      u[i] = *reinterpret_cast<const float4 *>(U + row * d + 4 * (lane + 64 * i));
+      gy[i] = *reinterpret_cast<const float4 *>(dY + row * d + 4 * (lane + 64 * i));
+      s += (u[i].x + u[i].y) + (u[i].z + u[i].w);
+    }
+    const float mean = wave_sum(s) / d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      u[i].x -= mean; u[i].y -= mean; u[i].z -= mean; u[i].w -= mean;
+      ss += (u[i].x * u[i].x + u[i].y * u[i].y) + (u[i].z * u[i].z + u[i].w * u[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / d + 1e-5f);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float *x = reinterpret_cast<float *>(&u[i]), *gq = reinterpret_cast<float *>(&gy[i]);
+      const float *wq = reinterpret_cast<const float *>(&wv[i]);
+      float *aw = reinterpret_cast<float *>(&pdw[i]), *ab = reinterpret_cast<float *>(&pdb[i]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = x[q] * rstd, gg = gq[q] * wq[q];
+        aw[q] = fmaf(gq[q], xh, aw[q]);
+        ab[q] += gq[q];
+        x[q] = xh; gq[q] = gg;
+        sg += gg;
+        sgx = fmaf(gg, xh, sgx);
+      }
+    }
+    const float mg = wave_sum(sg) / d, mgx = wave_sum(sgx) / d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 o = make_float4(rstd * (gy[i].x - mg - u[i].x * mgx), rstd * (gy[i].y - mg - u[i].y * mgx),
+                                   rstd * (gy[i].z - mg - u[i].z * mgx), rstd * (gy[i].w - mg - u[i].w * mgx));
+      *reinterpret_cast<float4 *>(dU + row * d + 4 * (lane + 64 * i)) = o;
+      omax = max(max(omax, __float_as_uint(o.x) & 0x7fffffffu), max(__float_as_uint(o.y) & 0x7fffffffu, max(__float_as_uint(o.z) & 0x7fffffffu, __float_as_uint(o.w) & 0x7fffffffu)));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float *aw = reinterpret_cast<const float *>(&pdw[i]), *ab = reinterpret_cast<const float *>(&pdb[i]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { atomicAdd(&sdw[4 * (lane + 64 * i) + q], aw[q]); atomicAdd(&sdb[4 * (lane + 64 * i) + q], ab[q]); }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) { atomicAdd(dw + c, sdw[c]); atomicAdd(db + c, sdb[c]); }
+  if (out_absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+    if (lane == 0 && omax) atomicMax(out_absmax, omax);
+  }
+}
+
 // ---- weight-gradient product on the f16 matrix pipe (round 4) ---------------------------------------------------------------------
 // out[a, b] += sum_m P[m, a0 + a] * Q[m, b0 + b] for a 256 x 256 block of (P columns) x (Q columns) and a chunk of rows, every product
 // the 3-term f16 split of the forward (hi * hi + hi * lo + lo * hi, fp32 accumulate).  One of the operands is a gradient (1e-8 .. 1e-5):
