@@ -1511,7 +1511,7 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
   if (out_max) *out_max = nullptr;
   if constexpr (HD == 32 || HD == 64) {
     const int nkt = (max_keys + 15) / 16;
-    if (mfma_on && aout && nkt <= (HD == 32 ? 3 : 2) && c.m->d % HD == 0) {      // (<32, 4> spills 64 registers: beyond 48 keys the VALU kernel)
+    if (mfma_on && aout && nkt <= 3 && c.m->d % HD == 0) {      // (<32, 4> spills 64 registers: beyond 48 keys the VALU kernel)
       unsigned *mw = (out_max && bwd_grad_f16(*c.m)) ? new_scale_word(c) : nullptr;
       if (out_max) *out_max = mw;
       if constexpr (HD == 32) {
@@ -1522,7 +1522,8 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
         }
       } else {
         if (nkt == 1) return launch_attention_bwd_wide<64, 1>(c, qkv, dA, aout, dqkv, mw);
-        return launch_attention_bwd_wide<64, 2>(c, qkv, dA, aout, dqkv, mw);
+        if (nkt == 2) return launch_attention_bwd_wide<64, 2>(c, qkv, dA, aout, dqkv, mw);
+        return launch_attention_bwd_wide<64, 3>(c, qkv, dA, aout, dqkv, mw);      // (cfg5: 1 + 29 context + 4 targets = 34 keys)
       }
     }
   }

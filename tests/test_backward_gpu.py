@@ -652,12 +652,12 @@ def test_scaled_f16_gradient_products_match_the_exact_fp32_products(d, F, H, B, 
 
 
 @pytest.mark.parametrize("d,F,H,B,T,nq", [(256, 256, 8, 6, 4, 50), (256, 256, 8, 5, 20, 40), (256, 256, 8, 3, 36, 60), (128, 192, 4, 7, 18, 30),
-                                          (512, 128, 8, 4, 3, 40), (512, 128, 8, 3, 28, 50)])
+                                          (512, 128, 8, 4, 3, 40), (512, 128, 8, 3, 28, 50), (512, 128, 8, 2, 40, 50)])
 def test_matrix_pipe_attention_backward_at_head_dim_32_and_64_matches_the_valu_kernel(d, F, H, B, T, nq):
     """`abww::attention_bwd_wide_kernel<32 | 64, NKT>` (attn_bwd_wide.h, round 4: the attention backward of the wide models on the fp32
     matrix pipe, one wave per head, dK / dV resident over the row tiles) against the fp32 VALU `attention_bwd_kernel` it replaces
     (`ALINE_DBG_NO_BWD_ATTN_MFMA`): every parameter gradient of the same rollout, exact-fp32 model (precision f32: no f16 scaling in the
-    way), 1 / 2 / 3 key tiles at head_dim 32 (6, 22 and 38 keys; 4 heads too) and 1 / 2 at head_dim 64; token counts that are not
+    way), 1 / 2 / 3 key tiles at head_dim 32 (6, 22 and 38 keys; 4 heads too) and at head_dim 64 (5, 30 and 42 keys); token counts that are not
     multiples of 16 (ragged last row tile)."""
     from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
     from aline_amd.rollout import Rollout
