@@ -1278,7 +1278,14 @@ namespace {
 struct BwdPlan {
   size_t Xs, QKV, A, U1, X1, Hid, U2, HidA, HidG, dXa, dXb, dQKV, dHid, dTmp, Ex, Ey, EHx, EHy, dEx, dEy, Wt, KeyIdx, Kcnt, Tvec, Scale,
       total;
+  int rc_width;                                   // 0, or the width (256 / 512) whose tile-image layer kernel recomputes the forward (x3_host.h: recompute)
+  x3::RecomputePlan rc3; x5::RecomputePlan rc5;
 };
+// Forward recompute of the per-op backward on the rollout's own layer kernel (x3_host.h).  ALINE_DBG_NO_BWD_IMAGE_RECOMPUTE: the generic kernels.
+static int image_recompute_width(const aline_model &m) {
+  if (dbg(ALINE_DBG_NO_BWD_IMAGE_RECOMPUTE) || dbg(ALINE_DBG_BWD_RECOMPUTE_F32)) return 0;
+  return x3::recompute_model_ok(m) ? x3::D : x5::recompute_model_ok(m) ? x5::D : 0;
+}
 
 // Fused token-local tail (tail_bwd.h) for the small-width model: U1 / X1 / Hid / U2 are never stored.  ALINE_BWD_TAIL=0
 // switches back to the per-op pipeline (A/B measurements).
@@ -1328,6 +1335,9 @@ BwdPlan make_bwd_plan(const aline_model &m, int B, int P, int n_td, int tc) {
   p.KeyIdx = take(M);      // (ints) key rows of every instance: K / V of the forward recompute on these rows only
   p.Kcnt = take(I * 2);
   p.Scale = take(16 * 16);      // (unsigned) ring of 16 max-|dY| words (one per 16-word line) of the scaled f16 gradient products
+  p.rc_width = image_recompute_width(m);
+  if (p.rc_width == x3::D) p.rc3 = x3::recompute_plan(m, (long)I, (int)N, take);
+  else if (p.rc_width == x5::D) p.rc5 = x5::recompute_plan(m, (long)I, (int)N, take);
   p.total = off;
   return p;
 }
@@ -1676,6 +1686,11 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
   (void)hipMemsetAsync(c.at(c.pl.dEy), 0, (size_t)rows_y * d * sizeof(float), c.st);
   }
 
+  const bool img_rc = c.pl.rc_width && do_emb && do_enc && !ft;
+  if (img_rc) {
+    if (c.pl.rc_width == x3::D) TRY(x3::pack_weights(*m, reinterpret_cast<unsigned *>(c.at(c.pl.rc3.img)), nullptr, c.st));
+    else TRY(x5::pack_weights(*m, reinterpret_cast<unsigned *>(c.at(c.pl.rc5.img)), nullptr, c.st));
+  }
   for (int tA = 0; tA < r->T; tA += tc) {
     const int nt_steps = std::min(tc, r->T - tA);
     const int I = B * nt_steps;
@@ -1720,8 +1735,40 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       hipLaunchKernelGGL(key_list_kernel, dim3(I), dim3(256), 0, c.st, g, max_keys, keyidx, kcnt);
       CHECK_LAUNCH();
     }
+    // (d = 256 / 512, <= 64 keys: everything but QKV from the rollout's layer kernel run over the instances)
+    const bool rc_now = img_rc && !use_saved && !ckv && max_keys <= x3::WNK;
+    // ... Q too when the matrix-pipe attention backward runs (it reads K / V of the key rows only: those come from a row-gather GEMM on
+    // the key list, 16 % of the rows at the d = 256 headline shape, scattered into the [M, 3 d] buffer the kernel indexes by token row)
+    const bool rc_q = rc_now && max_keys < N && max_keys <= 48 && (hd == 32 || hd == 64) && !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA);
+    if (rc_q) {
+      hipLaunchKernelGGL(key_list_kernel, dim3(I), dim3(256), 0, c.st, g, max_keys, keyidx, kcnt);
+      CHECK_LAUNCH();
+    }
+    if (rc_now) {
+      if (c.pl.rc_width == x3::D) {
+        x3::RecomputeRows rr{};
+        rr.q_ld = 3 * d;
+        for (int l = 0; l < L; ++l) { rr.Q[l] = rc_q ? QKVl(l) : c.at(c.pl.dQKV); rr.A[l] = Al(l); rr.U1[l] = U1l(l); rr.X1[l] = X1l(l); rr.Hid[l] = Hidl(l); rr.U2[l] = U2l(l); rr.Y[l] = Xs(l + 1); }
+        TRY(x3::recompute(m, g, max_keys, Ex, Ey, P, c.ws, c.pl.rc3, rr, c.st));
+      } else {
+        x5::RecomputeRows rr{};
+        rr.q_ld = 3 * d;
+        for (int l = 0; l < L; ++l) { rr.Q[l] = rc_q ? QKVl(l) : c.at(c.pl.dQKV); rr.A[l] = Al(l); rr.U1[l] = U1l(l); rr.X1[l] = X1l(l); rr.Hid[l] = Hidl(l); rr.U2[l] = U2l(l); rr.Y[l] = Xs(l + 1); }
+        TRY(x5::recompute(m, g, max_keys, Ex, Ey, P, c.ws, c.pl.rc5, rr, c.st));
+      }
+    }
     for (int l = 0; l < L && do_enc; ++l) {
       Ctx fc{}; fc.m = m; fc.g = g; fc.st = c.st; fc.ws = c.ws;
+      if (rc_q) {      // K | V of the key rows, stored at their token rows
+        GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, QKVl(l) + d, 3 * d, I * max_keys, 2 * d, d, false);
+        ka.row_index = keyidx; ka.out_index = keyidx;
+        TRY(launch_gemm(recompute_prec(*m), ka, 1, c.st));
+        continue;
+      }
+      if (rc_now) {      // the in-projection (K, V never leave the layer kernel's key image)
+        TRY(launch_gemm(recompute_prec(*m), gemm_args(Xs(l), d, m->in_proj_w[l], m->in_proj_b[l], d, QKVl(l), 3 * d, (int)M, 3 * d, d, false), 1, c.st));
+        continue;
+      }
       if (ckv) {      // K / V of the key rows: row-gather GEMM on the key list
         GemmArgs ka = gemm_args(Xs(l), d, m->in_proj_w[l] + (size_t)d * d, m->in_proj_b[l] + d, d, KVl(l), 2 * d, I * max_keys, 2 * d, d, false);
         ka.row_index = keyidx;

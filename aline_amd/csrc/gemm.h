@@ -23,6 +23,7 @@
 struct GemmArgs {
   const float *X; int ldx; int R_in, G_in, off_in;
   const int *row_index;            // optional gather: GEMM row m reads X row row_index[m] (< 0: a zero row)
+  const int *out_index;            // optional scatter: GEMM row m is stored to Y row out_index[m] (< 0: not stored); the rows must be distinct
   const float *W[GEMM_MAX_GROUPS]; const float *bias[GEMM_MAX_GROUPS]; int ldw;
   float *Y; int ldy; int R_out, G_out, off_out; int col_per_group;
   int M, N, K; int relu; int accum;   // accum: Y += result
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs a) {
         if (!(g.z > 0.f)) v.z = 0.f;
         if (!(g.w > 0.f)) v.w = 0.f;
       }
-      const long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
+      long dst = (long)(m / a.R_out) * a.G_out + a.off_out + (m % a.R_out);
+      if (a.out_index) { dst = a.out_index[m]; if (dst < 0) continue; }
       float4 *yp = reinterpret_cast<float4 *>(a.Y + dst * a.ldy + grp * a.col_per_group + n);
       if (a.accum) { const float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       *yp = v;

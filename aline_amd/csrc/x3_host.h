@@ -12,6 +12,94 @@ static int launch_head(const Ctx &c, HeadArgs a) {
   return ALINE_OK;
 }
 
+// weights -> split-f16 fragment pairs
+static int pack_weights(const aline_model &mm, unsigned *img, unsigned *range_flag, hipStream_t st) {
+  const aline_model *m = &mm;
+  PackArgs pa{};
+  pa.L = m->L; pa.F = m->F; pa.C = m->C;
+  for (int l = 0; l < m->L; ++l) {
+    pa.in_proj_w[l] = m->in_proj_w[l]; pa.in_proj_b[l] = m->in_proj_b[l];
+    pa.out_proj_w[l] = m->out_proj_w[l]; pa.out_proj_b[l] = m->out_proj_b[l];
+    pa.lin1_w[l] = m->lin1_w[l]; pa.lin1_b[l] = m->lin1_b[l];
+    pa.lin2_w[l] = m->lin2_w[l]; pa.lin2_b[l] = m->lin2_b[l];
+    pa.n1w[l] = m->norm1_w[l]; pa.n1b[l] = m->norm1_b[l];
+    pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
+  }
+  pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
+  for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
+  pa.out = img; pa.range_flag = range_flag; pa.time_token = m->time_token ? 1 : 0;
+  hipLaunchKernelGGL(pack_kernel, dim3(2048), dim3(256), 0, st, pa);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// ---- forward recompute of the training backward (round 4) -----------------------------------------------------------------
+// The per-op backward of a d = 256 / 512 model needs, per layer, the attention output, both LayerNorm inputs and outputs and the
+// hidden units of every (step, episode) INSTANCE of a chunk.  It used to recompute them with the generic kernels (four GEMMs, the
+// attention kernel and two LayerNorm kernels per layer: 15 % of the d = 256 step); this runs the rollout's own layer kernel over
+// the instances instead (layer_save_kernel: the same arithmetic, plus fp32 stores of those rows).  The buffers are float offsets
+// into the backward workspace.
+struct RecomputePlan { size_t img, in, a, b, kv, keys, kcnt, kx, kpos; };
+static bool recompute_model_ok(const aline_model &m) {
+  return m.precision == ALINE_PREC_F16X3 && m.d == D && m.H == H && m.F % 32 == 0 &&
+         (size_t)NBUF * CHUNK_BYTES + (size_t)layer_params(m.F) * 4 <= 160 * 1024;
+}
+template <class Take>
+static RecomputePlan recompute_plan(const aline_model &m, long I, int N, Take take) {
+  RecomputePlan p{};
+  const long tpe = (N + 15) / 16;
+  const size_t im = (size_t)img_pieces(I * tpe) * 4;
+  p.img = take((size_t)image_words(m.L, m.F, m.C));
+  p.in = take(im); p.a = take(im); p.b = take(im);
+  p.kv = take((size_t)I * KV_EP * 4);
+  p.keys = take((size_t)I * WNK); p.kcnt = take((size_t)I * 2);
+  p.kx = take((size_t)img_pieces(I * (WNK / 16)) * 4);
+  p.kpos = take((size_t)I * tpe * 16 / 2 + 1);
+  return p;
+}
+struct RecomputeRows { float *Q[ALINE_MAX_LAYERS]; long q_ld; float *A[ALINE_MAX_LAYERS], *U1[ALINE_MAX_LAYERS], *X1[ALINE_MAX_LAYERS], *Hid[ALINE_MAX_LAYERS], *U2[ALINE_MAX_LAYERS], *Y[ALINE_MAX_LAYERS]; };
+// g: the instance geometry of the chunk (Geo.inst_B > 0); max_keys <= WNK
+static int recompute(const aline_model *m, const Geo &g, int max_keys, const float *Ex, const float *Ey, int ey_rows, float *ws, const RecomputePlan &pl,
+                     const RecomputeRows &rows, hipStream_t st) {
+  const int I = g.B, N = g.N, F = m->F, tpe = (N + 15) / 16;
+  const long tiles = (long)I * tpe;
+  unsigned *img = reinterpret_cast<unsigned *>(ws + pl.img);
+  u32x4 *XIN = reinterpret_cast<u32x4 *>(ws + pl.in), *XA = reinterpret_cast<u32x4 *>(ws + pl.a), *XB = reinterpret_cast<u32x4 *>(ws + pl.b);
+  u32x4 *KV = reinterpret_cast<u32x4 *>(ws + pl.kv), *KX = reinterpret_cast<u32x4 *>(ws + pl.kx);
+  int *keyrow = reinterpret_cast<int *>(ws + pl.keys), *kcnt = reinterpret_cast<int *>(ws + pl.kcnt);
+  short *keypos = reinterpret_cast<short *>(ws + pl.kpos);
+  AsmArgs aa{};
+  aa.g = g; aa.tpe = tpe; aa.Ex = Ex; aa.Ey = Ey; aa.ey_rows = ey_rows; aa.theta_tokens = m->theta_tokens; aa.X = XIN; aa.range_flag = nullptr;
+  hipLaunchKernelGGL(assemble_kernel, grid1d((size_t)tiles * NKS * 64), dim3(256), 0, st, aa);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(keys_kernel, dim3(I), dim3(256), 0, st, g, tpe, keyrow, kcnt, keypos, XIN, KX);
+  CHECK_LAUNCH();
+  const long lw = layer_words(F);
+  const size_t smem_layer = (size_t)NBUF * CHUNK_BYTES + (size_t)layer_params(F) * 4;
+  const size_t smem_kv = (size_t)NBUF * CHUNK_BYTES + 2 * D * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&layer_save_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_layer);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kv_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
+  const int cus = device_cus();
+  const int nkt2 = 2 * ((std::min(max_keys, WNK) + 31) / 32);
+  const u32x4 *xin = XIN;
+  for (int l = 0; l < m->L; ++l) {
+    u32x4 *xout = (l & 1) ? XB : XA;
+    KvArgs ka{};
+    ka.g = g; ka.tpe = tpe; ka.nkt2 = nkt2; ka.X = KX; ka.img = img + l * lw; ka.F = F; ka.keyrow = keyrow; ka.kcnt = kcnt; ka.KV = KV;
+    ka.ngroups = (int)(((long)I * nkt2 + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL(kv_all_kernel, dim3((unsigned)std::min(ka.ngroups, cus)), dim3(THREADS), smem_kv, st, ka);
+    CHECK_LAUNCH();
+    LayerArgs la{};
+    la.g = g; la.tpe = tpe; la.ngroups = (int)((tiles + WAVES - 1) / WAVES);
+    la.XIN = xin; la.XOUT = xout; la.img = img + l * lw; la.F = F; la.KV = KV; la.kcnt = kcnt; la.range_flag = nullptr; la.keypos = keypos; la.KXout = KX;
+    la.svQ = rows.Q[l]; la.svQ_ld = rows.q_ld; la.svA = rows.A[l]; la.svU1 = rows.U1[l]; la.svX1 = rows.X1[l]; la.svHid = rows.Hid[l]; la.svU2 = rows.U2[l]; la.svY = rows.Y[l];
+    hipLaunchKernelGGL(layer_save_kernel, dim3((unsigned)std::min(la.ngroups, cus)), dim3(THREADS), smem_layer, st, la);
+    CHECK_LAUNCH();
+    xin = xout;
+  }
+  return ALINE_OK;
+}
+
 // Eligibility of the tile-image path of this width (x3: d = 256 / 8 heads of 32, x5: d = 512 / 8 heads of 64) at reference
 // precision -- every product a 3-term f16 split on the matrix pipe.
 static bool eligible(const aline_model &m, const aline_rollout &r) {
@@ -32,23 +120,8 @@ static int rollout(const aline_model *m, const aline_rollout *r, void *ws, size_
 
   hipLaunchKernelGGL(role_init_kernel, grid1d((size_t)r->B * r->P), dim3(256), 0, c.st, r->role, r->B, r->P, r->n_ctx0);
   CHECK_LAUNCH();
-  // weights -> split-f16 fragment pairs (once per rollout)
-  PackArgs pa{};
-  pa.L = m->L; pa.F = F; pa.C = m->C;
-  for (int l = 0; l < m->L; ++l) {
-    pa.in_proj_w[l] = m->in_proj_w[l]; pa.in_proj_b[l] = m->in_proj_b[l];
-    pa.out_proj_w[l] = m->out_proj_w[l]; pa.out_proj_b[l] = m->out_proj_b[l];
-    pa.lin1_w[l] = m->lin1_w[l]; pa.lin1_b[l] = m->lin1_b[l];
-    pa.lin2_w[l] = m->lin2_w[l]; pa.lin2_b[l] = m->lin2_b[l];
-    pa.n1w[l] = m->norm1_w[l]; pa.n1b[l] = m->norm1_b[l];
-    pa.n2w[l] = m->norm2_w[l]; pa.n2b[l] = m->norm2_b[l];
-  }
-  pa.acq_w1 = m->acq_w1; pa.acq_b1 = m->acq_b1; pa.acq_w2 = m->acq_w2; pa.acq_b2 = m->acq_b2;
-  for (int k = 0; k < m->C; ++k) { pa.gmm_w1[k] = m->gmm_w1[k]; pa.gmm_b1[k] = m->gmm_b1[k]; pa.gmm_w2[k] = m->gmm_w2[k]; pa.gmm_b2[k] = m->gmm_b2[k]; }
   unsigned *img = reinterpret_cast<unsigned *>(c.at(c.pl.xImg));
-  pa.out = img; pa.range_flag = c.flag(); pa.time_token = m->time_token ? 1 : 0;
-  hipLaunchKernelGGL(pack_kernel, dim3(2048), dim3(256), 0, c.st, pa);
-  CHECK_LAUNCH();
+  TRY(pack_weights(*m, img, c.flag(), c.st));      // weights -> split-f16 fragment pairs (once per rollout)
   // step-invariant point embeddings (fp32 rows; the generic GEMM runs the same 3-term f16 split)
   {
     Src3 xs{{r->point_x, r->target_x, nullptr}, {r->P, r->n_target_data, 0}};

@@ -226,11 +226,12 @@ __device__ __forceinline__ void store_split8(u32x4 *X, long tile, int ks, int la
 }
 __device__ __forceinline__ void embed_row8(const AsmArgs &a, int b, int row, int c, f32x4 &lo, f32x4 &hi) {
   const Geo &g = a.g;
+  const int eb = g.inst_B > 0 ? b % g.inst_B : b;      // (instance mode of the backward: b is a (step, episode) pair, the embeddings are per episode)
   if (row < g.P + g.n_td) {
-    const float *e = a.Ex + ((long)b * (g.P + g.n_td) + row) * D + c;
+    const float *e = a.Ex + ((long)eb * (g.P + g.n_td) + row) * D + c;
     lo = *reinterpret_cast<const f32x4 *>(e); hi = *reinterpret_cast<const f32x4 *>(e + 16);
     if (row < g.P && is_ctx(g, b, row)) {
-      const float *y = a.Ey + ((long)b * a.ey_rows + row) * D + c;
+      const float *y = a.Ey + ((long)eb * a.ey_rows + row) * D + c;
       lo += *reinterpret_cast<const f32x4 *>(y); hi += *reinterpret_cast<const f32x4 *>(y + 16);
     }
   } else {
@@ -788,6 +789,11 @@ struct LayerArgs {
   u32x4 *zimg; long zrow0;        // last layer: the rows of the target tokens also go to this (dense-row) image
   unsigned *range_flag;           // f16 range guard (common.h)
   const short *keypos; u32x4 *KXout;   // not the last layer: output rows that are keys also go to the next layer's key image
+  // layer_save_kernel (the forward recompute of the per-op backward, round 4): fp32 rows [instance * N + token row][..] of what that
+  // backward reads -- the attention output A, U1 = X + Wo A + bo, X1 = LN1(U1), the hidden units relu(W1 X1 + b1) [.., F], U2 = X1 + W2 h + b2
+  // and the layer output Y = LN2(U2)
+  float *svA, *svU1, *svX1, *svHid, *svU2, *svY;
+  float *svQ; long svQ_ld;      // the (unscaled) Q rows, into the [.., 3 d] buffer whose K | V slices a row-gather GEMM fills for the key rows
 #ifdef X3_STAMPS
   unsigned long long *stamps;     // [8 waves][X3_NSTAMP] of workgroup 0
 #endif
@@ -884,8 +890,8 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[NKS], f16x8 (&ql)[NKS
   }
 }
 
-template <bool LAST>
-__global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
+template <bool LAST, bool SAVE>
+__device__ __forceinline__ void layer_body(const LayerArgs &a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float *prm = reinterpret_cast<float *>(lds + NBUF * CHUNK_BYTES);   // bq bk bv | bo | b1 | b2 | ln1w ln1b ln2w ln2b
   const Geo &G = a.g;
@@ -959,6 +965,12 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #pragma unroll
       for (int h = 0; h < NKS; ++h) {
         const f32x4 c0 = P(32 * h), c1 = P(32 * h + 16);
+        if (SAVE && rowok) {
+          constexpr float QINV = (HD == 64 ? 8.f : 5.65685424949238f) * 0.69314718055994531f;      // sqrt(HD) / log2(e): undoes pack_kernel's qscale
+          float *qp = a.svQ + ((long)b * G.N + rc) * a.svQ_ld + 32 * h + 4 * g;
+          *reinterpret_cast<f32x4 *>(qp) = (y[2 * h] * WINV + c0) * QINV;
+          *reinterpret_cast<f32x4 *>(qp + 16) = (y[2 * h + 1] * WINV + c1) * QINV;
+        }
         split_frag(y[2 * h] * WINV + c0, y[2 * h + 1] * WINV + c1, qh[h], ql[h]);
       }
       if (X3_KV_AHEAD > 1) __builtin_amdgcn_sched_barrier(0);      // (the Q accumulators are dead before more K / V pairs are requested)
@@ -972,6 +984,20 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
       else { HeadKV<4> k0; k0.load(kv, 0); q_epilogue(); attention_tile<4>(qh, ql, kv, nv, k0); }
       X3_LAP(st, 6);
     }
+    const long srow = (long)b * G.N + rc;          // (SAVE) fp32 row of this lane's token
+    if (SAVE && rowok) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        *reinterpret_cast<f32x4 *>(a.svA + srow * D + 32 * ks + 4 * g) = frag_value(qh[ks], ql[ks], 0);
+        *reinterpret_cast<f32x4 *>(a.svA + srow * D + 32 * ks + 16 + 4 * g) = frag_value(qh[ks], ql[ks], 1);
+      }
+    }
+    auto save_rows = [&](float *dst, const f32x4 (&v)[NMT]) {
+      if (SAVE && rowok) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) *reinterpret_cast<f32x4 *>(dst + srow * D + 16 * mt + 4 * g) = v[mt];
+      }
+    };
     // ---- X1 = LN1(X + bo + Wo A): the residual X comes back from L2 a k-step per chunk, into the registers the consumed
     // fragments of the attention output free (it was not kept through the attention: registers) -------------------------
 #pragma unroll
@@ -986,7 +1012,9 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + P(o_bo + 16 * mt) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
+    save_rows(a.svU1, y);
     range_chk += layer_norm(y, P, o_ln1w, o_ln1b);
+    save_rows(a.svX1, y);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) split_frag(y[2 * ks], y[2 * ks + 1], xh[ks], xl[ks]);
     X3_LAP(st, 7);
@@ -1001,6 +1029,10 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
                 h0 = h0 * WINV + c0; h1 = h1 * WINV + c1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h0[r] = relu_nn(h0[r]); h1[r] = relu_nn(h1[r]); }
+                if (SAVE && rowok) {
+                  *reinterpret_cast<f32x4 *>(a.svHid + srow * F + 32 * c + 4 * g) = h0;
+                  *reinterpret_cast<f32x4 *>(a.svHid + srow * F + 32 * c + 16 + 4 * g) = h1;
+                }
                 split_frag(h0, h1, hbh, hbl);
                 X3_LAP(st, 5);
               },
@@ -1015,7 +1047,9 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
       y[mt] = y[mt] * WINV + P(o_b2 + 16 * mt) + frag_value(xh[mt >> 1], xl[mt >> 1], mt & 1);
+    save_rows(a.svU2, y);
     range_chk += layer_norm(y, P, o_ln2w, o_ln2b);
+    save_rows(a.svY, y);
     const bool ztgt = LAST && a.zimg && rowok && r >= G.P;
     const long zr = a.zrow0 + (long)b * n_t + (r - G.P);
     const int kp = (!LAST && rowok) ? a.keypos[(long)b * 16 * a.tpe + r] : -1;
@@ -1051,6 +1085,11 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) {
   }
 #endif
 }
+template <bool LAST>
+__global__ __launch_bounds__(THREADS) void layer_kernel(LayerArgs a) { layer_body<LAST, false>(a); }
+// the same layer with the fp32 side outputs the per-op backward reads (LayerArgs.sv*): its forward recompute at the speed of the
+// rollout's own kernel instead of four generic GEMMs, two LayerNorm kernels and the attention kernel per layer
+__global__ __launch_bounds__(THREADS) void layer_save_kernel(LayerArgs a) { layer_body<false, true>(a); }
 
 // ---- acquisition head (NOUT = 1, model/head.py:27-33) / one GMM head (NOUT = 3, model/head.py:152-186) --------------
 // out[row * out_stride + out_off + j] = w2[j] . relu(W1 z + b1) + b2[j] over the 16-row tiles of an image
