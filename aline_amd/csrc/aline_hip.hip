@@ -1379,7 +1379,7 @@ unsigned *grad_absmax(const BCtx &c, const float *dY, long rows, int cols, int l
 // scale: the word of dY (null: reduce dY here); out_max: a cleared word that receives max |Y| (Y is itself a gradient operand), or null
 int launch_grad_gemm(const BCtx &c, GemmArgs a, const unsigned *scale = nullptr, unsigned *out_max = nullptr) {
   a.out_absmax = out_max;
-  if (bwd_grad_f16(*c.m) && a.K % 4 == 0 && !a.row_index && a.R_in == a.G_in) {
+  if (bwd_grad_f16(*c.m) && a.K % 4 == 0 && (!a.row_index || scale) && a.R_in == a.G_in) {      // (a gathered operand: its scale word comes with it)
     a.xmax_bits = scale ? scale : grad_absmax(c, a.X, a.M, a.K, a.ldx);
     a.range_flag = nullptr;
     return launch_gemm(ALINE_PREC_F16X3, a, 1, c.st);
@@ -1403,8 +1403,9 @@ int gemm_dx(const BCtx &c, const float *dY, int ldy, const float *W, int N, int 
 // dW[N, K] += dY^T X, db[N] += colsum(dY)
 int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, long M,
             int N, int K, int Ry = 1, int Gy = 1, int offy = 0, int Rx = 1, int Gx = 1, int offx = 0, int ldw = 0,
-            const unsigned *scale = nullptr) {
+            const unsigned *scale = nullptr, const int *row_index = nullptr) {
   if (N % 32 || K % 32) return ALINE_EUNSUPPORTED;
+  if (row_index && !(scale && bwd_grad_f16(*c.m) && N % 256 == 0 && K % 256 == 0)) return ALINE_EUNSUPPORTED;      // (callers check: the f16 block kernel only)
   if (bwd_grad_f16(*c.m) && Ry == Gy && N % 256 == 0 && K % 256 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && M < (1l << 40)) {
     // the scaled 3-term f16 split on 256 x 256 blocks (backward.h: gemm_tn_f16_kernel); X may be row-mapped (the point rows of every
     // instance: the acquisition head's first layer), dY is dense
@@ -1416,7 +1417,7 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
       const long ldo = ldw > 0 ? ldw : K;
       f.P = pY; f.ldp = ldy; f.Q = pX; f.ldq = ldx; f.out = dW; f.sa = ldo; f.sb = 1; f.grad_is_p = 1;
       f.nba = N / 256; f.nbb = K / 256;
-      f.colsum = db; f.M = M;
+      f.colsum = db; f.M = M; f.row_index = row_index;
       // rows per workgroup: one workgroup per CU at a time, so the launch is whole rounds of n_cu workgroups -- the row chunk is sized
       // so that chunks x blocks fills r rounds (r the smallest that keeps a chunk <= 4096 rows: 400 workgroups of 4096 rows on 256 CUs
       // were 1.56 rounds that cost 2)
@@ -1504,19 +1505,19 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 
 // head_dim 32 / 64 on the fp32 matrix pipe (attn_bwd_wide.h); *out_max (when asked for) receives the scale word of dQKV
 template <int HD, int NKT>
-static int launch_attention_bwd_wide(const BCtx &c, const float *qkv, const float *dA, const float *aout, float *dqkv, unsigned *mw) {
+static int launch_attention_bwd_wide(const BCtx &c, const float *qkv, const float *dA, const float *aout, float *dqkv, unsigned *mw, int kro) {
   const int H = c.m->d / HD, waves = std::min(H, HD == 64 ? 4 : abww::MAXW);
   const size_t smem = abww::lds_bytes(HD, NKT, c.g.N, waves);
   if (smem > 160 * 1024) return ALINE_EUNSUPPORTED;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abww::attention_bwd_wide_kernel<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((abww::attention_bwd_wide_kernel<HD, NKT>), dim3((unsigned)c.g.B), dim3(64 * waves), smem, c.st, c.g, c.m->d, qkv, dA, aout, dqkv, mw);
+  hipLaunchKernelGGL((abww::attention_bwd_wide_kernel<HD, NKT>), dim3((unsigned)c.g.B), dim3(64 * waves), smem, c.st, c.g, c.m->d, qkv, dA, aout, dqkv, mw, kro);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
 
 template <int HD>
 int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys, const float *aout = nullptr,
-                         unsigned **out_max = nullptr) {
+                         unsigned **out_max = nullptr, bool key_rows_only = false) {
   const bool mfma_on = !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA);      // 0: the VALU kernel (A/B measurements)
   if (out_max) *out_max = nullptr;
   if constexpr (HD == 32 || HD == 64) {
@@ -1526,14 +1527,14 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
       if (out_max) *out_max = mw;
       if constexpr (HD == 32) {
         switch (nkt) {
-          case 1: return launch_attention_bwd_wide<32, 1>(c, qkv, dA, aout, dqkv, mw);
-          case 2: return launch_attention_bwd_wide<32, 2>(c, qkv, dA, aout, dqkv, mw);
-          default: return launch_attention_bwd_wide<32, 3>(c, qkv, dA, aout, dqkv, mw);
+          case 1: return launch_attention_bwd_wide<32, 1>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
+          case 2: return launch_attention_bwd_wide<32, 2>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
+          default: return launch_attention_bwd_wide<32, 3>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
         }
       } else {
-        if (nkt == 1) return launch_attention_bwd_wide<64, 1>(c, qkv, dA, aout, dqkv, mw);
-        if (nkt == 2) return launch_attention_bwd_wide<64, 2>(c, qkv, dA, aout, dqkv, mw);
-        return launch_attention_bwd_wide<64, 3>(c, qkv, dA, aout, dqkv, mw);      // (cfg5: 1 + 29 context + 4 targets = 34 keys)
+        if (nkt == 1) return launch_attention_bwd_wide<64, 1>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
+        if (nkt == 2) return launch_attention_bwd_wide<64, 2>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
+        return launch_attention_bwd_wide<64, 3>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);      // (cfg5: 1 + 29 context + 4 targets = 34 keys)
       }
     }
   }
@@ -1740,7 +1741,11 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     // ... Q too when the matrix-pipe attention backward runs (it reads K / V of the key rows only: those come from a row-gather GEMM on
     // the key list, 16 % of the rows at the d = 256 headline shape, scattered into the [M, 3 d] buffer the kernel indexes by token row)
     const bool rc_q = rc_now && max_keys < N && max_keys <= 48 && (hd == 32 || hd == 64) && !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA);
-    if (rc_q) {
+    // The same key list on the way back: dK / dV are zero outside the key rows, so the in-projection's gradient products split into a
+    // dense Q part (a third of the columns) and a K | V part over the key rows only (gathered by the list; dX scattered back)
+    const bool kv_sparse = do_enc && !ckv && bwd_grad_f16(*m) && !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA) && !dbg(ALINE_DBG_NO_BWD_KV_SPARSE) &&
+                           (hd == 32 || hd == 64) && max_keys <= 48 && max_keys < N && d % 256 == 0;
+    if (rc_q || kv_sparse) {
       hipLaunchKernelGGL(key_list_kernel, dim3(I), dim3(256), 0, c.st, g, max_keys, keyidx, kcnt);
       CHECK_LAUNCH();
     }
@@ -1869,10 +1874,12 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       AcqBwdArgs a{};
       a.g = g; a.F = F; a.hid = HidA; a.w2 = m->acq_w2; a.b2 = m->acq_b2; a.g_logp = g_logp; a.slot = r->slot;
       a.T = r->T; a.dw2 = gr->acq_w2; a.db2 = gr->acq_b2;
+      unsigned *sw_acq = bwd_grad_f16(*m) ? new_scale_word(c) : nullptr;      // (the kernel reduces what it stores: both products below read it)
+      a.out_absmax = sw_acq;
       hipLaunchKernelGGL(acq_bwd_kernel, dim3(I), dim3(256), (size_t)(P + F) * sizeof(float), c.st, a);
       CHECK_LAUNCH();
       const int ldw1 = m->time_token ? d + 1 : d;
-      TRY(gemm_dw(c, HidA, F, Z, d, gr->acq_w1, gr->acq_b1, (long)I * P, F, d, 1, 1, 0, P, N, 0, ldw1));
+      TRY(gemm_dw(c, HidA, F, Z, d, gr->acq_w1, gr->acq_b1, (long)I * P, F, d, 1, 1, 0, P, N, 0, ldw1, sw_acq));
       if (m->time_token) {     // the time column: dW1[f, d] += sum_rows dHidA[row, f] t(row)
         const long rows = (long)I * P, rpb = 512;
         hipLaunchKernelGGL(time_col_grad_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, c.st, HidA, F, rows, P, tvec,
@@ -1884,7 +1891,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       TRY(transpose_to(c, m->acq_w1, F, d, Wt, ldw1));
       GemmArgs ga = gemm_args(HidA, F, Wt, nullptr, F, dX, d, I * P, d, F, false);
       ga.R_out = P; ga.G_out = N; ga.off_out = 0;
-      TRY(launch_grad_gemm(c, ga));
+      TRY(launch_grad_gemm(c, ga, sw_acq));
       CHECK_LAUNCH();
     }
     if (fgmm) {
@@ -2012,11 +2019,26 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
         case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
         case 16: TRY(launch_attention_bwd<16>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
-        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att)); break;
-        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att)); break;
+        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse)); break;
+        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse)); break;
         default: return ALINE_EUNSUPPORTED;
       }
       // in-proj (the matrix-pipe attention backward leaves max |dQKV|; the VALU kernels do not: a reduction pass)
+      if (kv_sparse) {
+        if (!sw_att) return ALINE_EUNSUPPORTED;      // (kv_sparse implies the matrix-pipe kernel ran and left its scale word)
+        const long MK = (long)I * max_keys;
+        TRY(gemm_dw(c, dQKV, 3 * d, Xs(l), d, gr->in_proj_w[l], gr->in_proj_b[l], M, d, d, 1, 1, 0, 1, 1, 0, 0, sw_att));
+        TRY(gemm_dw(c, dQKV + d, 3 * d, Xs(l), d, gr->in_proj_w[l] + (size_t)d * d, gr->in_proj_b[l] + d, MK, 2 * d, d, 1, 1, 0, 1, 1, 0, 0, sw_att, keyidx));
+        TRY(gemm_dx(c, dQKV, 3 * d, m->in_proj_w[l], d, d, dXn, d, (int)M, true, nullptr, sw_att));      // dXn = dX_l: + dQ Wq
+        float *Wt = c.at(c.pl.Wt);
+        TRY(transpose_to(c, m->in_proj_w[l] + (size_t)d * d, 2 * d, d, Wt));
+        GemmArgs ka = gemm_args(dQKV + d, 3 * d, Wt, nullptr, 2 * d, dXn, d, (int)MK, d, 2 * d, false);      // + dK Wk + dV Wv on the key rows
+        ka.accum = 1; ka.row_index = keyidx; ka.out_index = keyidx;
+        TRY(launch_grad_gemm(c, ka, sw_att));
+        CHECK_LAUNCH();
+        std::swap(dX, dXn);
+        continue;
+      }
       const unsigned *sw_qkv = !bwd_grad_f16(*m) ? nullptr : sw_att ? sw_att : grad_absmax(c, dQKV, M, 3 * d, 3 * d);
       TRY(gemm_dw(c, dQKV, 3 * d, Xs(l), d, gr->in_proj_w[l], gr->in_proj_b[l], M, 3 * d, d, 1, 1, 0, 1, 1, 0, 0, sw_qkv));
       TRY(gemm_dx(c, dQKV, 3 * d, m->in_proj_w[l], 3 * d, d, dXn, d, (int)M, true, nullptr, sw_qkv));   // dXn = dX_l

@@ -48,7 +48,7 @@ __device__ __forceinline__ float group16_sum(float v) {
 template <int HD, int NKT>
 __global__ __launch_bounds__(HD == 64 ? 256 : 64 * MAXW) void attention_bwd_wide_kernel(Geo g, int d, const float *__restrict__ QKV, const float *__restrict__ dA,
                                                                        const float *__restrict__ Aout, float *__restrict__ dQKV,
-                                                                       unsigned *out_absmax) {
+                                                                       unsigned *out_absmax, int key_rows_only) {
   constexpr int NS = HD / 4, NCT = HD / 16, PT = pitch<HD>();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = blockDim.x >> 6;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(HD == 64 ? 256 : 64 * MAXW) void attention_bwd_wide
           const f32x4 v = dQT[ct] * scale;
           track(v);
           *reinterpret_cast<f32x4 *>(out + qc + 16 * ct + 4 * fg) = v;
-          if (notkey) {
+          if (notkey && !key_rows_only) {      // (key_rows_only: the in-projection's products read the K | V slices of the key rows alone)
             *reinterpret_cast<f32x4 *>(out + kc + 16 * ct + 4 * fg) = z4;
             *reinterpret_cast<f32x4 *>(out + vc + 16 * ct + 4 * fg) = z4;
           }

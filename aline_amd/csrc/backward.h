@@ -299,6 +299,7 @@ struct GemmTnF16Args {
   int grad_is_p;                      // which operand is the gradient (scaled; its column sums go to colsum)
   const unsigned *xmax_bits;          // bits of max |gradient operand| (absmax_bits_kernel)
   long M, mchunk; int gx, nba, nbb;   // rows, rows per workgroup, row chunks, blocks along a / b
+  const int *row_index;               // optional: product row m is row row_index[m] of BOTH operands (< 0: no row) -- the key rows of every instance
 };
 
 __global__ __launch_bounds__(512, 1) void gemm_tn_f16_kernel(GemmTnF16Args a) {
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f16_kernel(GemmTnF16Args a) {
   float xinv = 1.f;
   const float xscale = f16_operand_scale(*a.xmax_bits, xinv);
   // staging task of this thread: 4 consecutive columns x 8 rows of the combined [32 x 512] slab; waves 0, 2, 4, 6 load P, the others Q
-  const int rg = wave >> 1;                                   // row group 0 .. 3 (rows 8 rg .. 8 rg + 7 of the slab)
+  const int rg = __builtin_amdgcn_readfirstlane(wave >> 1);   // row group 0 .. 3 (rows 8 rg .. 8 rg + 7 of the slab)
   const bool is_p = (wave & 1) == 0;
   const int c4 = 4 * lane;                                    // first of the 4 columns inside the operand's tile
   const float *src = is_p ? a.P + (long)ba * TILE + c4 : a.Q + (long)bb * TILE + c4;
@@ -331,6 +332,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f16_kernel(GemmTnF16Args a) {
   const int mapR = is_p ? a.Rp : a.Rq, mapG = is_p ? a.Gp : a.Gq, mapOff = is_p ? a.offp : a.offq;
   auto load_slab = [&](long m0) {
     const long first = m0 + 8 * rg;
+    if (a.row_index) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ri = first + e < m_hi ? a.row_index[first + e] : -1;      // (wave-uniform)
+        v[e] = ri >= 0 ? *reinterpret_cast<const float4 *>(src + (long)ri * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
     long q = 0;
     int r = 0;
     if (mapR != mapG) { q = first / mapR; r = (int)(first - q * mapR); }      // one division per 8 rows, then a walked remainder
@@ -751,6 +760,7 @@ struct AcqBwdArgs {
   const int *slot;             // [B, T] chosen slot
   int T;
   float *dw2, *db2;
+  unsigned *out_absmax;        // optional: max |gradient written to hid| as bits (the scale word of the f16 gradient products that read it)
 };
 __global__ __launch_bounds__(256) void acq_bwd_kernel(AcqBwdArgs a) {
   extern __shared__ float lds[];   // logits [P], dw2 partial [F]
@@ -797,6 +807,7 @@ __global__ __launch_bounds__(256) void acq_bwd_kernel(AcqBwdArgs a) {
   // lane owns features f0 + lane + 64 n of one block of 512 features at a time.  (Rounds 1-3 handled the first block only: at
   // F = 1024 -- the d = 256 roofline variant -- the hidden units 512.. kept their FORWARD values as "gradient"; found by the
   // round-4 reference-autograd fixture grad_cfg2_d256.)
+  float gmax = 0.f;
   for (int f0 = 0; f0 < F; f0 += 512) {
     float pw[8], w2r[8];
 #pragma unroll
@@ -810,13 +821,19 @@ __global__ __launch_bounds__(256) void acq_bwd_kernel(AcqBwdArgs a) {
         if (f < F) {
           const float hv = hp[f];
           pw[n] = fmaf(dl, hv, pw[n]);
-          hp[f] = hv > 0.f ? dl * w2r[n] : 0.f;
+          const float gv = hv > 0.f ? dl * w2r[n] : 0.f;
+          hp[f] = gv;
+          gmax = fmaxf(gmax, fabsf(gv));
         }
       }
     }
 #pragma unroll
     for (int n = 0; n < 8; ++n)
       if (f0 + lane + 64 * n < F) atomicAdd(&sdw[f0 + lane + 64 * n], pw[n]);
+  }
+  if (a.out_absmax) {
+    gmax = wave_max(gmax);
+    if (lane == 0 && gmax > 0.f) atomicMax(a.out_absmax, __float_as_uint(gmax));
   }
   __syncthreads();
   for (int f = tid; f < F; f += 256) atomicAdd(a.dw2 + f, sdw[f]);

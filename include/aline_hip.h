@@ -314,6 +314,7 @@ enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off 
        ALINE_DBG_CES_GENERIC = 1u << 9,        /* CES likelihood: powf formulation */
        ALINE_DBG_FUSED_STAMPS = 1u << 10,      /* in-kernel phase stamps (diagnostic instantiations) */
        ALINE_DBG_NO_BWD_IMAGE_RECOMPUTE = 1u << 11,  /* per-op backward at d = 256 / 512: forward recompute on the generic kernels instead of x3 / x5 layer_save_kernel */
+       ALINE_DBG_NO_BWD_KV_SPARSE = 1u << 12,  /* per-op backward: the in-projection's gradient products over all rows x all 3 d columns (dK / dV of the non-key rows are zeros) */
        ALINE_DBG_SELECT_WORKGROUP = 1u << 13,  /* design selection: the workgroup-per-episode kernel also where one wave per episode would do */
        /* backward: switch ONE fused kernel back to the per-op pipeline it replaces */
        ALINE_DBG_NO_BWD_TAIL = 1u << 16, ALINE_DBG_NO_BWD_ATTN_BLOCK = 1u << 17, ALINE_DBG_NO_BWD_ACQ = 1u << 18,
