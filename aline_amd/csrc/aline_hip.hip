@@ -1935,6 +1935,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         hipLaunchKernelGGL(gmm_bwd_kernel, dim3((unsigned)((a.rows + GMM_BWD_ROWS - 1) / GMM_BWD_ROWS)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();
       float *Wt = c.at(c.pl.Wt);   // [d, C*F]: column block k = W1_k^T
+      // one scale word for the hidden gradients of all C components (2 C products read them; f16's range below the maximum is 2^28)
+      const unsigned *sw_gmm = bwd_grad_f16(*m) ? grad_absmax(c, HidG, (long)I * n_t, C * F, C * F) : nullptr;
       if (F == 128 && d % 32 == 0 && !dbg(ALINE_DBG_NO_BWD_GMM_BATCHED)) {
         // all C components in one launch each: dW1_k / db1_k (column block k of the hidden gradients), and dz as one K = C F product
         GemmTnArgs ta{};
@@ -1954,11 +1956,11 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         CHECK_LAUNCH();
         GemmArgs ga = gemm_args(HidG, C * F, Wt, nullptr, C * F, dX, d, I * n_t, d, C * F, false);
         ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
-        TRY(launch_grad_gemm(c, ga));
+        TRY(launch_grad_gemm(c, ga, sw_gmm));
       } else {
       for (int k = 0; k < C; ++k) {
         TRY(gemm_dw(c, HidG + (size_t)k * F, C * F, Z, d, gr->gmm_w1[k], gr->gmm_b1[k], (long)I * n_t, F, d, 1, 1, 0,
-                    n_t, N, P));
+                    n_t, N, P, 0, sw_gmm));
         // Wt[kk, k*F + f] = W1_k[f, kk]
         hipLaunchKernelGGL(transpose_kernel, grid1d((size_t)F * d), dim3(256), 0, c.st, m->gmm_w1[k], F, d, d,
                            Wt + (size_t)k * F * d);   // temporarily packed [d, F] blocks, fixed below
@@ -1968,7 +1970,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       for (int k = 0; k < C; ++k) {
         GemmArgs ga = gemm_args(HidG + (size_t)k * F, C * F, Wt + (size_t)k * F * d, nullptr, F, dX, d, I * n_t, d, F, false);
         ga.R_out = n_t; ga.G_out = N; ga.off_out = P; ga.accum = 1;
-        TRY(launch_grad_gemm(c, ga));
+        TRY(launch_grad_gemm(c, ga, sw_gmm));
       }
       }
       CHECK_LAUNCH();

@@ -27,7 +27,7 @@ try:
     print('train %.2f' % b['train_step']['ms_per_step'], 'qgmm %.4g' % b['value_with_query_gmm'], 'f32 %.2f' % b['f32']['ms_per_rollout'])
     for k in ('d256', 'd512'):
         x = b[k]['f16x3']; print(k, '%.2f ms' % x['ms_per_rollout'], 'kernel %.4f ms' % x['roofline']['kernel_ms_per_launch'], 'frac %.4f' % x['roofline']['frac'], 'traffic', x['roofline'].get('traffic'), x.get('train_step'))
-    print('eig', {k: (round(v['frac'], 3), round(v['step_ms'], 3)) for k, v in b['eig'].items() if isinstance(v, dict)})
+    print('eig', {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ('frac', 'step_ms', 'history_ms', 'steps_ms', 'speedup')} for k, v in b['eig'].items() if isinstance(v, dict)})
     c = b['cpu_baseline']; print('cpu', c['value'], c.get('cores'), c.get('train_step', {}).get('value'))
 except Exception as e:
     print('bench summary failed:', repr(e))
