@@ -890,6 +890,9 @@ __device__ __forceinline__ void attention_tile(f16x8 (&qh)[NKS], f16x8 (&ql)[NKS
   }
 }
 
+// fp32 side outputs of layer_save_kernel: written once, read by other kernels much later -- streaming stores
+__device__ __forceinline__ void sv_store(float *p, const f32x4 &v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); }
+
 template <bool LAST, bool SAVE>
 __device__ __forceinline__ void layer_body(const LayerArgs &a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -968,8 +971,8 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a) {
         if (SAVE && rowok) {
           constexpr float QINV = (HD == 64 ? 8.f : 5.65685424949238f) * 0.69314718055994531f;      // sqrt(HD) / log2(e): undoes pack_kernel's qscale
           float *qp = a.svQ + ((long)b * G.N + rc) * a.svQ_ld + 32 * h + 4 * g;
-          *reinterpret_cast<f32x4 *>(qp) = (y[2 * h] * WINV + c0) * QINV;
-          *reinterpret_cast<f32x4 *>(qp + 16) = (y[2 * h + 1] * WINV + c1) * QINV;
+          sv_store(qp, (y[2 * h] * WINV + c0) * QINV);
+          sv_store(qp + 16, (y[2 * h + 1] * WINV + c1) * QINV);
         }
         split_frag(y[2 * h] * WINV + c0, y[2 * h + 1] * WINV + c1, qh[h], ql[h]);
       }
@@ -988,14 +991,14 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a) {
     if (SAVE && rowok) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        *reinterpret_cast<f32x4 *>(a.svA + srow * D + 32 * ks + 4 * g) = frag_value(qh[ks], ql[ks], 0);
-        *reinterpret_cast<f32x4 *>(a.svA + srow * D + 32 * ks + 16 + 4 * g) = frag_value(qh[ks], ql[ks], 1);
+        sv_store(a.svA + srow * D + 32 * ks + 4 * g, frag_value(qh[ks], ql[ks], 0));
+        sv_store(a.svA + srow * D + 32 * ks + 16 + 4 * g, frag_value(qh[ks], ql[ks], 1));
       }
     }
     auto save_rows = [&](float *dst, const f32x4 (&v)[NMT]) {
       if (SAVE && rowok) {
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) *reinterpret_cast<f32x4 *>(dst + srow * D + 16 * mt + 4 * g) = v[mt];
+        for (int mt = 0; mt < NMT; ++mt) sv_store(dst + srow * D + 16 * mt + 4 * g, v[mt]);
       }
     };
     // ---- X1 = LN1(X + bo + Wo A): the residual X comes back from L2 a k-step per chunk, into the registers the consumed
@@ -1030,8 +1033,8 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h0[r] = relu_nn(h0[r]); h1[r] = relu_nn(h1[r]); }
                 if (SAVE && rowok) {
-                  *reinterpret_cast<f32x4 *>(a.svHid + srow * F + 32 * c + 4 * g) = h0;
-                  *reinterpret_cast<f32x4 *>(a.svHid + srow * F + 32 * c + 16 + 4 * g) = h1;
+                  sv_store(a.svHid + srow * F + 32 * c + 4 * g, h0);
+                  sv_store(a.svHid + srow * F + 32 * c + 16 + 4 * g, h1);
                 }
                 split_frag(h0, h1, hbh, hbl);
                 X3_LAP(st, 5);
