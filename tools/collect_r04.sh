@@ -26,6 +26,9 @@ python3 $R/bench.py > $O/bench.json 2> $O/bench.err || { echo "bench failed"; ta
 echo "bench done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_d256_train -- python3 $R/tools/d256_train_run.py > $O/d256_train.log 2>&1 || { echo "d256 train profile failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg3_train -- python3 $R/tools/train_cfg3.py > $O/cfg3_train.log 2>&1 || { echo "cfg3 train profile failed"; exit 1; }
+timeout -k 10 300 python3 $R/tools/train_cfg5.py > $O/cfg5_train.log 2>&1 || echo "cfg5 train failed"
+timeout -k 10 200 python3 $R/tools/d256_train_time.py > $O/d256_train_time.log 2>&1 || echo "d256 train time failed"
+timeout -k 10 200 python3 $R/tools/d256_train_time.py NO_BWD_IMAGE_RECOMPUTE NO_BWD_KV_SPARSE >> $O/d256_train_time.log 2>&1 || echo "d256 train time (switches off) failed"
 timeout -k 10 600 python3 $R/tools/config_bench.py > $O/config_bench.jsonl 2> $O/config_bench.err || { echo "config bench failed"; tail -5 $O/config_bench.err; }
 $R/tools/probes/mfma_f16x3_ceiling 1.5 > $O/ceiling.log 2>&1
 echo "all done"

@@ -19,6 +19,9 @@ for t in ('s3_f16x3_d32', 'x3_f16x3_d256', 'x5_f16x3_d512'):
 for src, dst in (('s3_pmc_cfg2.txt', 'r04_s3_f16x3_d32_pmc_summary.txt'), ('x3_pmc.txt', 'r04_x3_f16x3_d256_pmc_summary.txt'), ('x5_pmc.txt', 'r04_x5_f16x3_d512_pmc_summary.txt')):
     cp(f'{O}/{src}', dst)
 cp(f'{O}/ceiling.log', 'r04_mfma_ceiling_probe_run3.jsonl')
+for f in ('cfg5_train.log', 'd256_train_time.log', 'cfg3_train.log', 'd256_train.log'):
+    if os.path.exists(f'{O}/{f}'):
+        print(f, open(f'{O}/{f}').read().strip().splitlines()[-2:])
 try:
     b = json.load(open('profiles/r04_bench.json'))
     r = b['roofline']
