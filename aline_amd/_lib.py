@@ -136,7 +136,7 @@ lib, SIGNATURES = _load()
 # ---- diagnostics: the library never reads the environment; tests and A/B tools set its diagnostic word explicitly -------
 DBG = {"DISABLE_FUSED": 1 << 0, "DISABLE_X3": 1 << 2, "DISABLE_S3": 1 << 3,
        "NO_LAYER_TAIL": 1 << 5, "FULL_QKV": 1 << 6, "VALU_ATTENTION": 1 << 7, "S3_GENERIC_EMBED": 1 << 8, "CES_GENERIC": 1 << 9,
-       "FUSED_STAMPS": 1 << 10, "NO_BWD_IMAGE_RECOMPUTE": 1 << 11, "NO_BWD_KV_SPARSE": 1 << 12, "SELECT_WORKGROUP": 1 << 13,
+       "FUSED_STAMPS": 1 << 10, "NO_BWD_IMAGE_RECOMPUTE": 1 << 11, "NO_BWD_KV_SPARSE": 1 << 12, "SELECT_WORKGROUP": 1 << 13, "S3_SELECT_KERNEL": 1 << 14,
        "NO_BWD_TAIL": 1 << 16, "NO_BWD_ATTN_BLOCK": 1 << 17, "NO_BWD_ACQ": 1 << 18, "NO_BWD_LAYER_FWD": 1 << 19,
        "NO_BWD_LAYER_FWD_FLAT": 1 << 20, "NO_BWD_GMM_FUSED": 1 << 21, "NO_BWD_GMM128": 1 << 22, "NO_BWD_GMM_BATCHED": 1 << 23,
        "NO_BWD_ATTN_MFMA": 1 << 24, "NO_BWD_DW_WALK": 1 << 25, "NO_BWD_GMM_WIDE": 1 << 26, "NO_BWD_SAVED_ACTS": 1 << 27, "BWD_RECOMPUTE_F32": 1 << 28, "BWD_DW_TK2": 1 << 29, "BWD_GRAD_F32": 1 << 30}

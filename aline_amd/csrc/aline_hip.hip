@@ -581,7 +581,7 @@ static int device_cus() {      // compute units of the CURRENT device (cached pe
 // registers measured 1.5 % slower, ALINE_DBG_S3_WAVES = 16) while an episode never holds more than 64 keys, 8 waves (256
 // registers: all scores of a head pair over 160 keys) otherwise; as many episodes per
 // workgroup as keeps every CU busy and the token tiles spread evenly over the waves.
-struct S3Shape { int nw, nkp, epw; unsigned nwg; size_t lds; };     // nkp: key-tile pairs an episode's LDS slot holds
+struct S3Shape { int nw, nkp, epw; unsigned nwg; size_t lds; bool sel; };     // nkp: key-tile pairs an episode's LDS slot holds; sel: the design selection runs inside the step kernel
 static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
   S3Shape s{};
   const int n_t = r.n_target_data + m.n_theta, N = r.P + n_t, tpe = (N + 15) / 16;
@@ -590,7 +590,9 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
   s.nw = need <= 2 ? 12 : 8;
   if (const int w = dbg_param(ALINE_DBG_S3_WAVES)) s.nw = (w == 16 || w == 12) && need <= 2 ? w : 8;
   s.nkp = s.nw >= 12 ? 2 : s3::NKP_MAX;
-  const int per_ep = s3::kv_ep_bytes(s.nkp) + 32 * s.nkp * 4;
+  // the design selection inside the step kernel (s3.h: SelArgs) while an episode's logits fit its LDS line.  ALINE_DBG_S3_SELECT_KERNEL: the launch of its own
+  s.sel = r.P <= s3::SEL_PMAX && r.role && !dbg(ALINE_DBG_S3_SELECT_KERNEL);
+  const int per_ep = s3::kv_ep_bytes(s.nkp) + 32 * s.nkp * 4 + (s.sel ? s3::SEL_PMAX * 4 : 0);
   const int epw_max = std::max(1, std::min(s3::EPW_MAX, (s3::LDS_LIMIT - s3::KV_OFF - s3::MISC_INTS * 4) / per_ep));
   const int cus = device_cus();
   double best = 1e30;
@@ -603,7 +605,7 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
   }
   if (const int e = dbg_param(ALINE_DBG_S3_EPW)) s.epw = std::max(1, std::min(epw_max, e));
   s.nwg = (unsigned)((r.B + s.epw - 1) / s.epw);
-  s.lds = (size_t)s3::step_lds_bytes(s.epw, s.nkp);
+  s.lds = (size_t)s3::step_lds_bytes(s.epw, s.nkp, s.sel);
   return s;
 }
 
@@ -988,6 +990,19 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
   const bool want_gmm = r->post_mean || r->post_std || r->post_weight || r->target_ll;
   const S3Shape sh = s3_shape(*m, *r);
   u32x4 *Zq = wants_postq(*r) ? reinterpret_cast<u32x4 *>(c.at(c.pl.sZq)) : nullptr;   // candidate rows of all steps
+  const int zw = r->P - r->n_ctx0;
+  // in-kernel selection: the T argument sets live where the logits of the launch of its own would (they stay in LDS)
+  s3::SelArgs *selp = nullptr;
+  if (sh.sel && (size_t)r->T * sizeof(s3::SelArgs) <= (size_t)r->B * tpe * 16 * sizeof(float)) {
+    selp = reinterpret_cast<s3::SelArgs *>(logits);
+    s3::SelArgs q{};
+    q.on = 1; q.mode = r->select_mode; q.uniform = r->uniform;
+    q.forced = r->forced_idx; q.forced_stride = r->T;
+    q.idx = r->idx; q.idx_stride = r->T; q.slot = r->slot; q.slot_stride = r->T; q.log_prob = r->log_prob; q.lp_stride = r->T;
+    q.zt = r->zt; q.zt_stride = zw; q.zt_width = zw; q.role_out = r->role; q.range_flag = c.flag();
+    hipLaunchKernelGGL(s3::sel_args_kernel, dim3((r->T + 63) / 64), dim3(64), 0, c.st, q, (int)r->T, (long)r->B, selp);
+    CHECK_LAUNCH();
+  }
   for (int t = 0; t < r->T; ++t) {
     c.g.n_ctx = r->n_ctx0 + t;
     s3::StepArgs sa{};
@@ -1004,9 +1019,11 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
 #endif
     const bool timed = t == (r->ev_kernel_step > 0 ? r->ev_kernel_step - 1 : r->T - 1);      // bench.py times this launch of the dominant kernel
     if (timed && r->ev_kernel_start) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_start), c.st);
+    sa.selp = selp ? selp + t : nullptr;
     TRY(launch_s3_step(c, sh, sa));
     if (timed && r->ev_kernel_stop) (void)hipEventRecord(static_cast<hipEvent_t>(r->ev_kernel_stop), c.st);
     CHECK_LAUNCH();
+    if (selp) continue;
     SelectArgs sel{};
     sel.g = c.g; sel.F = F; sel.logits = logits; sel.logit_stride = NP;
     sel.mode = r->select_mode;
@@ -1015,7 +1032,6 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     sel.idx = r->idx ? r->idx + t : nullptr; sel.idx_stride = r->T;
     sel.slot = r->slot ? r->slot + t : nullptr; sel.slot_stride = r->T;
     sel.log_prob = r->log_prob ? r->log_prob + t : nullptr; sel.lp_stride = r->T;
-    const int zw = r->P - r->n_ctx0;
     sel.zt = r->zt ? r->zt + (size_t)t * r->B * zw : nullptr; sel.zt_stride = zw; sel.zt_width = zw;
     sel.role_out = r->role;
     TRY(launch_acq_select(c, sel));
@@ -1348,6 +1364,7 @@ struct BCtx {
   BwdPlan pl;
   float *ws;
   hipStream_t st;
+  mutable int scale_next = 0;      // next word of the scale ring (new_scale_word): per call, so that concurrent calls on other streams do not advance it
   float *at(size_t off) const { return ws + off; }
 };
 
@@ -1362,9 +1379,8 @@ int transpose_to(const BCtx &c, const float *W, int rows, int cols, float *dst, 
 // epilogue reduce what they store (one atomicMax per wave) -- or by a reduction pass over the stored tensor (grad_absmax: 190 us per
 // call at the d = 256 headline chunk, 11 % of the step when every product ran its own), and handed to the products that read the tensor.
 // A word lives until the ring comes round: 16 producers later (every consumer follows its producer within three calls).
-static int g_scale_next = 0;
 unsigned *new_scale_word(const BCtx &c) {
-  unsigned *w = reinterpret_cast<unsigned *>(c.at(c.pl.Scale)) + 16 * (g_scale_next++ & 15);
+  unsigned *w = reinterpret_cast<unsigned *>(c.at(c.pl.Scale)) + 16 * (c.scale_next++ & 15);
   hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(16), 0, c.st, w);
   return w;
 }

@@ -64,8 +64,11 @@ constexpr int W_OFF = 0, W_BYTES = 51200;                 // layer_bytes(F_MAX)
 constexpr int HEAD_OFF = W_OFF + W_BYTES, HEAD_BYTES = 19456;   // head_bytes(F_MAX)
 constexpr int KV_OFF = HEAD_OFF + HEAD_BYTES;
 constexpr int MISC_INTS = 2 * EPW_MAX + 32;               // n_ck [epw] | n_ak [epw] | wave counts [4][4] | running [4] | queues [2]
+constexpr int SEL_PMAX = 256;                             // the in-kernel design selection holds an episode's logits in LDS: [epw][SEL_PMAX] floats behind misc
 __host__ __device__ inline int kv_ep_bytes(int nkp) { return nkp * 8192; }
-__host__ __device__ inline int step_lds_bytes(int epw, int nkp) { return KV_OFF + epw * (kv_ep_bytes(nkp) + 32 * nkp * 4) + MISC_INTS * 4; }
+__host__ __device__ inline int step_lds_bytes(int epw, int nkp, bool sel = false) {
+  return KV_OFF + epw * (kv_ep_bytes(nkp) + 32 * nkp * 4) + MISC_INTS * 4 + (sel ? epw * SEL_PMAX * 4 : 0);
+}
 constexpr int LDS_LIMIT = 160 * 1024;
 static_assert(KV_OFF + (NKT_MAX * 4096 + NK_MAX * 4) * 2 + MISC_INTS * 4 <= LDS_LIMIT, "two episodes of 160 keys must fit");
 
@@ -376,6 +379,21 @@ struct Stamps {
 #endif
 
 // ---- one design step of EPW episodes: every encoder layer + the acquisition logits ----------------------------------
+// Design selection of the step (model/head.py:36-60: softmax over the remaining candidates, argmax / Categorical sample / forced index,
+// log-probability, role update) at the end of the step kernel (P <= SEL_PMAX), one wave per episode of the workgroup, instead of a launch
+// of its own (acq_select_wave_kernel: 5.5 us x T of the 2.8 ms headline rollout).  Same arithmetic, same order of operations as that kernel.
+struct SelArgs {
+  int on, mode;                                  // ALINE_SELECT_*
+  const float *uniform;                          // [B] of this step
+  const int64_t *forced; int forced_stride;
+  int64_t *idx; int idx_stride;
+  int *slot; int slot_stride;
+  float *log_prob; int lp_stride;
+  float *zt; int zt_stride, zt_width;
+  int *role_out;
+  unsigned *range_flag;
+};
+
 struct StepArgs {
   Geo g; int tpe, L, F;
   int epw;                         // episodes per workgroup (the LDS slot of an episode holds the variant's MAXNKP key-tile pairs)
@@ -388,11 +406,108 @@ struct StepArgs {
   u32x4 *zimg; long zrow0;         // dense-row image of the target rows of all steps (null: not wanted)
   u32x4 *zq; long zq_row0;         // dense-row image of the P point rows of all steps (null: posterior_out_query not wanted)
   float tau;                       // time token of this step (t / T or (T - t) / T: model/head.py:342-345), 0 without one
+  const SelArgs *selp;             // in-kernel design selection: this step's arguments in device memory (sel_args_kernel), or null: the selection is a launch of its own.
+                                   // (as kernel arguments they cost the tile loop its scalar registers: 98 SGPR spills, the rollout 6 % slower)
   float *sv; long sv_rows, sv_row0;   // aline_rollout.saved_acts (null: not wanted): [2 L + 1][sv_rows][32] fp32; this step's rows start at sv_row0
 #ifdef S3_STAMPS
   unsigned long long *stamps;      // [8 waves][S3_NSTAMP] of workgroup 0
 #endif
 };
+
+// the T argument sets of a rollout's in-kernel selections: the per-step pointers are the rollout's [.., T] arrays advanced by the step
+__global__ void sel_args_kernel(SelArgs base, int T, long B, SelArgs *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  SelArgs q = base;
+  if (q.uniform) q.uniform += (size_t)t * B;
+  if (q.forced) q.forced += t;
+  if (q.idx) q.idx += t;
+  if (q.slot) q.slot += t;
+  if (q.log_prob) q.log_prob += t;
+  if (q.zt) q.zt += (size_t)t * B * q.zt_stride;
+  out[t] = q;
+}
+
+// one wave: the selection of episode b from its logits in LDS (acq_select_wave_kernel, kernels.h, with lg[] read from LDS)
+__device__ __forceinline__ void select_episode(const Geo &G, const SelArgs &a, int b, const float *lgs, int lane) {
+  const int P = G.P;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  float lg[4], pr[4];
+  bool isq[4];
+  int ci[4], nq = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int p = 64 * c + lane;
+    const bool valid = p < P;
+    lg[c] = valid ? lgs[p] : -INFINITY;
+    isq[c] = valid && !is_ctx(G, b, p);
+    const unsigned long long bal = __ballot(isq[c]);
+    ci[c] = nq + __popcll(bal & below);
+    nq += __popcll(bal);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mx = fmaxf(mx, isq[c] ? lg[c] : -INFINITY);
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { pr[c] = isq[c] ? __expf(lg[c] - mx) : 0.f; sum += pr[c]; }
+  sum = wave_sum(sum);
+  if (lane == 0 && !(sum <= 3.4e38f)) range_raise(a.range_flag, ALINE_RANGE_ACT);     // a NaN / +inf logit
+  const float inv = 1.f / sum;
+  float tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { pr[c] *= inv; tot += pr[c]; }
+  tot = wave_sum(tot);
+  if (a.zt) {
+    float *z = a.zt + (long)b * a.zt_stride;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (isq[c] && ci[c] < a.zt_width) z[ci[c]] = pr[c];
+    for (int i = nq + lane; i < a.zt_width; i += 64) z[i] = 0.f;
+  }
+  int choice = 0;
+  if (a.mode == 0) {            // argmax, first maximal index (torch.max semantics)
+    float best = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (isq[c] && (pr[c] > best || (pr[c] == best && ci[c] < bi))) { best = pr[c]; bi = ci[c]; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    choice = bi == 0x7fffffff ? 0 : bi;
+  } else if (a.mode == 2) {
+    choice = (int)a.forced[(long)b * a.forced_stride];
+    choice = min(max(choice, 0), nq - 1);
+  } else {                      // inverse CDF of Categorical(probs = zt / sum zt)
+    const float u = a.uniform[b] * tot;
+    float run = 0.f; int found = nq - 1; bool done = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float incl = pr[c];
+      for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      const unsigned long long bal = __ballot(isq[c] && (run + incl) > u);
+      if (!done && bal) { found = __shfl(ci[c], __ffsll((long long)bal) - 1, 64); done = true; }
+      run += __shfl(incl, 63, 64);
+    }
+    choice = found;
+  }
+  float val = 0.f; int sl = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (isq[c] && ci[c] == choice) { val = pr[c]; sl = 64 * c + lane; }
+  val = wave_sum(val);
+  sl = (int)wave_sum((float)sl);          // (slots < 256: exact in fp32)
+  if (a.mode != 0) val = val / tot;       // Categorical(probs).log_prob uses probs / probs.sum() ...
+  if (lane == 0) {
+    if (a.mode != 0) val = fminf(fmaxf(val, 1.1920929e-07f), 1.f - 1.1920929e-07f);      // ... clamped to [eps, 1 - eps]
+    if (a.idx) a.idx[(long)b * a.idx_stride] = choice;
+    if (a.log_prob) a.log_prob[(long)b * a.lp_stride] = logf(val);
+    if (a.slot) a.slot[(long)b * a.slot_stride] = sl;
+    if (a.role_out) a.role_out[(long)b * P + sl] = (P - nq) + 1;
+  }
+}
 
 // SAVE: the instantiation of training rollouts (StepArgs.sv: layer inputs / attention outputs kept for the backward); the inference
 // instantiation carries none of its registers or branches.
@@ -410,6 +525,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   constexpr int kv_ep = nkp * 8192, kv_v = nkp * 4096, nkcap = 32 * nkp;
   int *keyrow = reinterpret_cast<int *>(lds + KV_OFF + epw * kv_ep), *misc = keyrow + epw * nkcap;
   int *n_ck = misc, *n_ak = misc + EPW_MAX, *wcnt = misc + 2 * EPW_MAX, *run = wcnt + 16, *queue = run + 4;
+  float *lgs = reinterpret_cast<float *>(misc + MISC_INTS);         // (in-kernel selection) logits [epw][SEL_PMAX]
   const char *gimg = reinterpret_cast<const char *>(a.img);
 #ifdef S3_STAMPS
   Stamps stamps{};
@@ -710,7 +826,10 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
             if (GH < NH) __builtin_amdgcn_sched_barrier(0);
           }
           const float v = group_sum4(plog) + hp[4 * F];
-          if (g == 0 && r < G.P) a.logits[(long)b * a.NP + r] = v;
+          if (g == 0 && r < G.P) {
+            if (a.selp) lgs[e * SEL_PMAX + r] = v;
+            else a.logits[(long)b * a.NP + r] = v;
+          }
         }
       }
       S3_LAP(5);
@@ -726,6 +845,13 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
     }
   }
   range_check_nan(a.emb.range_flag, range_chk);
+  // the design selection of the workgroup's episodes, one wave each (behind the last layer's barrier: every logit is in LDS).  Inside the
+  // layer loop -- the waves that run out of tiles selecting for the finished episodes -- it cost the tile loop 69 - 98 scalar-register
+  // spills and the rollout 6 % (profiles/r04_s3_select_in_kernel.txt); here the loop's registers are dead
+  if (a.selp) {
+    const int n_valid = min(epw, G.B - (int)blockIdx.x * epw);
+    for (int e = wave; e < n_valid; e += NW) select_episode(G, *a.selp, blockIdx.x * epw + e, lgs + e * SEL_PMAX, lane);
+  }
 #ifdef S3_STAMPS
   if (a.stamps && blockIdx.x == 0 && lane == 0) {
     stamps.acc[8] = stamps.t_prev - t_begin;

@@ -316,6 +316,7 @@ enum { ALINE_DBG_DISABLE_FUSED = 1u << 0,      /* fused::rollout_f32_kernel off 
        ALINE_DBG_NO_BWD_IMAGE_RECOMPUTE = 1u << 11,  /* per-op backward at d = 256 / 512: forward recompute on the generic kernels instead of x3 / x5 layer_save_kernel */
        ALINE_DBG_NO_BWD_KV_SPARSE = 1u << 12,  /* per-op backward: the in-projection's gradient products over all rows x all 3 d columns (dK / dV of the non-key rows are zeros) */
        ALINE_DBG_SELECT_WORKGROUP = 1u << 13,  /* design selection: the workgroup-per-episode kernel also where one wave per episode would do */
+       ALINE_DBG_S3_SELECT_KERNEL = 1u << 14,  /* s3 path: the design selection as a launch of its own (acq_select_wave_kernel) instead of inside the step kernel */
        /* backward: switch ONE fused kernel back to the per-op pipeline it replaces */
        ALINE_DBG_NO_BWD_TAIL = 1u << 16, ALINE_DBG_NO_BWD_ATTN_BLOCK = 1u << 17, ALINE_DBG_NO_BWD_ACQ = 1u << 18,
        ALINE_DBG_NO_BWD_LAYER_FWD = 1u << 19, ALINE_DBG_NO_BWD_LAYER_FWD_FLAT = 1u << 20,

@@ -210,10 +210,13 @@ def test_time_token_on_the_fused_reference_precision_paths(emb, d, path, reverse
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("select", ["sample", "argmax", "forced"])
-def test_one_wave_per_episode_selection_equals_the_workgroup_kernel(select):
-    """model/head.py:347-362 on the device: `acq_select_wave_kernel` (P <= 256, one wave per episode, no LDS) against `acq_select_kernel`
-    (any P, a workgroup per episode) on the same rollout -- same designs, slots and roles, probabilities / log-probabilities to fp32 rounding
-    (the two sum the softmax in different orders)."""
+def test_in_kernel_and_one_wave_per_episode_selection_equal_the_workgroup_kernel(select):
+    """model/head.py:347-362 on the device, three implementations on the same rollout: the selection at the end of `s3::step_kernel`
+    (round 4: one wave per episode of the workgroup, logits from LDS; the default of the s3 path at P <= 256), `acq_select_wave_kernel`
+    (`ALINE_DBG_S3_SELECT_KERNEL`: a launch of its own, one wave per episode) and `acq_select_kernel` (any P, a workgroup per episode).
+    The first two run the same arithmetic in the same order: bit-equal outputs.  Against the workgroup kernel: same designs, slots and
+    roles, probabilities / log-probabilities to fp32 rounding (it sums the softmax in another order).  B = 37 is not a multiple of the
+    episodes per workgroup (a ragged last workgroup)."""
     from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
     from aline_amd.rollout import Rollout
     from aline_amd.tasks import HiddenLocation
@@ -228,13 +231,15 @@ def test_one_wave_per_episode_selection_equals_the_workgroup_kernel(select):
     if select == "forced":
         kw["forced_idx"] = torch.stack([torch.randint(0, 150 - t, (37,)) for t in range(T)], 1)
     outs = []
-    for flags in ((), ("SELECT_WORKGROUP",)):
+    for flags in ((), ("S3_SELECT_KERNEL",), ("S3_SELECT_KERNEL", "SELECT_WORKGROUP")):
         with _lib.debug(*flags), torch.no_grad():
             ro = Rollout(model, batch, T, select=select, keep_zt=True, **kw).run()
             torch.cuda.synchronize()
         assert ro.path == "s3::step_kernel"
         outs.append((ro.idx.clone(), ro.slot.clone(), ro.log_prob.clone(), ro.zt.clone(), ro.role.clone(), ro.target_ll.clone()))
-    a, b = outs
+    k, a, b = outs
+    for x, y in zip(k, a):
+        assert torch.equal(x, y)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4])
     assert float((a[2] - b[2]).abs().max()) < 2e-6
     assert float((a[3] - b[3]).abs().max()) < 1e-7
