@@ -1457,6 +1457,7 @@ int gemm_dw(const BCtx &c, const float *dY, int ldy, const float *X, int ldx, fl
       return ALINE_OK;
     }
   }
+  if (row_index) return ALINE_EUNSUPPORTED;      // (only the f16 block kernel takes an index list; its conditions did not hold)
   GemmTnArgs a{};
   a.dY = dY; a.ldy = ldy; a.Ry = Ry; a.Gy = Gy; a.offy = offy;
   a.X = X; a.ldx = ldx; a.Rx = Rx; a.Gx = Gx; a.offx = offx;
