@@ -184,3 +184,59 @@ def test_range_status_word_survives_graph_replays_with_eager_launches_in_between
         if i % 100 == 99:
             torch.cuda.synchronize()
             assert ro.ws[:64].view(torch.int32).abs().sum().item() == 0 and ro.range_status() == 0, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,F,B,T,task", [(256, 1024, 1000, 30, "location"), (512, 128, 256, 30, "psychometric")])
+def test_fullsize_training_backward_against_the_exact_fp32_per_op_backward(d, F, B, T, task):
+    """The training backward at the two full-size wide shapes of the bench / config lines (d = 256 / F = 1024 / B = 1000 / T = 30 and cfg5:
+    d = 512 / B = 256 / T = 30, predefined mask): the default path -- forward recompute on `x3 / x5::layer_save_kernel` over 7 500+
+    instances per chunk, scaled-f16 gradient products with producer-emitted scale words, key-row K | V products, matrix-pipe attention
+    backward, chunks sized by the 144 GB workspace -- against the same rollout's gradients with every one of those switched off
+    (generic recompute in exact fp32, exact-fp32 products, VALU attention backward).  The small-shape tests hold each kernel to the
+    reference's autograd; this one holds the launch shapes the numbers are quoted on (whole rounds of row chunks, several chunks of
+    different key counts, index lists of 200 000+ key rows).  Tolerances as in the A/B test of the switches (ReLU gates on a knife's edge
+    move single units between the two recomputes): nothing beyond 3e-3 of a tensor's max |grad|, four tensors in five within 2e-4."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.train import backward, reinforce_terms
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    if task == "location":
+        from aline_amd.tasks import HiddenLocation
+        model = Aline(Embedder(2, 1, d, F, 2, "theta"), Encoder(d, F, 8, 0.0, 3), OutputHead(2, 1, d, F))
+        batch = HiddenLocation(n_query_init=200, device=dev).sample_batch(B)
+        emb, mask = "theta", "all"
+    else:
+        from aline_amd.tasks import PsychometricTask
+        model = Aline(Embedder(1, 1, d, F, 4, "theta"), Encoder(d, F, 8, 0.0, 3), OutputHead(1, 1, d, F))
+        batch = PsychometricTask(n_query_init=200, n_context_init=1, device=dev).sample_batch(B)
+        batch["target_mask"] = torch.tensor([False, False, True, True])
+        emb, mask = "theta", "predefined"
+    model = model.cuda().set_precision("f16x3").train()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    grads = []
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        assert ro.path in ("x3::layer_kernel", "x5::layer_kernel"), ro.path
+        assert ro.range_status() == 0
+        terms = reinforce_terms(ro, emb, mask)
+        for flags in ([], ["NO_BWD_IMAGE_RECOMPUTE", "NO_BWD_KV_SPARSE", "BWD_GRAD_F32", "BWD_RECOMPUTE_F32", "NO_BWD_ATTN_MFMA"]):
+            with _lib.debug(*flags):
+                for p in model.parameters():
+                    p.grad = None
+                backward(model, ro, terms["g_logp"], terms["g_ll"])
+                torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    new, ref = grads
+    floor = 1e-2 * max(float(g.abs().max()) for g in ref.values())
+    errs = {}
+    for k in ref:
+        assert torch.isfinite(new[k]).all(), k
+        errs[k] = float((new[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), floor)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert worst[1] < 3e-3, worst
+    close = sum(e < 2e-4 for e in errs.values())
+    assert close >= 0.8 * len(errs), (close, len(errs), sorted(errs.items(), key=lambda kv: -kv[1])[:6])
