@@ -592,7 +592,7 @@ static S3Shape s3_shape(const aline_model &m, const aline_rollout &r) {
   s.nkp = s.nw >= 12 ? 2 : s3::NKP_MAX;
   // the design selection inside the step kernel (s3.h: SelArgs) while an episode's logits fit its LDS line.  ALINE_DBG_S3_SELECT_KERNEL: the launch of its own
   s.sel = r.P <= s3::SEL_PMAX && r.role && !dbg(ALINE_DBG_S3_SELECT_KERNEL);
-  const int per_ep = s3::kv_ep_bytes(s.nkp) + 32 * s.nkp * 4 + (s.sel ? s3::SEL_PMAX * 4 : 0);
+  const int per_ep = s3::kv_ep_bytes(s.nkp) + 32 * s.nkp * 4 + (s.sel ? s3::SEL_PMAX * 4 + s3::SEL_PMAX / 8 : 0);
   const int epw_max = std::max(1, std::min(s3::EPW_MAX, (s3::LDS_LIMIT - s3::KV_OFF - s3::MISC_INTS * 4) / per_ep));
   const int cus = device_cus();
   double best = 1e30;

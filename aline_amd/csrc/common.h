@@ -49,6 +49,38 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- whole-wave reductions and scan on DPP (row shifts + row broadcasts: ~8 cycles a step; the __shfl_xor forms above go through the LDS
+// crossbar, ~120 cycles a step, and a design selection is a chain of ~36 of them) ----------------------------------------------------
+// dpp_ctrl: row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.  A lane whose source lies outside its row (or that the row /
+// bank mask switches off) gets `idle`.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_f32(float idle, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(idle), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// inclusive prefix sum over the 64 lanes (lane 63: the total)
+__device__ __forceinline__ float wave_scan_sum(float v) {
+  v += dpp_f32<0x111, 0xf, 0xf>(0.f, v);
+  v += dpp_f32<0x112, 0xf, 0xf>(0.f, v);
+  v += dpp_f32<0x114, 0xf, 0xf>(0.f, v);
+  v += dpp_f32<0x118, 0xf, 0xf>(0.f, v);
+  v += dpp_f32<0x142, 0xa, 0xf>(0.f, v);      // rows 1, 3 += lane 15 of rows 0, 2
+  v += dpp_f32<0x143, 0xc, 0xf>(0.f, v);      // rows 2, 3 += lane 31
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_sum(v)), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f32<0x111, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x112, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x114, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x118, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xa, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x143, 0xc, 0xf>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ float softplus_f(float x) {
   // torch.nn.functional.softplus(beta=1, threshold=20)
   return x > 20.f ? x : log1pf(expf(x));

@@ -542,17 +542,17 @@ __global__ __launch_bounds__(256) void acq_select_wave_kernel(SelectArgs a) {
   float mx = -INFINITY;
 #pragma unroll
   for (int c = 0; c < 4; ++c) mx = fmaxf(mx, isq[c] ? lg[c] : -INFINITY);
-  mx = wave_max(mx);
+  mx = wave_max_dpp(mx);
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) { pr[c] = isq[c] ? __expf(lg[c] - mx) : 0.f; sum += pr[c]; }
-  sum = wave_sum(sum);
+  sum = wave_sum_dpp(sum);
   if (lane == 0 && !(sum <= 3.4e38f)) range_raise(a.range_flag, ALINE_RANGE_ACT);     // a NaN / +inf logit
   const float inv = 1.f / sum;
   float tot = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) { pr[c] *= inv; tot += pr[c]; }
-  tot = wave_sum(tot);
+  tot = wave_sum_dpp(tot);
   if (a.zt) {
     float *z = a.zt + (long)b * a.zt_stride;
 #pragma unroll
@@ -576,24 +576,29 @@ __global__ __launch_bounds__(256) void acq_select_wave_kernel(SelectArgs a) {
     choice = min(max(choice, 0), nq - 1);
   } else {                      // inverse CDF of Categorical(probs = zt / sum zt)
     const float u = a.uniform[b] * tot;
+    float incl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) incl[c] = wave_scan_sum(pr[c]);      // (four independent DPP scans)
     float run = 0.f; int found = nq - 1; bool done = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float incl = pr[c];
-      for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-      const unsigned long long bal = __ballot(isq[c] && (run + incl) > u);
-      if (!done && bal) { found = __shfl(ci[c], __ffsll((long long)bal) - 1, 64); done = true; }
-      run += __shfl(incl, 63, 64);
+      const unsigned long long bal = __ballot(isq[c] && (run + incl[c]) > u);
+      if (!done && bal) { found = __builtin_amdgcn_readlane(ci[c], __builtin_amdgcn_readfirstlane(__ffsll((long long)bal) - 1)); done = true; }
+      run += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl[c]), 63));
     }
     choice = found;
   }
   // probability and point slot of the chosen query (one lane holds it)
-  float val = 0.f; int sl = 0;
+  float val = 0.f; int sl = 0;      // (exactly one lane of one chunk holds the chosen candidate: read it, no reduction)
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (isq[c] && ci[c] == choice) { val = pr[c]; sl = 64 * c + lane; }
-  val = wave_sum(val);
-  sl = (int)wave_sum((float)sl);          // (slots < 256: exact in fp32)
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long hit = __ballot(isq[c] && ci[c] == choice);
+    if (hit) {
+      const int ln = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+      val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr[c]), ln));
+      sl = 64 * c + ln;
+    }
+  }
   if (a.mode != 0) val = val / tot;       // Categorical(probs).log_prob uses probs / probs.sum() ...
   if (lane == 0) {
     if (a.mode != 0) val = fminf(fmaxf(val, 1.1920929e-07f), 1.f - 1.1920929e-07f);      // ... clamped to [eps, 1 - eps]

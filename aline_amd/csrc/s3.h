@@ -67,7 +67,7 @@ constexpr int MISC_INTS = 2 * EPW_MAX + 32;               // n_ck [epw] | n_ak [
 constexpr int SEL_PMAX = 256;                             // the in-kernel design selection holds an episode's logits in LDS: [epw][SEL_PMAX] floats behind misc
 __host__ __device__ inline int kv_ep_bytes(int nkp) { return nkp * 8192; }
 __host__ __device__ inline int step_lds_bytes(int epw, int nkp, bool sel = false) {
-  return KV_OFF + epw * (kv_ep_bytes(nkp) + 32 * nkp * 4) + MISC_INTS * 4 + (sel ? epw * SEL_PMAX * 4 : 0);
+  return KV_OFF + epw * (kv_ep_bytes(nkp) + 32 * nkp * 4) + MISC_INTS * 4 + (sel ? epw * (SEL_PMAX * 4 + SEL_PMAX / 8) : 0);      // logits + context bit masks
 }
 constexpr int LDS_LIMIT = 160 * 1024;
 static_assert(KV_OFF + (NKT_MAX * 4096 + NK_MAX * 4) * 2 + MISC_INTS * 4 <= LDS_LIMIT, "two episodes of 160 keys must fit");
@@ -429,8 +429,10 @@ __global__ void sel_args_kernel(SelArgs base, int T, long B, SelArgs *__restrict
 }
 
 // one wave: the selection of episode b from its logits in LDS (acq_select_wave_kernel, kernels.h, with lg[] read from LDS)
-__device__ __forceinline__ void select_episode(const Geo &G, const SelArgs &a, int b, const float *lgs, int lane) {
+__device__ __forceinline__ void select_episode(const Geo &G, const SelArgs &a, int b, const float *lgs, const unsigned long long *cmask, int lane) {
+  // cmask[c]: bit l = point 64 c + l is a context point (the ballots of the step's prologue): no role reads, no ballots here
   const int P = G.P;
+  const float u01 = a.mode == 1 ? a.uniform[b] : 0.f;      // (requested first: it lands while the softmax runs)
   const unsigned long long below = (1ull << lane) - 1ull;
   float lg[4], pr[4];
   bool isq[4];
@@ -438,27 +440,28 @@ __device__ __forceinline__ void select_episode(const Geo &G, const SelArgs &a, i
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int p = 64 * c + lane;
-    const bool valid = p < P;
-    lg[c] = valid ? lgs[p] : -INFINITY;
-    isq[c] = valid && !is_ctx(G, b, p);
-    const unsigned long long bal = __ballot(isq[c]);
+    const int nv = min(max(P - 64 * c, 0), 64);
+    const unsigned long long valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+    const unsigned long long bal = valid & ~cmask[c];       // the remaining candidates of this chunk
+    lg[c] = p < P ? lgs[p] : -INFINITY;
+    isq[c] = (bal >> lane) & 1ull;
     ci[c] = nq + __popcll(bal & below);
     nq += __popcll(bal);
   }
   float mx = -INFINITY;
 #pragma unroll
   for (int c = 0; c < 4; ++c) mx = fmaxf(mx, isq[c] ? lg[c] : -INFINITY);
-  mx = wave_max(mx);
+  mx = wave_max_dpp(mx);
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) { pr[c] = isq[c] ? __expf(lg[c] - mx) : 0.f; sum += pr[c]; }
-  sum = wave_sum(sum);
+  sum = wave_sum_dpp(sum);
   if (lane == 0 && !(sum <= 3.4e38f)) range_raise(a.range_flag, ALINE_RANGE_ACT);     // a NaN / +inf logit
   const float inv = 1.f / sum;
   float tot = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) { pr[c] *= inv; tot += pr[c]; }
-  tot = wave_sum(tot);
+  tot = wave_sum_dpp(tot);
   if (a.zt) {
     float *z = a.zt + (long)b * a.zt_stride;
 #pragma unroll
@@ -481,24 +484,29 @@ __device__ __forceinline__ void select_episode(const Geo &G, const SelArgs &a, i
     choice = (int)a.forced[(long)b * a.forced_stride];
     choice = min(max(choice, 0), nq - 1);
   } else {                      // inverse CDF of Categorical(probs = zt / sum zt)
-    const float u = a.uniform[b] * tot;
+    const float u = u01 * tot;
+    float incl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) incl[c] = wave_scan_sum(pr[c]);      // (four independent DPP scans)
     float run = 0.f; int found = nq - 1; bool done = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float incl = pr[c];
-      for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-      const unsigned long long bal = __ballot(isq[c] && (run + incl) > u);
-      if (!done && bal) { found = __shfl(ci[c], __ffsll((long long)bal) - 1, 64); done = true; }
-      run += __shfl(incl, 63, 64);
+      const unsigned long long bal = __ballot(isq[c] && (run + incl[c]) > u);
+      if (!done && bal) { found = __builtin_amdgcn_readlane(ci[c], __builtin_amdgcn_readfirstlane(__ffsll((long long)bal) - 1)); done = true; }
+      run += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl[c]), 63));
     }
     choice = found;
   }
-  float val = 0.f; int sl = 0;
+  float val = 0.f; int sl = 0;      // (exactly one lane of one chunk holds the chosen candidate: read it, no reduction)
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (isq[c] && ci[c] == choice) { val = pr[c]; sl = 64 * c + lane; }
-  val = wave_sum(val);
-  sl = (int)wave_sum((float)sl);          // (slots < 256: exact in fp32)
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long hit = __ballot(isq[c] && ci[c] == choice);
+    if (hit) {
+      const int ln = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+      val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr[c]), ln));
+      sl = 64 * c + ln;
+    }
+  }
   if (a.mode != 0) val = val / tot;       // Categorical(probs).log_prob uses probs / probs.sum() ...
   if (lane == 0) {
     if (a.mode != 0) val = fminf(fmaxf(val, 1.1920929e-07f), 1.f - 1.1920929e-07f);      // ... clamped to [eps, 1 - eps]
@@ -526,6 +534,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   int *keyrow = reinterpret_cast<int *>(lds + KV_OFF + epw * kv_ep), *misc = keyrow + epw * nkcap;
   int *n_ck = misc, *n_ak = misc + EPW_MAX, *wcnt = misc + 2 * EPW_MAX, *run = wcnt + 16, *queue = run + 4;
   float *lgs = reinterpret_cast<float *>(misc + MISC_INTS);         // (in-kernel selection) logits [epw][SEL_PMAX]
+  unsigned long long *cmask = reinterpret_cast<unsigned long long *>(lgs + epw * SEL_PMAX);      // ... and context bit masks [epw][SEL_PMAX / 64] (MISC_INTS is even: 8-byte aligned)
   const char *gimg = reinterpret_cast<const char *>(a.img);
 #ifdef S3_STAMPS
   Stamps stamps{};
@@ -553,6 +562,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
       const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
       if (key && k < nkcap) list[k] = p;
       n += __popcll(bal);
+      if (a.selp && lane == 0 && c0 < SEL_PMAX) cmask[e * (SEL_PMAX / 64) + (c0 >> 6)] = bal;
     }
     n = min(n, nkcap);
     if (lane == 0) n_ck[e] = n;
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(StepArgs a) {
   // spills and the rollout 6 % (profiles/r04_s3_select_in_kernel.txt); here the loop's registers are dead
   if (a.selp) {
     const int n_valid = min(epw, G.B - (int)blockIdx.x * epw);
-    for (int e = wave; e < n_valid; e += NW) select_episode(G, *a.selp, blockIdx.x * epw + e, lgs + e * SEL_PMAX, lane);
+    for (int e = wave; e < n_valid; e += NW) select_episode(G, *a.selp, blockIdx.x * epw + e, lgs + e * SEL_PMAX, cmask + e * (SEL_PMAX / 64), lane);
   }
 #ifdef S3_STAMPS
   if (a.stamps && blockIdx.x == 0 && lane == 0) {
