@@ -640,20 +640,23 @@ static int launch_s3_step(const Ctx &c, const S3Shape &sh, const s3::StepArgs &a
     default: return ALINE_EUNSUPPORTED;
   }
 }
+// the x rows and the y rows of a rollout in ONE launch (two were 2 x 42 us at the headline shape, most of it ramp: each workgroup packs its W2 pairs first)
 template <int F>
-static int launch_s3_embed_f(const Ctx &c, const s3::EmbArgs &a) {
-  const long ntiles = ((long)a.B * a.rows_per_ep + 15) / 16;
+static int launch_s3_embed_f(const Ctx &c, const s3::EmbArgs &a, const s3::EmbArgs &b) {
+  const long ta = ((long)a.B * a.rows_per_ep + 15) / 16, tb = ((long)b.B * b.rows_per_ep + 15) / 16;
   // (every workgroup first packs the W2 fragment pairs into LDS: a few workgroups per CU that walk the tiles, not one per 4 tiles)
-  hipLaunchKernelGGL(s3::embed_kernel<F>, dim3((unsigned)std::min<long>((ntiles + 3) / 4, 4L * device_cus())), dim3(256), 0, c.st, a);
+  const long cap = 2L * device_cus();
+  const unsigned na = (unsigned)std::max<long>(1, std::min<long>((ta + 3) / 4, cap)), nb = (unsigned)std::max<long>(1, std::min<long>((tb + 3) / 4, cap));
+  hipLaunchKernelGGL(s3::embed_kernel<F>, dim3(na + nb), dim3(256), 0, c.st, a, b, na);
   CHECK_LAUNCH();
   return ALINE_OK;
 }
-static int launch_s3_embed(const Ctx &c, int F, const s3::EmbArgs &a) {
+static int launch_s3_embed(const Ctx &c, int F, const s3::EmbArgs &a, const s3::EmbArgs &b) {
   switch (F) {
-    case 32: return launch_s3_embed_f<32>(c, a);
-    case 64: return launch_s3_embed_f<64>(c, a);
-    case 96: return launch_s3_embed_f<96>(c, a);
-    case 128: return launch_s3_embed_f<128>(c, a);
+    case 32: return launch_s3_embed_f<32>(c, a, b);
+    case 64: return launch_s3_embed_f<64>(c, a, b);
+    case 96: return launch_s3_embed_f<96>(c, a, b);
+    case 128: return launch_s3_embed_f<128>(c, a, b);
     default: return ALINE_EUNSUPPORTED;
   }
 }
@@ -976,8 +979,7 @@ static int rollout_s3(const aline_model *m, const aline_rollout *r, void *ws, si
     if (dbg(ALINE_DBG_S3_GENERIC_EMBED)) {       // (A/B: the generic hidden-layer kernel + GEMM pair)
       TRY(do_embed_points(c, ex.src, r->point_y, r->P));
     } else {
-      TRY(launch_s3_embed(c, F, ex));
-      TRY(launch_s3_embed(c, F, ey));
+      TRY(launch_s3_embed(c, F, ex, ey));
     }
   }
   u32x4 *X0 = reinterpret_cast<u32x4 *>(c.at(c.pl.sX0)), *XW = reinterpret_cast<u32x4 *>(c.at(c.pl.sXW));

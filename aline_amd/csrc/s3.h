@@ -200,15 +200,14 @@ struct EmbArgs {
   float *E;                             // [B * rows_per_ep, D] fp32 rows
   unsigned *range_flag;                 // f16 range guard: W2, and (through the assembled input image) the hidden units
 };
+// bid / nwg: this workgroup's index among the nwg that embed `a` (embed_kernel embeds two row sets -- x and y -- in one launch)
 template <int F>
-__global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
+__device__ __forceinline__ void embed_body(const EmbArgs &a, unsigned bid, unsigned nwg, unsigned *wimg, float *prm) {
   constexpr int NH = F / 16, PAIRS = F / 16;
-  __shared__ __attribute__((aligned(16))) unsigned wimg[PAIRS * PAIR_WORDS];
-  __shared__ float prm[D + F + F * 8];                       // b2 | b1 | w1 [F][K]
   const int tid = threadIdx.x, lane = tid & 63, tok = lane & 15, g = lane >> 4, wave = tid >> 6;
   for (int e = tid; e < PAIRS * PAIR_WORDS; e += 256) {      // pair (c, m) = k-step c of output tile m
     const int p = e / PAIR_WORDS;
-    wimg[e] = x3::pair_word(a.w2, F, 16 * (p & 1), p >> 1, e % PAIR_WORDS, WSCALE, blockIdx.x == 0 ? a.range_flag : nullptr);
+    wimg[e] = x3::pair_word(a.w2, F, 16 * (p & 1), p >> 1, e % PAIR_WORDS, WSCALE, bid == 0 ? a.range_flag : nullptr);
   }
   for (int i = tid; i < D; i += 256) prm[i] = a.b2[i];
   for (int i = tid; i < F; i += 256) prm[D + i] = a.b1[i];
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
   const long total = (long)a.B * a.rows_per_ep, ntiles = (total + 15) / 16;
   const int K = a.K;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+  for (long tile = (long)bid * 4 + wave; tile < ntiles; tile += (long)nwg * 4) {
     const long row = 16 * tile + tok, rr = min(row, total - 1);
     const int b = rr / a.rows_per_ep, p = rr % a.rows_per_ep;
     const float *x;
@@ -255,6 +254,14 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbArgs a) {
       *reinterpret_cast<f32x4 *>(e + 16 + 4 * g) = y1 * WINV + ld4(b2 + 16 + 4 * g);
     }
   }
+}
+// the first nwg_a workgroups embed `a` (the x rows), the rest `b` (the y rows; nwg_a == gridDim.x: one row set only)
+template <int F>
+__global__ __launch_bounds__(256) void embed_kernel(EmbArgs a, EmbArgs b, unsigned nwg_a) {
+  __shared__ __attribute__((aligned(16))) unsigned wimg[(F / 16) * PAIR_WORDS];
+  __shared__ float prm[D + F + F * 8];                       // b2 | b1 | w1 [F][K]
+  if (blockIdx.x < nwg_a) embed_body<F>(a, blockIdx.x, nwg_a, wimg, prm);
+  else embed_body<F>(b, blockIdx.x - nwg_a, gridDim.x - nwg_a, wimg, prm);
 }
 
 // (a, b) = LayerNorm over the 32 features of each token: 8 values per lane x 4 lane groups, fp32, two passes
