@@ -658,9 +658,13 @@ def main():
                  "frac_vs_instruction_mix_peak": achieved_tflops * 3 / PEAK_BF16_DENSE_TFLOPS,
                  "whole_rollout_tflops": fl_ep * args.batch * args.steps / (dev_ms * 1e-3) / 1e12,
                  "achieved_vs_fp32_mfma_peak": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                 "kernel_scope": "since round 4 the launch also holds the design selection of its episodes (one wave per episode behind "
+                                 "the last layer's barrier, ~2.5 us of the launch; before: acq_select_wave_kernel, 5.5 us per step on "
+                                 "its own): the rollout got 2.5 % faster, this kernel-level fraction ~3 % lower for the same FLOPs "
+                                 "(profiles/r04_s3_select_in_kernel.txt)",
                  "limiting_resource": "vector issue, not the matrix pipe: at d = 32 a token tile needs ~900 vector instructions per "
                                       "layer (f16 hi/lo splits of every activation, LayerNorm, softmax) beside ~100 MFMAs; PMC of "
-                                      "this launch (profiles/r03_s3_f16x3_d32_pmc_summary.txt): VALU busy 69 %, matrix pipe busy 33 %",
+                                      "this launch (profiles/r04_s3_f16x3_d32_pmc_summary.txt): VALU busy 57 - 70 %, matrix pipe busy 27 - 33 %",
                  "peak_note": "dense f16 MFMA peak (MI355X_MICROARCH.md).  Every product is a 3-term f16 split (reference "
                               "precision): the pipe can deliver at most peak / 3 in this mode (instruction_mix_peak).  "
                               "achieved_vs_fp32_mfma_peak: the same fp32-grade FLOP rate against the 157 TFLOP/s of the fp32 "
