@@ -1606,6 +1606,14 @@ int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, 
     a.dwo = gr->out_proj_w[l]; a.dbo = gr->out_proj_b[l]; a.dw1 = gr->lin1_w[l]; a.db1 = gr->lin1_b[l];
     a.dw2 = gr->lin2_w[l]; a.db2 = gr->lin2_b[l]; a.dg1 = gr->norm1_w[l]; a.de1 = gr->norm1_b[l];
     a.dg2 = gr->norm2_w[l]; a.de2 = gr->norm2_b[l];
+    if (m.precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32)) {
+      // the tile program on the f16 matrix pipe (tail_bwd.h: tail16_kernel), every gradient scaled by the power of two of max |dY|
+      a.dy_max_bits = grad_absmax(c, dY, M, tailbwd::D, tailbwd::D);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS * (int)sizeof(float));
+      hipLaunchKernelGGL(tailbwd::tail16_kernel, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);
+      CHECK_LAUNCH();
+      return ALINE_OK;
+    }
     hipLaunchKernelGGL(tailbwd::tail_kernel<true>, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);   // 434 registers: one wave per SIMD
   }
   CHECK_LAUNCH();

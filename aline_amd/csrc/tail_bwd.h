@@ -56,6 +56,7 @@ struct Args {
   long M;
   const float *wo, *bo, *w1, *b1, *w2, *b2, *g1, *e1, *g2, *e2;
   float *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dg1, *de1, *dg2, *de2;     // accumulated into (+=)
+  const unsigned *dy_max_bits;  // tail16_kernel: bits of max |dY| (absmax_bits_kernel): the power-of-two scale of every gradient in the tile program
 #if defined(TAIL_STAMPS)      // (tools/probes/tail_probe.hip: s_memtime deltas per phase, wave 0 of workgroup 0)
   unsigned long long *stamps;
 #endif
@@ -460,5 +461,284 @@ __global__ __launch_bounds__(LDSACC ? 64 * WAVES_ACC : THREADS) void tail_kernel
   }
 }
 
+
+
+// ---- round 4: the backward tile program on the f16 matrix pipe (tail16_kernel) -------------------------------------------------------
+// The same program, layouts and accumulators as tail_kernel<true>; every group of four v_mfma_f32_16x16x4_f32 over one 16 x 16 operand
+// block (k = 16: 128 pipe cycles) becomes the 3-term f16 split of the forward kernels on v_mfma_f32_16x16x16_f16 (hi * hi + hi * lo +
+// lo * hi): the T / N blocks of the fp32 program ARE the k = 4 g .. 4 g + 3 operand slices of that instruction, register for register.
+//   * weights: the LDS images hold, in the 16 bytes of four consecutive k, the f16 hi halves and the f16 lo halves of W * 2^8 (one
+//     ds_read_b128 per fragment as before; 2^8 keeps the lo halves of small weights normal; the accumulators are divided where they are read);
+//   * activations and gradients are split where they are produced (8 vector instructions per block, reused by every output tile);
+//   * the backward is LINEAR in dY: dY is multiplied once, at the load, by the power of two that puts max |dY| into [2^4, 2^5) (a
+//     reduction pass over dY in front of the launch: Args.dy_max_bits) -- f16 holds such values with 22 bits down to 2^-14 of the maximum
+//     and leaves 2^11 of head room for the tile program's own growth (LayerNorm backward: rstd * gamma per stage) -- and every result
+//     (dA, dU1, the 36 dW tiles, bias and LayerNorm gradients) is divided by it at the end.  An overflow would make the results
+//     non-finite, never silently wrong; the training loop refuses a non-finite gradient norm.
+// 3.4 ms -> see DESIGN.md section 7 for the measured figure; tail_kernel<true> stays as the exact-fp32 reference (ALINE_DBG_BWD_GRAD_F32).
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+struct H8 { h4 hi, lo; };
+__device__ __forceinline__ H8 split4(const f32x4 &v) {
+  H8 o;
+  o.hi = __builtin_convertvector(v, h4);
+  o.lo = __builtin_convertvector(v - __builtin_convertvector(o.hi, f32x4), h4);
+  return o;
+}
+__device__ __forceinline__ H8 as_h8(const f32x4 &raw) {      // an LDS weight fragment: words 0, 1 = hi halves, 2, 3 = lo halves
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 a = {__float_as_uint(raw[0]), __float_as_uint(raw[1])}, b = {__float_as_uint(raw[2]), __float_as_uint(raw[3])};
+  H8 o;
+  o.hi = __builtin_bit_cast(h4, a);
+  o.lo = __builtin_bit_cast(h4, b);
+  return o;
+}
+#define MFMA16O(acc, a, b)                                               \
+  do {                                                                   \
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);     \
+    __builtin_amdgcn_sched_barrier(0x7F6);                               \
+  } while (0)
+constexpr float WSC = 256.f, WINV16 = 1.f / 256.f;
+// acc[ob] += 2^8 W[16 ob + tok][16 kb + 4 g + r] * in[kb][r]
+template <int NOB, int NKB>
+__device__ __forceinline__ void mm_fwd16(f32x4 (&acc)[NOB], const float *W, int pitch, const H8 (&in)[NKB], int tok, int g) {
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    H8 w[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) w[ob] = as_h8(ld4(W + (16 * ob + tok) * pitch + 16 * kb + 4 * g));
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) MFMA16O(acc[ob], w[ob].lo, in[kb].hi);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) MFMA16O(acc[ob], w[ob].hi, in[kb].lo);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) MFMA16O(acc[ob], w[ob].hi, in[kb].hi);
+  }
+}
+__device__ __forceinline__ void mm_dw4_16(f32x4 &c0, f32x4 &c1, f32x4 &c2, f32x4 &c3, const H8 &a0, const H8 &b0, const H8 &a1,
+                                          const H8 &b1, const H8 &a2, const H8 &b2, const H8 &a3, const H8 &b3) {
+  MFMA16O(c0, a0.lo, b0.hi); MFMA16O(c1, a1.lo, b1.hi); MFMA16O(c2, a2.lo, b2.hi); MFMA16O(c3, a3.lo, b3.hi);
+  MFMA16O(c0, a0.hi, b0.lo); MFMA16O(c1, a1.hi, b1.lo); MFMA16O(c2, a2.hi, b2.lo); MFMA16O(c3, a3.hi, b3.lo);
+  MFMA16O(c0, a0.hi, b0.hi); MFMA16O(c1, a1.hi, b1.hi); MFMA16O(c2, a2.hi, b2.hi); MFMA16O(c3, a3.hi, b3.hi);
+}
+// image of a [rows][cols] matrix M(r, c) = src[r * sr + c * sc]: 16 bytes per four consecutive c = (hi x 4 | lo x 4) of 2^8 M
+__device__ __forceinline__ void pack_image16(float *dst, int pitch, const float *src, int rows, int cols, int sr, int sc, int tid, int nthr) {
+  const int gpr = cols >> 2;
+  for (int i = tid; i < rows * gpr; i += nthr) {
+    const int r = i / gpr, q = i - r * gpr;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = src[(long)r * sr + (long)(4 * q + j) * sc] * WSC;
+    const H8 h = split4(v);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 a = __builtin_bit_cast(u2, h.hi), b = __builtin_bit_cast(u2, h.lo);
+    *reinterpret_cast<f32x4 *>(dst + r * pitch + 4 * q) = (f32x4){__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(b[0]), __uint_as_float(b[1])};
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void tail16_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  pack_image16(lds + L_WO, PW, a.wo, D, D, D, 1, tid, THREADS);
+  pack_image16(lds + L_W1, PW, a.w1, F, D, D, 1, tid, THREADS);
+  pack_image16(lds + L_W2, PW2, a.w2, D, F, F, 1, tid, THREADS);
+  pack_image16(lds + L_WOT, PW, a.wo, D, D, 1, D, tid, THREADS);        // Wo^T [32][36]
+  pack_image16(lds + L_W1T, PW2, a.w1, D, F, 1, D, tid, THREADS);       // W1^T [32][132]
+  pack_image16(lds + L_W2T, PW, a.w2, F, D, 1, F, tid, THREADS);        // W2^T [128][36]
+  if (tid < F) lds[L_PRM + P_B1 + tid] = a.b1[tid];
+  if (tid < D) {
+    lds[L_PRM + P_BO + tid] = a.bo[tid]; lds[L_PRM + P_B2 + tid] = a.b2[tid];
+    lds[L_PRM + P_G1 + tid] = a.g1[tid]; lds[L_PRM + P_E1 + tid] = a.e1[tid];
+    lds[L_PRM + P_G2 + tid] = a.g2[tid]; lds[L_PRM + P_E2 + tid] = a.e2[tid];
+  }
+  __syncthreads();
+  // the scale of the gradients: max |dY| * gs in [2^4, 2^5)
+  float gs = 1.f, ginv = 1.f;
+  {
+    const unsigned b = *a.dy_max_bits;
+    const int e = (int)(b >> 23);
+    if (b != 0 && e < 255) {
+      int k = 4 + 127 - e;
+      k = k > 126 ? 126 : (k < -126 ? -126 : k);
+      gs = __uint_as_float((unsigned)(127 + k) << 23);
+      ginv = __uint_as_float((unsigned)(127 - k) << 23);
+    }
+  }
+  f32x4 gWo[2][2], gW1[8][2], gW2[2][8];
+  f32x4 gG1[2], gE1[2], gG2[2], gE2[2];
+  float gBo[2], gB1[8], gB2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gWo[i][j] = fused::zero4();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gW1[j][i] = fused::zero4(); gW2[i][j] = fused::zero4(); }
+    gG1[i] = gE1[i] = gG2[i] = gE2[i] = fused::zero4();
+    gBo[i] = gB2[i] = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gB1[j] = 0.f;
+
+  const long ntiles = (a.M + 15) / 16;
+  const long tstep = (long)gridDim.x * WAVES;
+  f32x4 nx[2], na[2], ndy[2];
+  auto load_tile = [&](long tile) {
+    const long r = min(tile * 16 + tok, a.M - 1);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      nx[mt] = ld4(a.X + r * D + 16 * mt + 4 * g);
+      na[mt] = ld4(a.A + r * D + 16 * mt + 4 * g);
+      ndy[mt] = ld4(a.dY + r * D + 16 * mt + 4 * g);
+    }
+  };
+  if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const float *W = lds + zoff, *prm = W + L_PRM;
+    float *scr = lds + zoff + L_SCR + wave * SCR;
+    const long row = tile * 16 + tok;
+    const bool ok = row < a.M;
+    f32x4 x[2], at[2], dy[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      x[mt] = nx[mt];
+      at[mt] = na[mt];
+      dy[mt] = ok ? ndy[mt] * gs : fused::zero4();
+    }
+    if (tile + tstep < ntiles) load_tile(tile + tstep);
+    // ---- forward ---------------------------------------------------------------------------------------------
+    H8 atS[2] = {split4(at[0]), split4(at[1])};
+    f32x4 n1[2] = {fused::zero4(), fused::zero4()};
+    mm_fwd16<2, 2>(n1, W + L_WO, PW, atS, tok, g);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) n1[mt] = n1[mt] * WINV16 + ld4(prm + P_BO + 16 * mt + 4 * g) + x[mt];
+    const float rstd1 = normalise(n1);
+    f32x4 x1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) x1[mt] = n1[mt] * ld4(prm + P_G1 + 16 * mt + 4 * g) + ld4(prm + P_E1 + 16 * mt + 4 * g);
+    H8 x1S[2] = {split4(x1[0]), split4(x1[1])};
+    f32x4 h[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) h[ob] = fused::zero4();
+    mm_fwd16<8, 2>(h, W + L_W1, PW, x1S, tok, g);
+    H8 hS[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+      const f32x4 b1v = ld4(prm + P_B1 + 16 * ob + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[ob][r] = relu_nn(fmaf(h[ob][r], WINV16, b1v[r]));
+      hS[ob] = split4(h[ob]);
+    }
+    f32x4 n2[2] = {fused::zero4(), fused::zero4()};
+    mm_fwd16<2, 8>(n2, W + L_W2, PW2, hS, tok, g);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) n2[mt] = n2[mt] * WINV16 + ld4(prm + P_B2 + 16 * mt + 4 * g) + x1[mt];
+    const float rstd2 = normalise(n2);
+    // ---- backward (every gradient below carries the factor gs) ---------------------------------------------------
+    f32x4 du2[2];
+    ln_backward(du2, dy, n2, rstd2, prm + P_G2, gG2, gE2, g);
+    f32x4 du2N[2], x1N[2];
+    to_n2(du2N, x1N, du2[0], du2[1], x1[0], x1[1], scr, tok, g);
+    gB2[0] += sum4(du2N[0]); gB2[1] += sum4(du2N[1]);
+    const H8 du2S[2] = {split4(du2[0]), split4(du2[1])};
+    const H8 du2NS[2] = {split4(du2N[0]), split4(du2N[1])}, x1NS[2] = {split4(x1N[0]), split4(x1N[1])};
+    f32x4 dx1a[2] = {fused::zero4(), fused::zero4()};      // W1^T dh, in units of 2^8
+    auto dh_chunk = [&](f32x4 (&dh)[2], int kc) {
+      dh[0] = dh[1] = fused::zero4();
+      mm_fwd16<2, 2>(dh, W + L_W2T + 32 * kc * PW, PW, du2S, tok, g);
+    };
+    f32x4 dhc[2];
+    dh_chunk(dhc, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dhc[j][r] = h[j][r] > 0.f ? dhc[j][r] * WINV16 : 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      f32x4 hN[2], dhN[2];
+      to_n2(hN, dhN, h[2 * kc], h[2 * kc + 1], dhc[0], dhc[1], scr, tok, g);
+      const H8 dhcS[2] = {split4(dhc[0]), split4(dhc[1])};
+      mm_fwd16<2, 2>(dx1a, W + L_W1T + 32 * kc, PW2, dhcS, tok, g);
+      f32x4 dhn[2];
+      if (kc < 3) dh_chunk(dhn, kc + 1);
+      const H8 hNS[2] = {split4(hN[0]), split4(hN[1])}, dhNS[2] = {split4(dhN[0]), split4(dhN[1])};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        mm_dw4_16(gW2[0][2 * kc + j], gW2[1][2 * kc + j], gW1[2 * kc + j][0], gW1[2 * kc + j][1], du2NS[0], hNS[j], du2NS[1], hNS[j],
+                  dhNS[j], x1NS[0], dhNS[j], x1NS[1]);
+        gB1[2 * kc + j] += sum4(dhN[j]);
+      }
+      if (kc < 3) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dhc[j][r] = h[2 * kc + 2 + j][r] > 0.f ? dhn[j][r] * WINV16 : 0.f;
+      }
+    }
+    f32x4 dx1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) dx1[mt] = du2[mt] + dx1a[mt] * WINV16;
+    f32x4 du1[2];
+    ln_backward(du1, dx1, n1, rstd1, prm + P_G1, gG1, gE1, g);
+    const H8 du1S[2] = {split4(du1[0]), split4(du1[1])};
+    f32x4 da[2] = {fused::zero4(), fused::zero4()};
+    mm_fwd16<2, 2>(da, W + L_WOT, PW, du1S, tok, g);
+    if (ok) {
+      const float dsc = WINV16 * ginv;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        *reinterpret_cast<f32x4 *>(a.dA + row * D + 16 * mt + 4 * g) = da[mt] * dsc;
+        *reinterpret_cast<f32x4 *>(a.dU + row * D + 16 * mt + 4 * g) = du1[mt] * ginv;
+      }
+    }
+    f32x4 du1N[2], aN[2];
+    to_n2(du1N, aN, du1[0], du1[1], at[0], at[1], scr, tok, g);
+    const H8 du1NS[2] = {split4(du1N[0]), split4(du1N[1])}, aNS[2] = {split4(aN[0]), split4(aN[1])};
+    mm_dw4_16(gWo[0][0], gWo[0][1], gWo[1][0], gWo[1][1], du1NS[0], aNS[0], du1NS[0], aNS[1], du1NS[1], aNS[0], du1NS[1], aNS[1]);
+    gBo[0] += sum4(du1N[0]); gBo[1] += sum4(du1N[1]);
+  }
+  // ---- the workgroup's gradients (divided by the gradient scale): LDS staging, then one atomic per element -----------------
+  float *const stg = lds;
+  __syncthreads();
+  for (int i = tid; i < G_TOT; i += THREADS) stg[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) atomicAdd(&stg[G_WO + (16 * i + 4 * g + r) * D + 16 * j + tok], gWo[i][j][r] * ginv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&stg[G_W1 + (16 * j + 4 * g + r) * D + 16 * i + tok], gW1[j][i][r] * ginv);
+        atomicAdd(&stg[G_W2 + (16 * i + 4 * g + r) * F + 16 * j + tok], gW2[i][j][r] * ginv);
+      }
+      atomicAdd(&stg[G_PRM + P_G1 + 16 * i + 4 * g + r], gG1[i][r] * ginv);
+      atomicAdd(&stg[G_PRM + P_E1 + 16 * i + 4 * g + r], gE1[i][r] * ginv);
+      atomicAdd(&stg[G_PRM + P_G2 + 16 * i + 4 * g + r], gG2[i][r] * ginv);
+      atomicAdd(&stg[G_PRM + P_E2 + 16 * i + 4 * g + r], gE2[i][r] * ginv);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    atomicAdd(&stg[G_PRM + P_BO + 16 * i + tok], gBo[i] * ginv);
+    atomicAdd(&stg[G_PRM + P_B2 + 16 * i + tok], gB2[i] * ginv);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(&stg[G_PRM + P_B1 + 16 * j + tok], gB1[j] * ginv);
+  __syncthreads();
+  for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwo + i, stg[G_WO + i]);
+  for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1 + i, stg[G_W1 + i]);
+  for (int i = tid; i < D * F; i += THREADS) unsafeAtomicAdd(a.dw2 + i, stg[G_W2 + i]);
+  if (tid < F) unsafeAtomicAdd(a.db1 + tid, stg[G_PRM + P_B1 + tid]);
+  if (tid < D) {
+    unsafeAtomicAdd(a.dbo + tid, stg[G_PRM + P_BO + tid]);
+    unsafeAtomicAdd(a.db2 + tid, stg[G_PRM + P_B2 + tid]);
+    unsafeAtomicAdd(a.dg1 + tid, stg[G_PRM + P_G1 + tid]);
+    unsafeAtomicAdd(a.de1 + tid, stg[G_PRM + P_E1 + tid]);
+    unsafeAtomicAdd(a.dg2 + tid, stg[G_PRM + P_G2 + tid]);
+    unsafeAtomicAdd(a.de2 + tid, stg[G_PRM + P_E2 + tid]);
+  }
+}
 
 }  // namespace tailbwd
