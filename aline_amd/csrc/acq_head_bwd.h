@@ -27,7 +27,10 @@ struct Args {
   long M;
   const float *w1, *b1, *w2, *b2;
   float *dw1, *db1, *dw2;
+  const unsigned *g_max_bits;   // bwd16_kernel: bits of max |dLoss/dlogit| (dlogit_kernel's DlArgs.out_absmax)
 };
+// bwd16_kernel (round 4: the products on the f16 matrix pipe, tail_bwd.h): the W1 image packed as f16 (hi | lo) quads, and its transpose
+constexpr int PW2 = tailbwd::PW2, L_W1T = L_SCR + WAVES * SCR, LDS_FLOATS16 = L_W1T + D * PW2;
 
 using fused::ld4;
 using fused::group_sum;
@@ -74,13 +77,14 @@ struct DlArgs {
   const int32_t *slot;     // [B, T] chosen slot
   int T;
   float *db2;
+  unsigned *out_absmax;    // optional: max |dLoss/dlogit| as bits (the gradient scale of bwd16_kernel)
 };
 // one wave per instance at a time (persistent waves: the db2 sums leave as one atomic per wave, not per instance --
 // 30 000 adds to one address were most of the 0.39 ms this kernel took)
 __global__ __launch_bounds__(256) void dlogit_kernel(DlArgs a) {
   const int lane = threadIdx.x & 63;
   const int P = a.g.P, N = a.g.N;
-  float dbl = 0.f;
+  float dbl = 0.f, amax = 0.f;
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < a.g.B; i += gridDim.x * 4) {
     const int b = i % a.g.inst_B, t = a.g.inst_t0 + i / a.g.inst_B;
     float *lg = a.logit + (long)i * N;
@@ -97,10 +101,15 @@ __global__ __launch_bounds__(256) void dlogit_kernel(DlArgs a) {
       if (p < P && !is_ctx(a.g, i, p)) dl = gl * ((p == chosen ? 1.f : 0.f) - __expf(lg[p] - mx) * inv);
       lg[p] = dl;
       dbl += dl;
+      amax = fmaxf(amax, fabsf(dl));
     }
   }
   dbl = wave_sum(dbl);
   if (lane == 0) atomicAdd(a.db2, dbl);
+  if (a.out_absmax) {
+    amax = wave_max(amax);
+    if (lane == 0 && amax > 0.f) atomicMax(a.out_absmax, __float_as_uint(amax));
+  }
 }
 
 __global__ __launch_bounds__(THREADS) void bwd_kernel(Args a) {
@@ -186,6 +195,100 @@ __global__ __launch_bounds__(THREADS) void bwd_kernel(Args a) {
   if (tid < F) { unsafeAtomicAdd(a.db1 + tid, lds[F * D + tid]); unsafeAtomicAdd(a.dw2 + tid, lds[F * D + F + tid]); }
 }
 
+// bwd_kernel with every product a 3-term f16 split on v_mfma_f32_16x16x16_f16 (tail_bwd.h: tail16_kernel has the scheme): dLoss/dlogit is
+// multiplied by the power of two of its maximum at the load, dz and the weight gradients are divided by it at the end.
+__global__ __launch_bounds__(THREADS) void bwd16_kernel(Args a) {
+  using tailbwd::H8;
+  using tailbwd::split4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
+  tailbwd::pack_image16(lds + L_W1, PW, a.w1, F, D, D, 1, tid, THREADS);
+  tailbwd::pack_image16(lds + L_W1T, PW2, a.w1, D, F, 1, D, tid, THREADS);
+  if (tid < F) { lds[L_B1 + tid] = a.b1[tid]; lds[L_W2 + tid] = a.w2[tid]; }
+  __syncthreads();
+  float ginv;
+  const float gs = tailbwd::grad_scale16(*a.g_max_bits, ginv);
+  f32x4 gW1[8][2], gw2[8];
+  float gB1[8];
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) { gW1[ob][0] = gW1[ob][1] = gw2[ob] = zero4(); gB1[ob] = 0.f; }
+  const long ntiles = (a.M + 15) / 16;
+  const long tstep = (long)gridDim.x * WAVES;
+  f32x4 nz[2];
+  float ndl;
+  auto load_tile = [&](long tile) {
+    const long rn = min(tile * 16 + tok, a.M - 1);
+    nz[0] = ld4(a.Z + rn * D + 4 * g); nz[1] = ld4(a.Z + rn * D + 16 + 4 * g);
+    ndl = a.logit[rn];
+  };
+  if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const float *W = lds + zoff;
+    float *scr = lds + zoff + L_SCR + wave * SCR;
+    const long row = tile * 16 + tok;
+    const bool ok = row < a.M;
+    const f32x4 z[2] = {nz[0], nz[1]};
+    const float dl = ok ? ndl * gs : 0.f;
+    if (tile + tstep < ntiles) load_tile(tile + tstep);
+    const H8 zS[2] = {split4(z[0]), split4(z[1])};
+    f32x4 h[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) h[ob] = zero4();
+    tailbwd::mm_fwd16<8, 2>(h, W + L_W1, PW, zS, tok, g);
+    H8 dhS[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+      const f32x4 w2 = ld4(W + L_W2 + 16 * ob + 4 * g), b1v = ld4(W + L_B1 + 16 * ob + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = relu_nn(fmaf(h[ob][r], tailbwd::WINV16, b1v[r]));
+        gw2[ob][r] = fmaf(dl, hv, gw2[ob][r]);
+        h[ob][r] = hv > 0.f ? dl * w2[r] : 0.f;
+      }
+      dhS[ob] = split4(h[ob]);
+    }
+    f32x4 dz[2] = {zero4(), zero4()};
+    tailbwd::mm_fwd16<2, 8>(dz, W + L_W1T, PW2, dhS, tok, g);
+    if (ok) {
+      const float dsc = tailbwd::WINV16 * ginv;
+      *reinterpret_cast<f32x4 *>(a.dZ + row * D + 4 * g) = dz[0] * dsc;
+      *reinterpret_cast<f32x4 *>(a.dZ + row * D + 16 + 4 * g) = dz[1] * dsc;
+    }
+    f32x4 zN[2], dhN[2];
+    tailbwd::to_n2(zN, dhN, z[0], z[1], h[0], h[1], scr, tok, g);
+    const H8 zNS[2] = {split4(zN[0]), split4(zN[1])};
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      f32x4 nxt[2];
+      if (kc < 3) tailbwd::to_n(nxt, h[2 * kc + 2], h[2 * kc + 3], scr, tok, g);
+      const H8 dhNS[2] = {split4(dhN[0]), split4(dhN[1])};
+      tailbwd::mm_dw4_16(gW1[2 * kc][0], gW1[2 * kc][1], gW1[2 * kc + 1][0], gW1[2 * kc + 1][1], dhNS[0], zNS[0], dhNS[0], zNS[1],
+                         dhNS[1], zNS[0], dhNS[1], zNS[1]);
+      gB1[2 * kc] += tailbwd::sum4(dhN[0]);
+      gB1[2 * kc + 1] += tailbwd::sum4(dhN[1]);
+      if (kc < 3) { dhN[0] = nxt[0]; dhN[1] = nxt[1]; }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < F * D + 2 * F; i += THREADS) lds[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(&lds[(16 * ob + 4 * g + r) * D + tok], gW1[ob][0][r] * ginv);
+      atomicAdd(&lds[(16 * ob + 4 * g + r) * D + 16 + tok], gW1[ob][1][r] * ginv);
+      atomicAdd(&lds[F * D + F + 16 * ob + 4 * g + r], gw2[ob][r] * ginv);
+    }
+    atomicAdd(&lds[F * D + 16 * ob + tok], gB1[ob] * ginv);
+  }
+  __syncthreads();
+  for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1 + i, lds[i]);
+  if (tid < F) { unsafeAtomicAdd(a.db1 + tid, lds[F * D + tid]); unsafeAtomicAdd(a.dw2 + tid, lds[F * D + F + tid]); }
+}
+
 }  // namespace acqb
 
 // ---- GMM head (model/head.py:152-186, utils/eval.py:200-207) in the training backward, the same way ------------------------
@@ -217,7 +320,9 @@ struct Args {
   float std_min;
   const float *value; long value_mod;
   const float *g_ll, *g_mean, *g_std, *g_wgt;
+  unsigned *draw_absmax;         // optional: max |draw| as bits, written by draw_kernel: the gradient scale of bwd16_kernel
 };
+constexpr int PW2 = tailbwd::PW2, L_W1T = L_SCR + WAVES * SCR, LDS_FLOATS16 = L_W1T + D * PW2;      // (bwd16_kernel: + the transposed W1 image)
 
 using fused::ld4;
 using fused::group_sum;
@@ -302,6 +407,12 @@ __global__ __launch_bounds__(256) void draw_kernel(Args a) {
       d[c][0] = d0; d[c][1] = dsd * (1.f / (1.f + __expf(-r1[c]))); d[c][2] = d2;
       *reinterpret_cast<f32x4 *>(a.draw + (q * a.C + c) * 4) = (f32x4){d[c][0], d[c][1], d[c][2], 0.f};
     }
+  }
+  if (a.draw_absmax) {
+    float am = 0.f;
+    if (ok) for (int c = 0; c < a.C; ++c) am = fmaxf(am, fmaxf(fabsf(d[c][0]), fmaxf(fabsf(d[c][1]), fabsf(d[c][2]))));
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(a.draw_absmax, __float_as_uint(am));
   }
   // db2: wave sums, then one LDS add per wave and value (48 values), one global atomic per block and value
   for (int c = 0; c < a.C; ++c)
@@ -394,6 +505,105 @@ __global__ __launch_bounds__(THREADS) void bwd_kernel(Args a) {
       for (int o = 0; o < 3; ++o) atomicAdd(&lds[F * D + F + o * F + 16 * ob + 4 * g + r], gw2[o][ob][r]);
     }
     atomicAdd(&lds[F * D + 16 * ob + tok], gB1[ob]);
+  }
+  __syncthreads();
+  for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1[c] + i, lds[i]);
+  if (tid < F) unsafeAtomicAdd(a.db1[c] + tid, lds[F * D + tid]);
+  for (int i = tid; i < 3 * F; i += THREADS) unsafeAtomicAdd(a.dw2[c] + i, lds[F * D + F + i]);
+}
+
+// bwd_kernel on the f16 matrix pipe (as acqb::bwd16_kernel): dLoss/draw scaled by the power of two of its maximum (draw_kernel)
+__global__ __launch_bounds__(THREADS) void bwd16_kernel(Args a) {
+  using tailbwd::H8;
+  using tailbwd::split4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4, c = blockIdx.y;
+  tailbwd::pack_image16(lds + L_W1, PW, a.w1[c], F, D, D, 1, tid, THREADS);
+  tailbwd::pack_image16(lds + L_W1T, PW2, a.w1[c], D, F, 1, D, tid, THREADS);
+  if (tid < F) lds[L_B1 + tid] = a.b1[c][tid];
+  for (int i = tid; i < 3 * F; i += THREADS) lds[L_W2 + i] = a.w2[c][i];
+  __syncthreads();
+  float ginv;
+  const float gs = tailbwd::grad_scale16(*a.draw_absmax, ginv);
+  f32x4 gW1[8][2], gw2[3][8];
+  float gB1[8];
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) { gW1[ob][0] = gW1[ob][1] = gw2[0][ob] = gw2[1][ob] = gw2[2][ob] = zero4(); gB1[ob] = 0.f; }
+  const long ntiles = (a.rows + 15) / 16;
+  float *dzc = a.dzc + (long)c * a.rows * D;
+  const long tstep = (long)gridDim.x * WAVES;
+  f32x4 nz[2], ndr;
+  auto load_tile = [&](long tile) {
+    const long qn = min(tile * 16 + tok, a.rows - 1), zr = token_row(a, qn);
+    nz[0] = ld4(a.Z + zr * D + 4 * g); nz[1] = ld4(a.Z + zr * D + 16 + 4 * g);
+    ndr = ld4(a.draw + (qn * a.C + c) * 4);
+  };
+  if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
+  for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const float *W = lds + zoff;
+    float *scr = lds + zoff + L_SCR + wave * SCR;
+    const long q = tile * 16 + tok;
+    const bool ok = q < a.rows;
+    const f32x4 z[2] = {nz[0], nz[1]};
+    const f32x4 dr = ok ? ndr * gs : zero4();
+    if (tile + tstep < ntiles) load_tile(tile + tstep);
+    const H8 zS[2] = {split4(z[0]), split4(z[1])};
+    f32x4 h[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) h[ob] = zero4();
+    tailbwd::mm_fwd16<8, 2>(h, W + L_W1, PW, zS, tok, g);
+    H8 dhS[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+      const f32x4 w0 = ld4(W + L_W2 + 16 * ob + 4 * g), w1 = ld4(W + L_W2 + F + 16 * ob + 4 * g), w2 = ld4(W + L_W2 + 2 * F + 16 * ob + 4 * g);
+      const f32x4 b1v = ld4(W + L_B1 + 16 * ob + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = relu_nn(fmaf(h[ob][r], tailbwd::WINV16, b1v[r]));
+        gw2[0][ob][r] = fmaf(dr[0], hv, gw2[0][ob][r]);
+        gw2[1][ob][r] = fmaf(dr[1], hv, gw2[1][ob][r]);
+        gw2[2][ob][r] = fmaf(dr[2], hv, gw2[2][ob][r]);
+        h[ob][r] = hv > 0.f ? fmaf(dr[0], w0[r], fmaf(dr[1], w1[r], dr[2] * w2[r])) : 0.f;      // dh
+      }
+      dhS[ob] = split4(h[ob]);
+    }
+    f32x4 dz[2] = {zero4(), zero4()};
+    tailbwd::mm_fwd16<2, 8>(dz, W + L_W1T, PW2, dhS, tok, g);
+    if (ok) {
+      const float dsc = tailbwd::WINV16 * ginv;
+      *reinterpret_cast<f32x4 *>(dzc + q * D + 4 * g) = dz[0] * dsc;
+      *reinterpret_cast<f32x4 *>(dzc + q * D + 16 + 4 * g) = dz[1] * dsc;
+    }
+    f32x4 zN[2], dhN[2];
+    tailbwd::to_n2(zN, dhN, z[0], z[1], h[0], h[1], scr, tok, g);
+    const H8 zNS[2] = {split4(zN[0]), split4(zN[1])};
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      f32x4 nxt[2];
+      if (kc < 3) tailbwd::to_n(nxt, h[2 * kc + 2], h[2 * kc + 3], scr, tok, g);
+      const H8 dhNS[2] = {split4(dhN[0]), split4(dhN[1])};
+      tailbwd::mm_dw4_16(gW1[2 * kc][0], gW1[2 * kc][1], gW1[2 * kc + 1][0], gW1[2 * kc + 1][1], dhNS[0], zNS[0], dhNS[0], zNS[1],
+                         dhNS[1], zNS[0], dhNS[1], zNS[1]);
+      gB1[2 * kc] += tailbwd::sum4(dhN[0]);
+      gB1[2 * kc + 1] += tailbwd::sum4(dhN[1]);
+      if (kc < 3) { dhN[0] = nxt[0]; dhN[1] = nxt[1]; }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < F * D + F + 3 * F; i += THREADS) lds[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(&lds[(16 * ob + 4 * g + r) * D + tok], gW1[ob][0][r] * ginv);
+      atomicAdd(&lds[(16 * ob + 4 * g + r) * D + 16 + tok], gW1[ob][1][r] * ginv);
+#pragma unroll
+      for (int o = 0; o < 3; ++o) atomicAdd(&lds[F * D + F + o * F + 16 * ob + 4 * g + r], gw2[o][ob][r] * ginv);
+    }
+    atomicAdd(&lds[F * D + 16 * ob + tok], gB1[ob] * ginv);
   }
   __syncthreads();
   for (int i = tid; i < F * D; i += THREADS) unsafeAtomicAdd(a.dw1[c] + i, lds[i]);

@@ -1891,10 +1891,19 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       const long groups = ((M + 15) / 16 + acqb::WAVES - 1) / acqb::WAVES;
       hipLaunchKernelGGL(acqb::logit_kernel, dim3((unsigned)std::min<long>(groups, 256 * 4)), dim3(acqb::THREADS), acqb::LDS_FLOATS_LOGIT * sizeof(float), c.st, a);
       CHECK_LAUNCH();
+      // F16X3 models: the products of the head kernels on the f16 matrix pipe, the gradient scaled by the power of two of its maximum
+      // (tail_bwd.h: tail16_kernel; the producers -- dlogit_kernel, draw_kernel -- reduce what they write).  ALINE_DBG_BWD_GRAD_F32: exact fp32
+      const bool head16 = m->precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32);
       acqb::DlArgs dl{};
       dl.g = g; dl.logit = dTmp; dl.g_logp = g_logp; dl.slot = r->slot; dl.T = r->T; dl.db2 = gr->acq_b2;
+      dl.out_absmax = head16 ? new_scale_word(c) : nullptr;
+      a.g_max_bits = dl.out_absmax;
       hipLaunchKernelGGL(acqb::dlogit_kernel, dim3((unsigned)std::min((I + 3) / 4, 2048)), dim3(256), 0, c.st, dl);
       CHECK_LAUNCH();
+      if (head16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&acqb::bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, acqb::LDS_FLOATS16 * (int)sizeof(float));
+        hipLaunchKernelGGL(acqb::bwd16_kernel, dim3((unsigned)std::min<long>(groups, 512)), dim3(acqb::THREADS), acqb::LDS_FLOATS16 * sizeof(float), c.st, a);
+      } else
       hipLaunchKernelGGL(acqb::bwd_kernel, dim3((unsigned)std::min<long>(groups, 512)), dim3(acqb::THREADS), acqb::LDS_FLOATS * sizeof(float), c.st, a);
       CHECK_LAUNCH();
     } else if (do_head) {
@@ -1937,8 +1946,14 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       const long groups = ((a.rows + 15) / 16 + gmmb::WAVES - 1) / gmmb::WAVES;
       hipLaunchKernelGGL(gmmb::raw_kernel, dim3((unsigned)std::min<long>(groups, std::max(1, 768 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS_RAW * sizeof(float), c.st, a);
       CHECK_LAUNCH();
+      const bool gmm16 = m->precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32);
+      a.draw_absmax = gmm16 ? new_scale_word(c) : nullptr;
       hipLaunchKernelGGL(gmmb::draw_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, c.st, a);
       CHECK_LAUNCH();
+      if (gmm16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gmmb::bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, gmmb::LDS_FLOATS16 * (int)sizeof(float));
+        hipLaunchKernelGGL(gmmb::bwd16_kernel, dim3((unsigned)std::min<long>(groups, std::max(1, 256 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS16 * sizeof(float), c.st, a);
+      } else
       hipLaunchKernelGGL(gmmb::bwd_kernel, dim3((unsigned)std::min<long>(groups, std::max(1, 256 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS * sizeof(float), c.st, a);
       CHECK_LAUNCH();
       hipLaunchKernelGGL(gmmb::dzsum_kernel, grid1d((size_t)a.rows * 8), dim3(256), 0, c.st, a);

@@ -535,6 +535,17 @@ __device__ __forceinline__ void pack_image16(float *dst, int pitch, const float 
   }
 }
 
+// the power of two gs with max * gs in [2^4, 2^5) for a gradient tensor whose max |.| has the bits b (1 for an all-zero / non-finite one)
+__device__ __forceinline__ float grad_scale16(unsigned b, float &ginv) {
+  const int e = (int)(b >> 23);
+  ginv = 1.f;
+  if (b == 0 || e >= 255) return 1.f;
+  int k = 4 + 127 - e;
+  k = k > 126 ? 126 : (k < -126 ? -126 : k);
+  ginv = __uint_as_float((unsigned)(127 - k) << 23);
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
+
 __global__ __launch_bounds__(THREADS) void tail16_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
@@ -552,17 +563,8 @@ __global__ __launch_bounds__(THREADS) void tail16_kernel(Args a) {
   }
   __syncthreads();
   // the scale of the gradients: max |dY| * gs in [2^4, 2^5)
-  float gs = 1.f, ginv = 1.f;
-  {
-    const unsigned b = *a.dy_max_bits;
-    const int e = (int)(b >> 23);
-    if (b != 0 && e < 255) {
-      int k = 4 + 127 - e;
-      k = k > 126 ? 126 : (k < -126 ? -126 : k);
-      gs = __uint_as_float((unsigned)(127 + k) << 23);
-      ginv = __uint_as_float((unsigned)(127 - k) << 23);
-    }
-  }
+  float ginv;
+  const float gs = grad_scale16(*a.dy_max_bits, ginv);
   f32x4 gWo[2][2], gW1[8][2], gW2[2][8];
   f32x4 gG1[2], gE1[2], gG2[2], gE2[2];
   float gBo[2], gB1[8], gB2[2];
