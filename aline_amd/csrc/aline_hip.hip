@@ -1590,7 +1590,8 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
 
 // token-local tail of layer l (tail_bwd.h): forward recompute (dY == nullptr: Y = layer output) or forward + backward
 int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, const float *dY, float *dA, float *dU,
-                const aline_grads *gr, long M) {
+                const aline_grads *gr, long M, unsigned **da_max = nullptr) {
+  if (da_max) *da_max = nullptr;
   const aline_model &m = *c.m;
   tailbwd::Args a{};
   a.X = X; a.A = A; a.dY = dY; a.Y = Y; a.dA = dA; a.dU = dU; a.M = M;
@@ -1609,6 +1610,7 @@ int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, 
     if (m.precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32)) {
       // the tile program on the f16 matrix pipe (tail_bwd.h: tail16_kernel), every gradient scaled by the power of two of max |dY|
       a.dy_max_bits = grad_absmax(c, dY, M, tailbwd::D, tailbwd::D);
+      if (da_max) { a.da_absmax = new_scale_word(c); *da_max = a.da_absmax; }      // max |dA|: the scale of the attention block's f16 kernel
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS * (int)sizeof(float));
       hipLaunchKernelGGL(tailbwd::tail16_kernel, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);
       CHECK_LAUNCH();
@@ -1657,6 +1659,13 @@ static int launch_layer_fwd(hipStream_t st, const lfwd::Args &fa, int I, int max
 }
 template <int KT>
 static int launch_attn_block_bwd_kt(hipStream_t st, const abwd::BlockArgs &ba, int I) {
+  if (ba.da_max_bits) {      // the f16 matrix pipe (attn_bwd_mfma.h: attn_block_bwd16_kernel)
+    const size_t lds16 = (size_t)abwd::block16_lds_floats(KT) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd16_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    hipLaunchKernelGGL(abwd::attn_block_bwd16_kernel<KT>, dim3((unsigned)std::min(I, KT <= 2 ? 512 : 256)), dim3(abwd::THREADS), lds16, st, ba);
+    CHECK_LAUNCH();
+    return ALINE_OK;
+  }
   const size_t lds = (size_t)abwd::block_lds_floats(KT) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abwd::attn_block_bwd_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // persistent workgroups: two per CU at <= 32 keys (242 registers), one otherwise
@@ -2024,8 +2033,9 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
     }
     // ---- encoder layers backward ---------------------------------------------------------------------------
     for (int l = L - 1; l >= 0 && do_enc; --l) {
+      unsigned *sw_da = nullptr;     // (fused tail on the f16 pipe: max |dA|, the scale of the attention block's f16 kernel)
       if (ft) {                      // dTmp = dA, dXn = dU1 (the residual branch), parameter gradients of the tail
-        TRY(launch_tail(c, l, Xs(l), Al(l), nullptr, dX, dTmp, dXn, gr, M));
+        TRY(launch_tail(c, l, Xs(l), Al(l), nullptr, dX, dTmp, dXn, gr, M, &sw_da));
       } else {
       // LN2
       // (sw_*: the scale words of the F16X3 gradient products -- the producer of a gradient tensor leaves max |.| for its readers)
@@ -2049,6 +2059,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         ba.g = g; ba.X = Xs(l); ba.dA = dTmp; ba.dX = dXn; ba.win = m->in_proj_w[l]; ba.bin = m->in_proj_b[l];
         ba.dwin = gr->in_proj_w[l]; ba.dbin = gr->in_proj_b[l];
         ba.kvc = KVl(l); ba.dkvc = dKVc; ba.keyidx = keyidx; ba.kcnt = kcnt; ba.max_keys = max_keys;
+        ba.da_max_bits = sw_da;
         TRY(launch_attn_block_bwd(c.st, ba, I, max_keys));
         // key rows: dx += Wk^T dK + Wv^T dV, Wk / Wv gradients (one wave per (instance, key tile))
         const long units = (long)I * ((max_keys + 15) / 16);

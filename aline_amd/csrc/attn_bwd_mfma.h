@@ -218,6 +218,7 @@ struct BlockArgs {
   float *dkvc;                 // [I * max_keys, 64] dK | dV sums of the key rows (attn_block_bwd_kernel -> kv_bwd_kernel)
   const int *keyidx, *kcnt;    // key_list_kernel: global token row of key j of instance b (-1 beyond), [I, 2] counts
   int max_keys;
+  const unsigned *da_max_bits; // attn_block_bwd16_kernel: bits of max |dA| (tail16_kernel's Args.da_absmax): the scale of every gradient in it
 };
 
 __device__ __forceinline__ int load_role(const Geo &g, int b, int p) {
@@ -446,6 +447,255 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd_kerne
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(&stg[(16 * i + 4 * gq + r) * D + 16 * j + tok], gWq[i][j][r]);
     atomicAdd(&stg[D * D + 16 * i + tok], gBq[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwin + i, stg[i]);
+  if (tid < D) unsafeAtomicAdd(a.dbin + tid, stg[D * D + tid]);
+}
+
+// ---- round 4: the same kernel on the f16 matrix pipe (tail_bwd.h: tail16_kernel has the scheme) ---------------------------------------
+// Every group of four v_mfma_f32_16x16x4_f32 over a 16 x 16 operand block becomes the 3-term f16 split on v_mfma_f32_16x16x16_f16.
+// K and V of the instance sit in LDS as (hi | lo) quads of four consecutive channels (the A operands of S^T and dP^T: one ds_read_b128
+// as before), K a second time in fp32 (the K^T operand of dQ^T is read down a column and split in registers); Wq and Wq^T as packed
+// images (x 2^8); q, dO, P, dS and the N-layout operands are split where they are produced.  dO is multiplied by the power of two of
+// max |dA| (tail16_kernel reduces what it writes: BlockArgs.da_max_bits) at the load -- the backward is linear in it --, and dX, the
+// dK / dV sums and the Wq gradients are divided by it where they leave.
+// LDS (floats): Wq image [32][36] | Wq^T image | bq [32] | Kp, Vp, Kf, zeros [4][16 KT][36] | wave scratch [4][16][36] | dK / dV slots [4][2][16 KT][36]
+constexpr int block16_lds_floats(int KT) { return 2 * D * PK + D + 4 * 16 * KT * PK + WAVES * 16 * PK + WAVES * 2 * 16 * KT * PK; }
+
+template <int KT>
+__global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd16_kernel(BlockArgs a) {
+  using tailbwd::H8;
+  using tailbwd::split4;
+  using tailbwd::as_h8;
+  constexpr int MK = 16 * KT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *const Wi = lds, *const WiT = Wi + D * PK, *const bi = WiT + D * PK, *const Ks = bi + D, *const Vs = Ks + MK * PK, *const Kf = Vs + MK * PK,
+               *const Zs = Kf + MK * PK, *const scrs = Zs + MK * PK, *const slots = scrs + WAVES * 16 * PK;      // slots [wave][dK | dV][MK][PK]
+  static_assert(2 * MK * PK >= D * D + D, "gradient staging reuses the key-row arrays");
+  const Geo &g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, gq = lane >> 4;
+  tailbwd::pack_image16(Wi, PK, a.win, D, D, D, 1, tid, THREADS);
+  tailbwd::pack_image16(WiT, PK, a.win, D, D, 1, D, tid, THREADS);
+  if (tid < D) bi[tid] = a.bin[tid];
+  float ginv;
+  const float gs = tailbwd::grad_scale16(*a.da_max_bits, ginv);
+  for (int i = tid; i < MK * PK; i += THREADS) Zs[i] = 0.f;
+  // scores in base-2 units: q carries 1 / sqrt(hd) and log2(e), the softmax is exp2(s - max); dQ gets the plain
+  // 1 / sqrt(hd) at the end and the dK sums (products with this q) are multiplied by ln 2 when they leave the registers
+  const float scale = rsqrtf((float)HD), scale2 = scale * 1.44269504088896340736f, ln2 = 0.69314718055994530942f;
+  float *scr = scrs + wave * 16 * PK;
+  f32x4 gWq[2][2];
+  float gBq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gWq[i][j] = zero4();
+  const int ntile = (g.N + 15) >> 4;
+
+  // K | V of an instance's key rows: 16 KT rows of 16 float4, KT per thread, fetched one instance ahead.  Rows beyond the
+  // instance's keys hold the projection of a zero row (finite) and are masked; rows beyond max_keys are clamped.
+  f32x4 nkv[KT];
+  auto load_kv = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int i = tid + u * THREADS, j = min(i >> 4, a.max_keys - 1), c4 = (i & 15) * 4;
+      nkv[u] = ld4(a.kvc + ((long)b * a.max_keys + j) * 2 * D + c4);
+    }
+  };
+  if ((int)blockIdx.x < g.B) load_kv(blockIdx.x);
+  for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
+    const long ep = (long)b * g.N;
+    // first tile of this wave: its loads fly while K / V arrive
+    f32x4 nx[2], ngo[2];
+    int nrole = 0;
+    {
+      const int row = min(wave * 16 + tok, g.N - 1);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        nx[mt] = ld4(a.X + (ep + row) * D + 16 * mt + 4 * gq);
+        ngo[mt] = ld4(a.dA + (ep + row) * D + 16 * mt + 4 * gq);
+      }
+      if (row < g.P) nrole = load_role(g, b, row);
+    }
+    const int n_ck = min(a.kcnt[2 * b], MK), n_ak = min(a.kcnt[2 * b + 1], MK);
+    const int nkt = (n_ak + 15) >> 4;
+    __syncthreads();      // the previous instance is done with the arrays
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {      // (loaded while the previous instance was computed)
+      const int i = tid + u * THREADS, j = i >> 4, c4 = (i & 15) * 4;
+      const H8 pk = split4(nkv[u]);
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      const u2 ph = __builtin_bit_cast(u2, pk.hi), pl = __builtin_bit_cast(u2, pk.lo);
+      *reinterpret_cast<f32x4 *>((c4 < D ? Ks : Vs - D) + j * PK + c4) = (f32x4){__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(pl[0]), __uint_as_float(pl[1])};
+      if (c4 < D) *reinterpret_cast<f32x4 *>(Kf + j * PK + c4) = nkv[u];
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < g.B) load_kv(b + gridDim.x);
+
+    f32x4 dKt[2][KT], dVt[2][KT];      // [chan 16 mt + 4 g + r][key 16 kt + tok], summed over this wave's tiles
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) { dKt[mt][kt] = zero4(); dVt[mt][kt] = zero4(); }
+    for (int tile = wave; tile < ntile; tile += WAVES) {
+      const int row = tile * 16 + tok;
+      const bool ok = row < g.N;
+      const int rc = ok ? row : g.N - 1;
+      const bool isq = ok && row < g.P && !role_is_ctx(g, b, nrole);
+      const int nk = isq ? n_ak : n_ck;      // (padding rows: dO = 0, they contribute nothing)
+      f32x4 kmask[KT];                       // 0 on the visible keys of this row, -inf elsewhere: initial value of the scores
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kmask[kt][r] = 16 * kt + 4 * gq + r < nk ? 0.f : -INFINITY;
+      f32x4 x[2], q[2], go[2], dq[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        x[mt] = nx[mt];
+        go[mt] = ok ? ngo[mt] * gs : zero4();
+        q[mt] = zero4();
+        dq[mt] = zero4();
+      }
+      if (tile + WAVES < ntile) {      // the next tile's rows
+        const int nr = min(row + 16 * WAVES, g.N - 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          nx[mt] = ld4(a.X + (ep + nr) * D + 16 * mt + 4 * gq);
+          ngo[mt] = ld4(a.dA + (ep + nr) * D + 16 * mt + 4 * gq);
+        }
+        nrole = nr < g.P ? load_role(g, b, nr) : 0;
+      }
+      const H8 xS[2] = {split4(x[0]), split4(x[1])};
+      tailbwd::mm_fwd16<2, 2>(q, Wi, PK, xS, tok, gq);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) q[mt] = (q[mt] * tailbwd::WINV16 + ld4(bi + 16 * mt + 4 * gq)) * scale2;
+      const H8 qS[2] = {split4(q[0]), split4(q[1])}, goS[2] = {split4(go[0]), split4(go[1])};
+      f32x4 qN[2], goN[2];
+      tailbwd::to_n(qN, q[0], q[1], scr, tok, gq);
+      tailbwd::to_n(goN, go[0], go[1], scr, tok, gq);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int mt = h >> 1, hg = h & 1;
+        const bool mine_g = (gq >> 1) == hg;      // this lane group's channels 16 mt + 4 g + r belong to head h (k axis)
+        const bool mine_c = (tok >> 3) == hg;     // channel 16 mt + tok belongs to head h (i axis)
+        // operands of the other heads come from the block of zeros: an address select instead of a branch around the loads
+        const float *Kg = mine_g ? Ks : Zs, *Vg = mine_g ? Vs : Zs, *Kc = mine_c ? Kf : Zs;
+        f32x4 s[KT], dp[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          s[kt] = kmask[kt]; dp[kt] = zero4();
+          if (kt < nkt) {
+            const H8 kf = as_h8(ld4(Kg + (16 * kt + tok) * PK + 16 * mt + 4 * gq));
+            const H8 vf = as_h8(ld4(Vg + (16 * kt + tok) * PK + 16 * mt + 4 * gq));
+            MFMA16O(s[kt], kf.lo, qS[mt].hi); MFMA16O(dp[kt], vf.lo, goS[mt].hi);
+            MFMA16O(s[kt], kf.hi, qS[mt].lo); MFMA16O(dp[kt], vf.hi, goS[mt].lo);
+            MFMA16O(s[kt], kf.hi, qS[mt].hi); MFMA16O(dp[kt], vf.hi, goS[mt].hi);
+          }
+        }
+        float mx = -3.0e38f;      // (a row without a visible key: every exp2 below is 0, inv = 0)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = group_max(mx);
+        float l = 0.f, delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+            s[kt][r] = e;
+            l += e;
+            delta = fmaf(e, dp[kt][r], delta);
+          }
+        l = group_sum(l);
+        const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;
+        delta = group_sum(delta) * inv;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = s[kt][r] * inv;
+            s[kt][r] = p;
+            dp[kt][r] = p * (dp[kt][r] - delta);      // dS^T
+          }
+        const H8 goA = split4(mine_c ? goN[mt] : zero4()), qA = split4(mine_c ? qN[mt] : zero4());
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          if (kt < nkt) {
+            f32x4 kc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kc[r] = Kc[(16 * kt + 4 * gq + r) * PK + 16 * mt + tok];
+            const H8 kcS = split4(kc), dsS = split4(dp[kt]);
+            f32x4 pn[2];
+            tailbwd::to_n(pn, s[kt], dp[kt], scr, tok, gq);      // pn[0] = P_N, pn[1] = dS_N  (key on lane, row on (g, r))
+            const H8 pS = split4(pn[0]), dsN = split4(pn[1]);
+            MFMA16O(dq[mt], kcS.lo, dsS.hi); MFMA16O(dVt[mt][kt], goA.lo, pS.hi); MFMA16O(dKt[mt][kt], qA.lo, dsN.hi);
+            MFMA16O(dq[mt], kcS.hi, dsS.lo); MFMA16O(dVt[mt][kt], goA.hi, pS.lo); MFMA16O(dKt[mt][kt], qA.hi, dsN.lo);
+            MFMA16O(dq[mt], kcS.hi, dsS.hi); MFMA16O(dVt[mt][kt], goA.hi, pS.hi); MFMA16O(dKt[mt][kt], qA.hi, dsN.hi);
+          }
+        }
+      }
+      dq[0] *= scale; dq[1] *= scale;
+      f32x4 dxo[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) dxo[mt] = ok ? ld4(a.dX + (ep + rc) * D + 16 * mt + 4 * gq) : zero4();
+      {
+        const H8 dqS[2] = {split4(dq[0]), split4(dq[1])};
+        f32x4 acc[2] = {zero4(), zero4()};
+        tailbwd::mm_fwd16<2, 2>(acc, WiT, PK, dqS, tok, gq);          // dx = du1 + Wq^T dq
+        const float dsc = tailbwd::WINV16 * ginv;
+        dxo[0] += acc[0] * dsc; dxo[1] += acc[1] * dsc;
+      }
+      if (ok) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4 *>(a.dX + (ep + row) * D + 16 * mt + 4 * gq) = dxo[mt];
+      }
+      f32x4 dqN[2], xN[2];
+      tailbwd::to_n(dqN, dq[0], dq[1], scr, tok, gq);
+      tailbwd::to_n(xN, x[0], x[1], scr, tok, gq);
+      {
+        const H8 dqNS[2] = {split4(dqN[0]), split4(dqN[1])}, xNS[2] = {split4(xN[0]), split4(xN[1])};
+        tailbwd::mm_dw4_16(gWq[0][0], gWq[0][1], gWq[1][0], gWq[1][1], dqNS[0], xNS[0], dqNS[0], xNS[1], dqNS[1], xNS[0], dqNS[1], xNS[1]);
+        gBq[0] += tailbwd::sum4(dqN[0]); gBq[1] += tailbwd::sum4(dqN[1]);
+      }
+    }
+    // ---- dK / dV of the key rows: every wave leaves its partial sums in its own LDS slot (plain 16-byte stores: LDS float
+    // atomics retire a few lanes per cycle), the store to the compact buffer adds the four slots -------------------------
+    {
+      float *my = slots + wave * 2 * MK * PK;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+          if (kt < nkt) {
+            *reinterpret_cast<f32x4 *>(my + (16 * kt + tok) * PK + 16 * mt + 4 * gq) = dKt[mt][kt] * (ln2 * ginv);
+            *reinterpret_cast<f32x4 *>(my + MK * PK + (16 * kt + tok) * PK + 16 * mt + 4 * gq) = dVt[mt][kt] * ginv;
+          }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_ak * 16; i += THREADS) {
+      const int j = i >> 4, c4 = (i & 15) * 4;
+      const float *src = slots + (c4 < D ? 0 : MK * PK - D) + j * PK + c4;
+      f32x4 v = ld4(src);
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) v += ld4(src + w * 2 * MK * PK);
+      *reinterpret_cast<f32x4 *>(a.dkvc + ((long)b * a.max_keys + j) * 2 * D + c4) = v;
+    }
+  }
+  // ---- the workgroup's Wq gradients: LDS staging, then one atomic per element ---------------------------------------
+  __syncthreads();
+  float *stg = Ks;      // Wq [32][32], then bq [32]
+  for (int i = tid; i < D * D + D; i += THREADS) stg[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&stg[(16 * i + 4 * gq + r) * D + 16 * j + tok], gWq[i][j][r] * ginv);
+    atomicAdd(&stg[D * D + 16 * i + tok], gBq[i] * ginv);
   }
   __syncthreads();
   for (int i = tid; i < D * D; i += THREADS) unsafeAtomicAdd(a.dwin + i, stg[i]);

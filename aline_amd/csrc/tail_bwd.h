@@ -56,6 +56,7 @@ struct Args {
   long M;
   const float *wo, *bo, *w1, *b1, *w2, *b2, *g1, *e1, *g2, *e2;
   float *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dg1, *de1, *dg2, *de2;     // accumulated into (+=)
+  unsigned *da_absmax;          // tail16_kernel, optional: max |dA| written, as bits (the gradient scale of attn_block_bwd16_kernel)
   const unsigned *dy_max_bits;  // tail16_kernel: bits of max |dY| (absmax_bits_kernel): the power-of-two scale of every gradient in the tile program
 #if defined(TAIL_STAMPS)      // (tools/probes/tail_probe.hip: s_memtime deltas per phase, wave 0 of workgroup 0)
   unsigned long long *stamps;
@@ -592,6 +593,7 @@ __global__ __launch_bounds__(THREADS) void tail16_kernel(Args a) {
       ndy[mt] = ld4(a.dY + r * D + 16 * mt + 4 * g);
     }
   };
+  float da_max = 0.f;
   if ((long)blockIdx.x * WAVES + wave < ntiles) load_tile((long)blockIdx.x * WAVES + wave);
   for (long tile = (long)blockIdx.x * WAVES + wave; tile < ntiles; tile += tstep) {
     int zoff = 0;
@@ -689,8 +691,10 @@ __global__ __launch_bounds__(THREADS) void tail16_kernel(Args a) {
       const float dsc = WINV16 * ginv;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        *reinterpret_cast<f32x4 *>(a.dA + row * D + 16 * mt + 4 * g) = da[mt] * dsc;
+        const f32x4 dav = da[mt] * dsc;
+        *reinterpret_cast<f32x4 *>(a.dA + row * D + 16 * mt + 4 * g) = dav;
         *reinterpret_cast<f32x4 *>(a.dU + row * D + 16 * mt + 4 * g) = du1[mt] * ginv;
+        da_max = fmaxf(fmaxf(da_max, fmaxf(fabsf(dav[0]), fabsf(dav[1]))), fmaxf(fabsf(dav[2]), fabsf(dav[3])));
       }
     }
     f32x4 du1N[2], aN[2];
@@ -698,6 +702,10 @@ __global__ __launch_bounds__(THREADS) void tail16_kernel(Args a) {
     const H8 du1NS[2] = {split4(du1N[0]), split4(du1N[1])}, aNS[2] = {split4(aN[0]), split4(aN[1])};
     mm_dw4_16(gWo[0][0], gWo[0][1], gWo[1][0], gWo[1][1], du1NS[0], aNS[0], du1NS[0], aNS[1], du1NS[1], aNS[0], du1NS[1], aNS[1]);
     gBo[0] += sum4(du1N[0]); gBo[1] += sum4(du1N[1]);
+  }
+  if (a.da_absmax) {
+    da_max = wave_max(da_max);
+    if (lane == 0 && da_max > 0.f) atomicMax(a.da_absmax, __float_as_uint(da_max));
   }
   // ---- the workgroup's gradients (divided by the gradient scale): LDS staging, then one atomic per element -----------------
   float *const stg = lds;

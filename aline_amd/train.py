@@ -379,6 +379,10 @@ def train_step(model, batch, T, optimizer=None, embedding_type="theta", mask_typ
         terms = reinforce_terms(ro, embedding_type, mask_type, gamma, alpha, burn_in,
                                 dist=dist if (global_reward_moments and world > 1) else None, world=world)
         backward(model, ro, terms["g_logp"], terms["g_ll"], t_chunk=t_chunk, grads=gstruct)
+        if status is not None and ro.m.precision == _lib.PREC["f16x3"]:
+            # the f16 gradient products of the backward scale their operands by the power of two of the upstream gradient's maximum; if a
+            # tile program's own growth still left f16's range the gradients are inf / NaN, never silently wrong: same slot, same refusal
+            status.add_((~torch.isfinite(flat.abs().max())).to(torch.float32))
         if dist is not None and (world > 1 or force_collective):
             all_reduce_grads(model, dist, world, flat=flat)
         if clip_grads:
@@ -399,7 +403,7 @@ def check_training_range(terms):
     st = terms.get("range_status")
     if st is not None and float(st) > 0:
         _RANGE_PENDING.clear()
-        raise RuntimeError("aline_amd: an F16X3 operand left f16's range during a training rollout (on this or another rank); "
+        raise RuntimeError("aline_amd: an F16X3 operand left f16's range during a training rollout or its backward (on this or another rank); "
                            "the step's gradients are not applied -- train with precision 'f32'")
 
 
