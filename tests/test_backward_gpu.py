@@ -651,6 +651,61 @@ def test_scaled_f16_gradient_products_match_the_exact_fp32_products(d, F, H, B, 
     assert worst[1] < 2e-4, worst
 
 
+@pytest.mark.parametrize("B,T,nq,task", [(37, 12, 150, "location"), (9, 40, 60, "location"), (6, 9, 40, "al_mix")])
+def test_f16_fused_backward_kernels_match_the_exact_fp32_fused_kernels(B, T, nq, task):
+    """Round 4: the fused backward kernels of the d = 32 model on the f16 matrix pipe -- `tailbwd::tail16_kernel`, `acqb / gmmb::bwd16_kernel`,
+    `abwd::attn_block_bwd16_kernel<2 | 3>`: every group of four fp32 16x16x4 MFMAs a 3-term f16 split on `v_mfma_f32_16x16x16_f16`, the
+    gradients scaled by the power of two of the upstream maximum (reduced by the producer kernels), weights packed x 2^8 -- against the
+    exact-fp32 kernels they replace (`ALINE_DBG_BWD_GRAD_F32`) on the same rollout: two and three key tiles (T = 12 / 40), ragged token
+    tiles, the al_mix geometry with data targets and a split mask.  Both sides recompute the hidden units of the heads and of the FFN from
+    the same saved activations, one through the f16 split (1e-7 relative), one in fp32: a unit within that of zero changes side of its
+    ReLU, and ONE such gate is 1e-4 .. 1e-3 of a head gradient at these row counts (millions of units: a handful per run).  So, as in the
+    A/B test of the recompute switches below: nothing beyond 3e-3 of a tensor's max |grad|, four tensors in five within 2e-4."""
+    from aline_amd import Aline, Embedder, Encoder, OutputHead, _lib
+    from aline_amd.rollout import Rollout
+    from aline_amd.train import backward, reinforce_terms
+    torch.manual_seed(B + T)
+    dev = torch.device("cuda")
+    if task == "location":
+        from aline_amd.tasks import HiddenLocation
+        model = Aline(Embedder(2, 1, 32, 128, 2, "theta"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128))
+        batch = HiddenLocation(n_query_init=nq, device=dev).sample_batch(B)
+        emb, mask = "theta", "all"
+    else:
+        from aline_amd.tasks import GPTask
+        from aline_amd.utils import create_target_mask
+        model = Aline(Embedder(2, 1, 32, 128, 3, "mix"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128))
+        batch = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=nq, n_target_theta=3, n_target_data=20, device=dev).sample_batch(B)
+        batch["target_mask"] = create_target_mask("split", "mix", 20, 3, None, None, None, None, "data")
+        emb, mask = "mix", "split"
+    model = model.cuda().set_precision("f16x3").train()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    grads = []
+    with torch.no_grad():
+        ro = Rollout(model, batch, T, select="sample").run()
+        assert ro.path == "s3::step_kernel", ro.path
+        terms = reinforce_terms(ro, emb, mask)
+        for flags in ([], ["BWD_GRAD_F32"]):
+            with _lib.debug(*flags):
+                for p in model.parameters():
+                    p.grad = None
+                backward(model, ro, terms["g_logp"], terms["g_ll"])
+                torch.cuda.synchronize()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    new, ref = grads
+    floor = 1e-2 * max(float(g.abs().max()) for g in ref.values())
+    errs = {}
+    for k in ref:
+        assert torch.isfinite(new[k]).all(), k
+        errs[k] = float((new[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), floor)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert worst[1] < 3e-3, worst
+    close = sum(e < 2e-4 for e in errs.values())
+    assert close >= 0.8 * len(errs), (close, len(errs), sorted(errs.items(), key=lambda kv: -kv[1])[:6])
+
+
 @pytest.mark.parametrize("d,F,H,B,T,tc,mask", [(256, 512, 8, 24, 9, 4, False), (256, 256, 8, 5, 40, 16, False), (512, 128, 8, 9, 12, 5, True)])
 def test_image_recompute_and_key_row_products_match_the_generic_recompute(d, F, H, B, T, tc, mask):
     """Round 4, second half: the per-op backward of a d = 256 / 512 F16X3 model recomputes the forward with the rollout's own layer kernel
