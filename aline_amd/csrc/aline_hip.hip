@@ -1590,7 +1590,7 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
 
 // token-local tail of layer l (tail_bwd.h): forward recompute (dY == nullptr: Y = layer output) or forward + backward
 int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, const float *dY, float *dA, float *dU,
-                const aline_grads *gr, long M, unsigned **da_max = nullptr) {
+                const aline_grads *gr, long M, unsigned **da_max = nullptr, const unsigned *dy_scale = nullptr) {
   if (da_max) *da_max = nullptr;
   const aline_model &m = *c.m;
   tailbwd::Args a{};
@@ -1609,7 +1609,7 @@ int launch_tail(const BCtx &c, int l, const float *X, const float *A, float *Y, 
     a.dg2 = gr->norm2_w[l]; a.de2 = gr->norm2_b[l];
     if (m.precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32)) {
       // the tile program on the f16 matrix pipe (tail_bwd.h: tail16_kernel), every gradient scaled by the power of two of max |dY|
-      a.dy_max_bits = grad_absmax(c, dY, M, tailbwd::D, tailbwd::D);
+      a.dy_max_bits = dy_scale ? dy_scale : grad_absmax(c, dY, M, tailbwd::D, tailbwd::D);      // (the layer above's attention block left max |dX|)
       if (da_max) { a.da_absmax = new_scale_word(c); *da_max = a.da_absmax; }      // max |dA|: the scale of the attention block's f16 kernel
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tailbwd::tail16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, tailbwd::LDS_FLOATS * (int)sizeof(float));
       hipLaunchKernelGGL(tailbwd::tail16_kernel, dim3((unsigned)std::min<long>(groups, 256)), dim3(tailbwd::THREADS), smem, c.st, a);
@@ -2032,10 +2032,12 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       continue;
     }
     // ---- encoder layers backward ---------------------------------------------------------------------------
+    unsigned *sw_dx = nullptr;       // (f16 fused kernels: max |dX_l| left by the attention block of layer l, the scale of layer l - 1's tail)
     for (int l = L - 1; l >= 0 && do_enc; --l) {
       unsigned *sw_da = nullptr;     // (fused tail on the f16 pipe: max |dA|, the scale of the attention block's f16 kernel)
       if (ft) {                      // dTmp = dA, dXn = dU1 (the residual branch), parameter gradients of the tail
-        TRY(launch_tail(c, l, Xs(l), Al(l), nullptr, dX, dTmp, dXn, gr, M, &sw_da));
+        TRY(launch_tail(c, l, Xs(l), Al(l), nullptr, dX, dTmp, dXn, gr, M, &sw_da, sw_dx));
+        sw_dx = nullptr;
       } else {
       // LN2
       // (sw_*: the scale words of the F16X3 gradient products -- the producer of a gradient tensor leaves max |.| for its readers)
@@ -2060,6 +2062,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         ba.dwin = gr->in_proj_w[l]; ba.dbin = gr->in_proj_b[l];
         ba.kvc = KVl(l); ba.dkvc = dKVc; ba.keyidx = keyidx; ba.kcnt = kcnt; ba.max_keys = max_keys;
         ba.da_max_bits = sw_da;
+        if (sw_da && l > 0) { sw_dx = new_scale_word(c); ba.dx_absmax = sw_dx; }
         TRY(launch_attn_block_bwd(c.st, ba, I, max_keys));
         // key rows: dx += Wk^T dK + Wv^T dV, Wk / Wv gradients (one wave per (instance, key tile))
         const long units = (long)I * ((max_keys + 15) / 16);

@@ -218,6 +218,8 @@ struct BlockArgs {
   float *dkvc;                 // [I * max_keys, 64] dK | dV sums of the key rows (attn_block_bwd_kernel -> kv_bwd_kernel)
   const int *keyidx, *kcnt;    // key_list_kernel: global token row of key j of instance b (-1 beyond), [I, 2] counts
   int max_keys;
+  unsigned *dx_absmax;         // attn_block_bwd16_kernel, optional: max |dX| it writes, as bits (the next layer's tail16_kernel scales its dY by it; the
+                               // key rows' K / V terms of kv_bwd_kernel come on top: the tile program's head room of 2^11 covers them)
   const unsigned *da_max_bits; // attn_block_bwd16_kernel: bits of max |dA| (tail16_kernel's Args.da_absmax): the scale of every gradient in it
 };
 
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd16_ker
   tailbwd::pack_image16(Wi, PK, a.win, D, D, D, 1, tid, THREADS);
   tailbwd::pack_image16(WiT, PK, a.win, D, D, 1, D, tid, THREADS);
   if (tid < D) bi[tid] = a.bin[tid];
-  float ginv;
+  float ginv, dx_max = 0.f;
   const float gs = tailbwd::grad_scale16(*a.da_max_bits, ginv);
   for (int i = tid; i < MK * PK; i += THREADS) Zs[i] = 0.f;
   // scores in base-2 units: q carries 1 / sqrt(hd) and log2(e), the softmax is exp2(s - max); dQ gets the plain
@@ -647,6 +649,9 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd16_ker
         tailbwd::mm_fwd16<2, 2>(acc, WiT, PK, dqS, tok, gq);          // dx = du1 + Wq^T dq
         const float dsc = tailbwd::WINV16 * ginv;
         dxo[0] += acc[0] * dsc; dxo[1] += acc[1] * dsc;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          dx_max = fmaxf(fmaxf(dx_max, fmaxf(fabsf(dxo[mt][0]), fabsf(dxo[mt][1]))), fmaxf(fabsf(dxo[mt][2]), fabsf(dxo[mt][3])));
       }
       if (ok) {
 #pragma unroll
@@ -683,6 +688,10 @@ __global__ __launch_bounds__(THREADS, KT <= 2 ? 2 : 1) void attn_block_bwd16_ker
       for (int w = 1; w < WAVES; ++w) v += ld4(src + w * 2 * MK * PK);
       *reinterpret_cast<f32x4 *>(a.dkvc + ((long)b * a.max_keys + j) * 2 * D + c4) = v;
     }
+  }
+  if (a.dx_absmax) {
+    dx_max = wave_max(dx_max);
+    if (lane == 0 && dx_max > 0.f) atomicMax(a.dx_absmax, __float_as_uint(dx_max));
   }
   // ---- the workgroup's Wq gradients: LDS staging, then one atomic per element ---------------------------------------
   __syncthreads();
