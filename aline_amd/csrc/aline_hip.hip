@@ -14,6 +14,7 @@
 #include "attn3.h"
 #include "backward.h"
 #include "attn_bwd_wide.h"
+#include "attn_bwd8.h"
 #include "tail_bwd.h"
 #include "attn_bwd_mfma.h"
 #include "acq_head_bwd.h"
@@ -1534,11 +1535,30 @@ static int launch_attention_bwd_wide(const BCtx &c, const float *qkv, const floa
   return ALINE_OK;
 }
 
+template <int NKT>
+static int launch_attention_bwd8(const BCtx &c, const float *qkv, const float *dA, const float *aout, float *dqkv, const unsigned *da_scale) {
+  const size_t smem = abw8::lds_bytes(NKT, c.g.N);
+  if (smem > 160 * 1024) return ALINE_EUNSUPPORTED;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abw8::attention_bwd8_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((abw8::attention_bwd8_kernel<NKT>), dim3((unsigned)c.g.B), dim3(64 * abw8::WAVES), smem, c.st, c.g, qkv, dA, aout, dqkv, da_scale);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
 template <int HD>
 int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float *dqkv, int max_keys, const float *aout = nullptr,
-                         unsigned **out_max = nullptr, bool key_rows_only = false) {
+                         unsigned **out_max = nullptr, bool key_rows_only = false, const unsigned *da_scale = nullptr) {
   const bool mfma_on = !dbg(ALINE_DBG_NO_BWD_ATTN_MFMA);      // 0: the VALU kernel (A/B measurements)
   if (out_max) *out_max = nullptr;
+  if constexpr (HD == 8) {
+    // d = 32 / 4 heads beyond the fused attention block's 48 keys (cfg3): the f16 matrix pipe (attn_bwd8.h), given the scale word of dA
+    if (mfma_on && aout && da_scale && c.m->d == 32 && c.m->H == 4 && max_keys <= 160 && c.m->precision == ALINE_PREC_F16X3 &&
+        !dbg(ALINE_DBG_BWD_GRAD_F32)) {
+      if (max_keys <= 64) return launch_attention_bwd8<4>(c, qkv, dA, aout, dqkv, da_scale);
+      if (max_keys <= 112) return launch_attention_bwd8<7>(c, qkv, dA, aout, dqkv, da_scale);
+      return launch_attention_bwd8<10>(c, qkv, dA, aout, dqkv, da_scale);
+    }
+  }
   if constexpr (HD == 32 || HD == 64) {
     const int nkt = (max_keys + 15) / 16;
     if (mfma_on && aout && nkt <= 3 && c.m->d % HD == 0) {      // (<32, 4> spills 64 registers: beyond 48 keys the VALU kernel)
@@ -2075,7 +2095,7 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       unsigned *sw_att = nullptr;
       switch (hd) {
         case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
-        case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
+        case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), nullptr, false, sw_da)); break;
         case 16: TRY(launch_attention_bwd<16>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
         case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse)); break;
         case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse)); break;

@@ -651,10 +651,11 @@ def test_scaled_f16_gradient_products_match_the_exact_fp32_products(d, F, H, B, 
     assert worst[1] < 2e-4, worst
 
 
-@pytest.mark.parametrize("B,T,nq,task", [(37, 12, 150, "location"), (9, 40, 60, "location"), (6, 9, 40, "al_mix")])
+@pytest.mark.parametrize("B,T,nq,task", [(37, 12, 150, "location"), (9, 40, 60, "location"), (6, 9, 40, "al_mix"),
+                                         (4, 6, 40, "al_mix50"), (5, 10, 70, "al_mix100"), (3, 45, 60, "al_mix100")])
 def test_f16_fused_backward_kernels_match_the_exact_fp32_fused_kernels(B, T, nq, task):
     """Round 4: the fused backward kernels of the d = 32 model on the f16 matrix pipe -- `tailbwd::tail16_kernel`, `acqb / gmmb::bwd16_kernel`,
-    `abwd::attn_block_bwd16_kernel<2 | 3>`: every group of four fp32 16x16x4 MFMAs a 3-term f16 split on `v_mfma_f32_16x16x16_f16`, the
+    `abwd::attn_block_bwd16_kernel<2 | 3>`, and beyond 48 keys `abw8::attention_bwd8_kernel<4 | 7 | 10>` (head_dim 8, up to 160 keys): every group of four fp32 16x16x4 MFMAs a 3-term f16 split on `v_mfma_f32_16x16x16_f16`, the
     gradients scaled by the power of two of the upstream maximum (reduced by the producer kernels), weights packed x 2^8 -- against the
     exact-fp32 kernels they replace (`ALINE_DBG_BWD_GRAD_F32`) on the same rollout: two and three key tiles (T = 12 / 40), ragged token
     tiles, the al_mix geometry with data targets and a split mask.  Both sides recompute the hidden units of the heads and of the FFN from
@@ -675,8 +676,9 @@ def test_f16_fused_backward_kernels_match_the_exact_fp32_fused_kernels(B, T, nq,
         from aline_amd.tasks import GPTask
         from aline_amd.utils import create_target_mask
         model = Aline(Embedder(2, 1, 32, 128, 3, "mix"), Encoder(32, 128, 4, 0.0, 3), OutputHead(2, 1, 32, 128))
-        batch = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=nq, n_target_theta=3, n_target_data=20, device=dev).sample_batch(B)
-        batch["target_mask"] = create_target_mask("split", "mix", 20, 3, None, None, None, None, "data")
+        ntd = 100 if task == "al_mix100" else 50 if task == "al_mix50" else 20      # 57 / 111 / 146 keys: `abw8::attention_bwd8_kernel<4 | 7 | 10>`
+        batch = GPTask(dim_x=2, embedding_type="mix", n_context_init=1, n_query_init=nq, n_target_theta=3, n_target_data=ntd, device=dev).sample_batch(B)
+        batch["target_mask"] = create_target_mask("split", "mix", ntd, 3, None, None, None, None, "data")
         emb, mask = "mix", "split"
     model = model.cuda().set_precision("f16x3").train()
     with torch.no_grad():
