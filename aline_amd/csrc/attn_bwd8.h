@@ -10,8 +10,8 @@
 //     k = 4 g .. 4 g + 3 slice of that instruction's B operand, as they were four k-steps of the fp32 one.  A head has 8 channels: they sit
 //     in k (or M) positions 0 .. 7, positions 8 .. 15 are zeros -- half of every tile, as at fp32, at 3 x 16 pipe cycles per tile instead of
 //     2 x 32 (S, dP) or 4 x 32 (dV, dK, dQ).  dO is scaled by the power of two of max |dA| at the staging (the backward is linear in it).
-//   * the softmax statistics of a row tile come from a first sweep over its key tiles (running maximum and sum per lane, combined over
-//     the 16 lanes of a group at the end), so that S and dP are held for ONE key tile at a time;
+//   * a row tile's scores of all its key tiles stay in registers (4 per tile) through maximum, 2^(s - max) and sum; dP / dS exist for ONE key
+//     tile at a time;
 //   * TWO waves per head (eight per workgroup, two per SIMD) share the head's K / V operands -- packed (hi | lo) quads in LDS, 30 KB per head at
 //     160 keys -- and take alternate row tiles; each keeps its own dK^T / dV^T tiles (80 registers at ten key tiles), the second wave of a
 //     pair adds its sums to the rows the first has stored.  (First version: one wave per head with the operands in registers, 350
@@ -172,48 +172,49 @@ __global__ __launch_bounds__(64 * WAVES) void attention_bwd8_kernel(Geo g, const
     const int4 nv = *reinterpret_cast<const int4 *>(nvis + r0 + 4 * fg);
     const f32x4 dl4 = *reinterpret_cast<const f32x4 *>(Dl + 4 * fg);
     const int nkt = r0 < g.P ? nkt_all : nkt_ctx;          // (wave-uniform) a tile without point rows sees the context keys only
-    // sweep 1: running maximum and sum of 2^(s - max) per lane over the key tiles, then over the 16 lanes of the group
+    // sweep 1: the scores of every key tile (kept: 4 registers per tile), their maximum per row; then e = 2^(s - max) in place and the sum
+    const int nvr[4] = {nv.x, nv.y, nv.z, nv.w};
+    f32x4 S[NKT];
     f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sum = z4;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
-        f32x4 S = z4;
-        mfma3(S, QA, tailbwd::as_h8(*reinterpret_cast<const f32x4 *>(KBs + (kt * 64 + lane) * 4)));
+        S[kt] = z4;
+        mfma3(S[kt], QA, tailbwd::as_h8(*reinterpret_cast<const f32x4 *>(KBs + (kt * 64 + lane) * 4)));
         const int key = 16 * kt + fr;
-        const int nvr[4] = {nv.x, nv.y, nv.z, nv.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float s = key < nvr[r] ? S[r] : -INFINITY;
-          const float m2 = fmaxf(mx[r], s);
-          const float e = m2 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s - m2);
-          const float resc = m2 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mx[r] - m2);
-          sum[r] = fmaf(sum[r], resc, e);
-          mx[r] = m2;
+          S[kt][r] = key < nvr[r] ? S[kt][r] : -INFINITY;
+          mx[r] = fmaxf(mx[r], S[kt][r]);
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float m = group16_max(mx[r]);
-      const float part = m == -INFINITY ? 0.f : sum[r] * __builtin_amdgcn_exp2f(mx[r] - m);
-      const float l = group16_sum(part);
-      mx[r] = m;
-      sum[r] = l > 0.f ? 1.f / l : 0.f;
+    for (int r = 0; r < 4; ++r) mx[r] = group16_max(mx[r]);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = mx[r] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(S[kt][r] - mx[r]);      // (a masked score: 2^-inf = 0; a row without keys: 0)
+          S[kt][r] = e;
+          sum[r] += e;
+        }
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float l = group16_sum(sum[r]); sum[r] = l > 0.f ? 1.f / l : 0.f; }
     // sweep 2: P, dS;  dV^T += dO^T P,  dK^T += Q^T dS;  dQ^T += K^T dS^T through the transpose slot
     f32x4 dQT = z4;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
-        f32x4 S = z4, dP = z4;
-        mfma3(S, QA, tailbwd::as_h8(*reinterpret_cast<const f32x4 *>(KBs + (kt * 64 + lane) * 4)));
+        f32x4 dP = z4;
         mfma3(dP, GA, tailbwd::as_h8(*reinterpret_cast<const f32x4 *>(VBs + (kt * 64 + lane) * 4)));
-        const int key = 16 * kt + fr;
-        const int nvr[4] = {nv.x, nv.y, nv.z, nv.w};
         f32x4 P, dS;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          P[r] = key < nvr[r] ? __builtin_amdgcn_exp2f(S[r] - mx[r]) * sum[r] : 0.f;
+          P[r] = S[kt][r] * sum[r];
           dS[r] = P[r] * (dP[r] - dl4[r]);
         }
         const H8 PS = split4(P), dSS = split4(dS);
