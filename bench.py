@@ -449,7 +449,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
-    ap.add_argument("--train-steps", type=int, default=2,
+    ap.add_argument("--train-steps", type=int, default=5,
                     help="also time K full training steps (rollout + backward + all-reduce + AdamW); 0 = skip")
     ap.add_argument("--sustain-s", type=float, default=2.5,
                     help="after the timed steps, replay the rollout back to back for this many seconds (sustained_ms_per_step)")
@@ -713,7 +713,8 @@ def main():
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
         err = None
         try:
-            train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world, force_collective=force_dist)        # warm-up
+            for _ in range(2):      # warm-up (the first call builds the rollout's graph and the backward workspace)
+                train_step(model, batch, args.T, optimizer=opt, dist=dist, world=world, force_collective=force_dist)
         except Exception as e:      # a secondary leg must not take the headline line with it ...
             err = e
             log(f"train step leg failed: {e!r}")
