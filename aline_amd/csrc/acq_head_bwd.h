@@ -41,10 +41,15 @@ __device__ __forceinline__ void load_image(float *lds, const Args &a, int tid) {
   if (tid < F) { lds[L_B1 + tid] = a.b1[tid]; lds[L_W2 + tid] = a.w2[tid]; }
 }
 
+// F16: the hidden-unit product as the 3-term f16 split on v_mfma_f32_16x16x16_f16 (tail_bwd.h), as the rollout computed it
+template <bool F16>
 __global__ __launch_bounds__(THREADS) void logit_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4;
-  load_image(lds, a, tid);
+  if (F16) {
+    tailbwd::pack_image16(lds + L_W1, PW, a.w1, F, D, D, 1, tid, THREADS);
+    if (tid < F) { lds[L_B1 + tid] = a.b1[tid]; lds[L_W2 + tid] = a.w2[tid]; }
+  } else load_image(lds, a, tid);
   __syncthreads();
   const float b2 = a.b2[0];
   const long ntiles = (a.M + 15) / 16;
@@ -55,9 +60,18 @@ __global__ __launch_bounds__(THREADS) void logit_kernel(Args a) {
     const long row = tile * 16 + tok, rc = min(row, a.M - 1);
     const f32x4 z[2] = {ld4(a.Z + rc * D + 4 * g), ld4(a.Z + rc * D + 16 + 4 * g)};
     f32x4 h[8];
+    if (F16) {
+      const tailbwd::H8 zS[2] = {tailbwd::split4(z[0]), tailbwd::split4(z[1])};
 #pragma unroll
-    for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
-    tailbwd::mm_fwd<8, 2>(h, W + L_W1, PW, z, tok, g);
+      for (int ob = 0; ob < 8; ++ob) h[ob] = zero4();
+      tailbwd::mm_fwd16<8, 2>(h, W + L_W1, PW, zS, tok, g);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) h[ob] = h[ob] * tailbwd::WINV16 + ld4(W + L_B1 + 16 * ob + 4 * g);
+    } else {
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
+      tailbwd::mm_fwd<8, 2>(h, W + L_W1, PW, z, tok, g);
+    }
     float s = 0.f;
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob) {
@@ -335,10 +349,15 @@ __device__ __forceinline__ void load_image(float *lds, const Args &a, int c, int
 }
 __device__ __forceinline__ long token_row(const Args &a, long q) { return (q / a.n_t) * a.N + a.P + q % a.n_t; }
 
+template <bool F16>
 __global__ __launch_bounds__(THREADS) void raw_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tok = lane & 15, g = lane >> 4, c = blockIdx.y;
-  load_image(lds, a, c, tid);
+  if (F16) {
+    tailbwd::pack_image16(lds + L_W1, PW, a.w1[c], F, D, D, 1, tid, THREADS);
+    if (tid < F) lds[L_B1 + tid] = a.b1[c][tid];
+    for (int i = tid; i < 3 * F; i += THREADS) lds[L_W2 + i] = a.w2[c][i];
+  } else load_image(lds, a, c, tid);
   __syncthreads();
   const float b20 = a.b2[c][0], b21 = a.b2[c][1], b22 = a.b2[c][2];
   const long ntiles = (a.rows + 15) / 16;
@@ -349,9 +368,18 @@ __global__ __launch_bounds__(THREADS) void raw_kernel(Args a) {
     const long q = tile * 16 + tok, zr = token_row(a, min(q, a.rows - 1));
     const f32x4 z[2] = {ld4(a.Z + zr * D + 4 * g), ld4(a.Z + zr * D + 16 + 4 * g)};
     f32x4 h[8];
+    if (F16) {
+      const tailbwd::H8 zS[2] = {tailbwd::split4(z[0]), tailbwd::split4(z[1])};
 #pragma unroll
-    for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
-    tailbwd::mm_fwd<8, 2>(h, W + L_W1, PW, z, tok, g);
+      for (int ob = 0; ob < 8; ++ob) h[ob] = zero4();
+      tailbwd::mm_fwd16<8, 2>(h, W + L_W1, PW, zS, tok, g);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) h[ob] = h[ob] * tailbwd::WINV16 + ld4(W + L_B1 + 16 * ob + 4 * g);
+    } else {
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) h[ob] = ld4(W + L_B1 + 16 * ob + 4 * g);
+      tailbwd::mm_fwd<8, 2>(h, W + L_W1, PW, z, tok, g);
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob) {

@@ -1918,7 +1918,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       a.dw1 = gr->acq_w1; a.db1 = gr->acq_b1; a.dw2 = gr->acq_w2;
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&acqb::bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, acqb::LDS_FLOATS * (int)sizeof(float));
       const long groups = ((M + 15) / 16 + acqb::WAVES - 1) / acqb::WAVES;
-      hipLaunchKernelGGL(acqb::logit_kernel, dim3((unsigned)std::min<long>(groups, 256 * 4)), dim3(acqb::THREADS), acqb::LDS_FLOATS_LOGIT * sizeof(float), c.st, a);
+      if (m->precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32))
+        hipLaunchKernelGGL(acqb::logit_kernel<true>, dim3((unsigned)std::min<long>(groups, 256 * 4)), dim3(acqb::THREADS), acqb::LDS_FLOATS_LOGIT * sizeof(float), c.st, a);
+      else
+        hipLaunchKernelGGL(acqb::logit_kernel<false>, dim3((unsigned)std::min<long>(groups, 256 * 4)), dim3(acqb::THREADS), acqb::LDS_FLOATS_LOGIT * sizeof(float), c.st, a);
       CHECK_LAUNCH();
       // F16X3 models: the products of the head kernels on the f16 matrix pipe, the gradient scaled by the power of two of its maximum
       // (tail_bwd.h: tail16_kernel; the producers -- dlogit_kernel, draw_kernel -- reduce what they write).  ALINE_DBG_BWD_GRAD_F32: exact fp32
@@ -1973,7 +1976,10 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       a.g_std = g_ps ? g_ps + (size_t)tA * B * n_t * C : nullptr;
       a.g_wgt = g_pw ? g_pw + (size_t)tA * B * n_t * C : nullptr;
       const long groups = ((a.rows + 15) / 16 + gmmb::WAVES - 1) / gmmb::WAVES;
-      hipLaunchKernelGGL(gmmb::raw_kernel, dim3((unsigned)std::min<long>(groups, std::max(1, 768 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS_RAW * sizeof(float), c.st, a);
+      if (m->precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32))
+        hipLaunchKernelGGL(gmmb::raw_kernel<true>, dim3((unsigned)std::min<long>(groups, std::max(1, 768 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS_RAW * sizeof(float), c.st, a);
+      else
+        hipLaunchKernelGGL(gmmb::raw_kernel<false>, dim3((unsigned)std::min<long>(groups, std::max(1, 768 / C)), C), dim3(gmmb::THREADS), gmmb::LDS_FLOATS_RAW * sizeof(float), c.st, a);
       CHECK_LAUNCH();
       const bool gmm16 = m->precision == ALINE_PREC_F16X3 && !dbg(ALINE_DBG_BWD_GRAD_F32);
       a.draw_absmax = gmm16 ? new_scale_word(c) : nullptr;
