@@ -1525,10 +1525,17 @@ int ln_bwd(const BCtx &c, const float *dY, const float *U, const float *w, float
 
 // head_dim 32 / 64 on the fp32 matrix pipe (attn_bwd_wide.h); *out_max (when asked for) receives the scale word of dQKV
 template <int HD, int NKT>
-static int launch_attention_bwd_wide(const BCtx &c, const float *qkv, const float *dA, const float *aout, float *dqkv, unsigned *mw, int kro) {
+static int launch_attention_bwd_wide(const BCtx &c, const float *qkv, const float *dA, const float *aout, float *dqkv, unsigned *mw, int kro,
+                                     const unsigned *da_scale = nullptr) {
   const int H = c.m->d / HD, waves = std::min(H, HD == 64 ? 4 : abww::MAXW);
   const size_t smem = abww::lds_bytes(HD, NKT, c.g.N, waves);
   if (smem > 160 * 1024) return ALINE_EUNSUPPORTED;
+  if (da_scale) {      // the f16 matrix pipe, dO scaled by the power of two of max |dA| (attn_bwd_wide.h: attention_bwd_wide16_kernel)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abww::attention_bwd_wide16_kernel<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((abww::attention_bwd_wide16_kernel<HD, NKT>), dim3((unsigned)c.g.B), dim3(64 * waves), smem, c.st, c.g, c.m->d, qkv, dA, aout, dqkv, mw, kro, da_scale);
+    CHECK_LAUNCH();
+    return ALINE_OK;
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&abww::attention_bwd_wide_kernel<HD, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL((abww::attention_bwd_wide_kernel<HD, NKT>), dim3((unsigned)c.g.B), dim3(64 * waves), smem, c.st, c.g, c.m->d, qkv, dA, aout, dqkv, mw, kro);
   CHECK_LAUNCH();
@@ -1564,16 +1571,17 @@ int launch_attention_bwd(const BCtx &c, const float *qkv, const float *dA, float
     if (mfma_on && aout && nkt <= 3 && c.m->d % HD == 0) {      // (<32, 4> spills 64 registers: beyond 48 keys the VALU kernel)
       unsigned *mw = (out_max && bwd_grad_f16(*c.m)) ? new_scale_word(c) : nullptr;
       if (out_max) *out_max = mw;
+      const unsigned *wide_scale = (da_scale && bwd_grad_f16(*c.m)) ? da_scale : nullptr;      // F16X3 model + the scale word of dA: the f16 twin
       if constexpr (HD == 32) {
         switch (nkt) {
-          case 1: return launch_attention_bwd_wide<32, 1>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
-          case 2: return launch_attention_bwd_wide<32, 2>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
-          default: return launch_attention_bwd_wide<32, 3>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
+          case 1: return launch_attention_bwd_wide<32, 1>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0, wide_scale);
+          case 2: return launch_attention_bwd_wide<32, 2>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0, wide_scale);
+          default: return launch_attention_bwd_wide<32, 3>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0, wide_scale);
         }
       } else {
-        if (nkt == 1) return launch_attention_bwd_wide<64, 1>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
-        if (nkt == 2) return launch_attention_bwd_wide<64, 2>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);
-        return launch_attention_bwd_wide<64, 3>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0);      // (cfg5: 1 + 29 context + 4 targets = 34 keys)
+        if (nkt == 1) return launch_attention_bwd_wide<64, 1>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0, wide_scale);
+        if (nkt == 2) return launch_attention_bwd_wide<64, 2>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0, wide_scale);
+        return launch_attention_bwd_wide<64, 3>(c, qkv, dA, aout, dqkv, mw, key_rows_only ? 1 : 0, wide_scale);      // (cfg5: 1 + 29 context + 4 targets = 34 keys)
       }
     }
   }
@@ -2079,7 +2087,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
       TRY(ln_bwd(c, dTmp, U1l(l), m->norm1_w[l], dXn, gr->norm1_w[l], gr->norm1_b[l], M, &sw_u1));   // dXn = dU1
       // out-proj
       TRY(gemm_dw(c, dXn, d, Al(l), d, gr->out_proj_w[l], gr->out_proj_b[l], M, d, d, 1, 1, 0, 1, 1, 0, 0, sw_u1));
-      TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false, nullptr, sw_u1));  // dTmp = dA
+      if (bwd_grad_f16(*m)) sw_da = new_scale_word(c);      // (max |dA| for the attention backward's f16 twin)
+      TRY(gemm_dx(c, dXn, d, m->out_proj_w[l], d, d, dTmp, d, (int)M, false, nullptr, sw_u1, sw_da));  // dTmp = dA
       }
       // attention block: in-projection + attention in one kernel (attn_bwd_mfma.h), dXn = dU1 -> dX_l
       if (ckv) {
@@ -2103,8 +2112,8 @@ static int backward_impl(const aline_model *m, const aline_rollout *r, const flo
         case 4: TRY(launch_attention_bwd<4>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
         case 8: TRY(launch_attention_bwd<8>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), nullptr, false, sw_da)); break;
         case 16: TRY(launch_attention_bwd<16>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l))); break;
-        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse)); break;
-        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse)); break;
+        case 32: TRY(launch_attention_bwd<32>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse, sw_da)); break;
+        case 64: TRY(launch_attention_bwd<64>(c, QKVl(l), dTmp, dQKV, max_keys, Al(l), &sw_att, kv_sparse, sw_da)); break;
         default: return ALINE_EUNSUPPORTED;
       }
       // in-proj (the matrix-pipe attention backward leaves max |dQKV|; the VALU kernels do not: a reduction pass)
