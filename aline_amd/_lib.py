@@ -119,6 +119,7 @@ def _load():
         "aline_eig_history_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
         "aline_eig_location_history": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                                   _fp, _fp, _fp, C.c_size_t, _fp]),
+        "aline_eig_ces_history": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
         "aline_head_backward": (C.c_int, [MP, RP, _fp, _fp, _fp, _fp, _fp, GP, _fp, _fp, C.c_size_t, _fp]),
         "aline_encoder_backward": (C.c_int, [MP, RP, _fp, _fp, GP, _fp, _fp, C.c_size_t, _fp]),
         "aline_embed_backward": (C.c_int, [MP, RP, _fp, GP, _fp, C.c_size_t, _fp]),

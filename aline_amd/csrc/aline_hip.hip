@@ -1222,7 +1222,28 @@ int aline_eig_location_history(const float *theta, const float *xi, const float 
     hipLaunchKernelGGL(eig_location_history_kernel<0>, grid, dim3(256), smem, st, theta, xi, y, (long)L1, B, T, K, D, noise_scale,
                        base_signal, max_signal, R, part, s0);
   CHECK_LAUNCH();
-  hipLaunchKernelGGL(eig_history_combine_kernel, grid1d((size_t)T * B), dim3(256), 0, st, part, s0, (int)R, (long)L1, B, T, pce, nmc);
+  hipLaunchKernelGGL(eig_history_combine_kernel, grid1d((size_t)T * B * 64), dim3(256), 0, st, part, s0, (int)R, (long)L1, B, T, pce, nmc);
+  CHECK_LAUNCH();
+  return ALINE_OK;
+}
+
+// CES histories (tasks/ces.py:96-115): thetas [L1, B, 5], xi [B, T, 6], y [B, T] -> pce / nmc [B, T].  ALINE_EUNSUPPORTED when the per-(episode,
+// step) table does not fit LDS or T > 16: the caller keeps the step kernels.
+int aline_eig_ces_history(const float *theta, const float *xi, const float *y, int64_t L1, int B, int T, float noise_scale, float epsilon,
+                          float *pce, float *nmc, int32_t *nan_flag, void *ws, size_t ws_bytes, void *stream) {
+  if (!theta || !xi || !y || L1 < 2 || B <= 0 || T <= 0 || !ws) return ALINE_EINVAL;
+  const size_t tab_only = ((size_t)B * ((T * (CES_ROW + 1)) | 1) + 2) * sizeof(float);      // padded pitches (eig.h)
+  const size_t tab_bytes = tab_only + (size_t)T * 256 * 2 * sizeof(float);      // + the (max, sum-exp) pairs of the workgroup's threads
+  if (T > 16 || tab_only > 64 * 1024) return ALINE_EUNSUPPORTED;
+  if (ws_bytes < aline_eig_history_workspace_bytes(L1, B, T)) return ALINE_EWORKSPACE;
+  const long R = eig_history_groups(L1, B);
+  float *part = static_cast<float *>(ws), *s0 = part + (size_t)R * T * B * 2;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&eig_ces_history_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes);
+  hipLaunchKernelGGL(eig_ces_history_kernel, dim3((unsigned)(((long)B * R + 255) / 256)), dim3(256), tab_bytes, st, theta, xi, y, (long)L1, B, T,
+                     noise_scale, epsilon, R, part, s0, nan_flag);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(eig_history_combine_kernel, grid1d((size_t)T * B * 64), dim3(256), 0, st, part, s0, (int)R, (long)L1, B, T, pce, nmc);
   CHECK_LAUNCH();
   return ALINE_OK;
 }

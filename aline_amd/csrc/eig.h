@@ -404,20 +404,30 @@ __global__ __launch_bounds__(256) void eig_location_history_kernel(const float *
       }
   }
 }
-// combine the chunks: one thread per (t, b); bounds of utils/eval.py:77-78 per step
+// combine the chunks: one WAVE per (t, b) -- its lanes walk the row groups 64 apart and merge their (max, sum-exp) pairs at the end (one
+// thread per (t, b) walked them alone: 9 830 dependent round trips at B = 20, 5 of the CES history's 5.3 ms); bounds of utils/eval.py:77-78
 __global__ __launch_bounds__(256) void eig_history_combine_kernel(const float *__restrict__ part, const float *__restrict__ s0, int nchunk,
                                                                   long L1, int B, int T, float *pce, float *nmc) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (i >= (long)T * B) return;
   const int t = (int)(i / B), b = (int)(i % B);
   float m = -INFINITY, s = 0.f;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = lane; c < nchunk; c += 64) {
     const float *pp = part + (((size_t)c * T + t) * B + b) * 2;
     const float m2 = pp[0], s2 = pp[1];
     const float mn = fmaxf(m, m2);
     if (mn != -INFINITY) s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
     m = mn;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    if (mn != -INFINITY) s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+  }
+  if (lane != 0) return;
   const float sv = s0[(size_t)t * B + b];
   const float lse1 = m + logf(s);                 // l >= 1
   const float mx = fmaxf(lse1, sv);
@@ -425,6 +435,104 @@ __global__ __launch_bounds__(256) void eig_history_combine_kernel(const float *_
   const float L = (float)(L1 - 1);
   if (pce) pce[(size_t)b * T + t] = logf(L + 1.f) - (lse0 - sv);      // [B, T] as torch.stack(..., dim=-1)
   if (nmc) nmc[(size_t)b * T + t] = logf(L) - (lse1 - sv);
+}
+
+// ---- CES: all T steps of a design history in one pass over theta (round 4, end) -------------------------------------------------------
+// The same scheme as eig_location_history_kernel for CESTask.log_likelihood (tasks/ces.py:96-115, :169-210): a thread owns episode b and the
+// rows 1 + rg, 1 + rg + R, ... of theta (five floats, read ONCE), walks the T designs of its episode -- the per-(episode, step) table of
+// eig_ces_step_table_kernel (clamped designs, their log2, noise scale, logit(y), the censoring kind: CES_ROW floats) is built by every
+// workgroup in LDS, B T rows -- with the running log-likelihood in a register and one online (max, sum-exp) pair per step.  The
+// arithmetic of a step is the table kernel's (same series, same native exp2 / log2): bounds equal to the step kernels' to rounding.
+// T <= 16 (CES histories are 10 steps); the host falls back to the step kernels when the table does not fit 64 KB.
+__global__ __launch_bounds__(256) void eig_ces_history_kernel(const float *__restrict__ theta, const float *__restrict__ xi, const float *__restrict__ y,
+                                                              long L1, int B, int T, float noise, float eps, long R,
+                                                              float *__restrict__ part, float *__restrict__ s0, int *nan_flag) {
+  extern __shared__ float tab[];        // [B][T] rows: x[6] | log2 x[6] | 1/dn | cst | logit(y) | kind | dn | y | log2(xa / xb)[3]
+  // row pitch 25 floats, episode pitch odd: the lanes of a wave hold different episodes and read the same word of their rows -- with the
+  // pitch of the step kernel (24, episodes 240 floats apart) they met in two banks
+  constexpr int RP = CES_ROW + 1;
+  const int EP = (T * RP) | 1;
+  for (int i = threadIdx.x; i < B * T; i += blockDim.x) {
+    float *r = tab + (size_t)(i / T) * EP + (size_t)(i % T) * RP;
+    const float *xr = xi + (size_t)i * 6;      // xi [B, T, 6], y [B, T]
+    float x[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { x[c] = fminf(fmaxf(xr[c], 0.01f), 100.f); r[c] = x[c]; r[6 + c] = log2f(x[c]); }
+    const float dd0 = x[0] - x[3], dd1 = x[1] - x[4], dd2 = x[2] - x[5];
+    const float dn = (1.f + sqrtf(dd0 * dd0 + dd1 * dd1 + dd2 * dd2)) * noise;
+    const float v = y[i], lo = eps, hi = 1.f - eps;
+    const int kind = (v > hi || v < lo) ? 3 : (v == hi || v == lo) ? 1 : 0;
+    const float xl = logit_clamped(v);
+    r[12] = 1.f / dn;
+    r[13] = softplus_t(-xl) + softplus_t(xl) - LOG_SQRT_2PI - logf(dn);
+    r[14] = xl;
+    r[15] = __int_as_float(kind);
+    r[16] = dn;
+    r[17] = v;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[18 + c] = (float)log2((double)x[c] / (double)x[3 + c]);
+  }
+  __syncthreads();
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)B * R) return;
+  const int b = (int)(gid % B);
+  const long rg = gid / B;
+  const float *rows = tab + (size_t)b * EP;
+  auto lp_of = [&](const float *th, const float *r) -> float {      // (eig_ces_step_table_kernel's step)
+    const float rho = th[0], a0 = th[1], a1 = th[2], a2 = th[3], t4 = th[4];
+    const int kind = __float_as_int(r[15]);
+    if (kind == 3) return -INFINITY;
+    const float ir = 1.f / rho;
+    const float t0 = a0 * __builtin_amdgcn_exp2f(rho * r[9]), t1 = a1 * __builtin_amdgcn_exp2f(rho * r[10]), t2 = a2 * __builtin_amdgcn_exp2f(rho * r[11]);
+    const float s2 = t0 + t1 + t2;
+    const float ds = t0 * exp2m1_f(rho * r[18]) + t1 * exp2m1_f(rho * r[19]) + t2 * exp2m1_f(rho * r[20]);
+    const float u2 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(s2) * ir);
+    const float du = u2 * exp2m1_f(log2_1p_f(ds / s2) * ir);          // u1 - u2
+    if (kind == 0) {
+      const float z = (r[14] * __expf(-t4) - du) * r[12];
+      return -0.5f * z * z - t4 + r[13];
+    }
+    const float u = expf(t4);                                          // outcome at a censoring limit
+    return csn_log_prob(r[17], du * u, r[16] * u, eps, 1.f - eps);
+  };
+  bool bad = false;
+  if (rg == 0) {                               // row l = 0 (the true theta)
+    float th[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) th[e] = theta[(size_t)b * 5 + e];
+    float S = 0.f;
+    for (int t = 0; t < T; ++t) { const float lp = lp_of(th, rows + t * RP); bad |= (lp != lp) || isinf(lp); S += lp; s0[(size_t)t * B + b] = S; }
+  }
+  // the (max, sum-exp) pair of every step lives in LDS ([T][256] pairs behind the table: the step loop is a real loop -- unrolled over 16
+  // steps with two rows in flight the body was ~10 000 instructions, more than the instruction cache, and the kernel 2 x slower than the
+  // ten step launches it replaces)
+  float2 *ms = reinterpret_cast<float2 *>(tab + (((size_t)B * EP + 1) & ~(size_t)1)) + threadIdx.x;
+  for (int t = 0; t < T; ++t) ms[t * 256] = make_float2(-INFINITY, 0.f);
+  for (long l = 1 + rg; l < L1; l += 2 * R) {      // two rows per pass: two independent chains
+    const bool on1 = l + R < L1;
+    float tha[5], thb[5];
+    const float *pa = theta + (l * B + b) * 5, *pb = theta + ((on1 ? l + R : l) * B + b) * 5;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) { tha[e] = __builtin_nontemporal_load(pa + e); thb[e] = __builtin_nontemporal_load(pb + e); }
+    float Sa = 0.f, Sb = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+      const float la = lp_of(tha, rows + t * RP), lb = lp_of(thb, rows + t * RP);
+      bad |= (la != la) || isinf(la) || (on1 && ((lb != lb) || isinf(lb)));
+      Sa += la; Sb = on1 ? Sb + lb : -INFINITY;
+      float2 p = ms[t * 256];
+      const float mn = fmaxf(p.x, fmaxf(Sa, Sb));
+      if (mn != -INFINITY) p.y = p.y * __expf(p.x - mn) + __expf(Sa - mn) + __expf(Sb - mn);
+      p.x = mn;
+      ms[t * 256] = p;
+    }
+  }
+  for (int t = 0; t < T; ++t) {
+    const float2 p = ms[t * 256];
+    float *pp = part + (((size_t)rg * T + t) * B + b) * 2;
+    pp[0] = p.x; pp[1] = p.y;
+  }
+  if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
 // ---- batched Cholesky for the GP task sampler (tasks/gaussian_process.py:391-415) ------

@@ -67,6 +67,26 @@ class CESTask(Task):
             y.reshape(B).contiguous().data_ptr(), S.data_ptr(), L1, B, self.noise_scale, self.epsilon,
             None if nan_flag is None else nan_flag.data_ptr(), _lib.stream_ptr(S.device)), "eig_ces_step")
 
+    _hist_ws = _lib.Workspace()
+
+    def native_eig_history(self, thetas, x, y):
+        """Stepwise sPCE / sNMC bounds of a whole design history in ONE pass over the contrastive samples (C ABI aline_eig_ces_history):
+        thetas [L + 1, B, 5] with row 0 the true parameter, x [B, T, 6] designs in order of acquisition, y [B, T(, 1)] ->
+        (pce [B, T], nmc [B, T]) = what utils/eval.py:64-78 returns with stepwise=True.  Returns None where the kernel does not apply
+        (more than 16 steps, or a per-(episode, step) table beyond 64 KB): the caller keeps the step kernels."""
+        L1, B = thetas.shape[0], thetas.shape[1]
+        T = x.shape[1]
+        if T > 16 or B * T * 96 > 64 * 1024:
+            return None
+        th = _lib.f32(thetas).reshape(L1, B, 5).contiguous()
+        xx, yy = _lib.f32(x).reshape(B, T, 6).contiguous(), _lib.f32(y).reshape(B, T).contiguous()
+        pce, nmc = torch.empty(B, T, device=th.device), torch.empty(B, T, device=th.device)
+        ws = self._hist_ws.get(_lib.lib.aline_eig_history_workspace_bytes(L1, B, T), th.device)
+        _lib.check(_lib.lib.aline_eig_ces_history(th.data_ptr(), xx.data_ptr(), yy.data_ptr(), L1, B, T, self.noise_scale, self.epsilon,
+                                                  pce.data_ptr(), nmc.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                                  _lib.stream_ptr(th.device)), "eig_ces_history")
+        return pce, nmc
+
     @torch.no_grad()
     def sample_batch(self, batch_size):
         theta = self.sample_theta(batch_size).reshape(batch_size, self.n_theta, 1)

@@ -54,8 +54,10 @@ def compute_EIG_from_history(experiment, theta_0, x, y, L=int(1e6), batch_size=4
     thetas = torch.concat([theta_0.unsqueeze(0), thetas], dim=0).contiguous()
     if fused and hasattr(experiment, "native_eig_history"):
         # all T steps in one pass over thetas (the T step launches read thetas and the running sums T times: eig.h)
-        pce, nmc = experiment.native_eig_history(thetas, x, y)
-        return (pce, nmc) if stepwise else (pce[:, -1], nmc[:, -1])
+        out = experiment.native_eig_history(thetas, x, y)
+        if out is not None:      # (None: the task's history kernel does not take this shape -- the step kernels below)
+            pce, nmc = out
+            return (pce, nmc) if stepwise else (pce[:, -1], nmc[:, -1])
     criterion = EIGStepLoss(L, batch_size, experiment, reduction="none", device=x.device)
     pce_l, nmc_l = [], []
     for t in range(T):

@@ -377,6 +377,27 @@ def measure_eig(device, n=10):
                                        "fused_algorithmic_bytes": (L + 1) * B * 8, "fused_GBps": (L + 1) * B * 8 / (res[True] * 1e-3) / 1e9,
                                        "note": "fused: one pass over theta for all T steps (bound: transcendental units, not HBM); stepwise: "
                                                "T x (step kernel + streaming logsumexp), 20 B per (l, b) and step"}
+        if name == "ces":
+            # the CES history of T = 10 designs (BASELINE.json configs[3]): T step + logsumexp launches against ONE pass over theta
+            # (aline_eig_ces_history, round 4): theta once, 20 B per (l, b)
+            from aline_amd.utils import compute_EIG_from_history
+            T = 10
+            th0, thl = theta[0], theta[1:]
+            xs = 100.0 * torch.rand(B, T, 6, device=device)
+            ys = torch.stack([task.forward(xs[:, t], th0) for t in range(T)], 1)
+            res = {}
+            for fused in (True, False):
+                compute_EIG_from_history(task, th0, xs, ys, L=L, batch_size=B, stepwise=True, thetas=thl, fused=fused)
+                torch.cuda.synchronize(device)
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                f0.record()
+                for _ in range(5):
+                    compute_EIG_from_history(task, th0, xs, ys, L=L, batch_size=B, stepwise=True, thetas=thl, fused=fused)
+                f1.record()
+                torch.cuda.synchronize(device)
+                res[fused] = f0.elapsed_time(f1) / 5
+            out["ces_history"] = {"T": T, "L": L, "B": B, "fused_ms": res[True], "stepwise_ms": res[False], "speedup": res[False] / res[True],
+                                  "fused_algorithmic_bytes": (L + 1) * B * 20, "fused_GBps": (L + 1) * B * 20 / (res[True] * 1e-3) / 1e9}
         del theta, crit
         torch.cuda.empty_cache()
     return out

@@ -228,6 +228,11 @@ size_t aline_eig_history_workspace_bytes(int64_t L1, int B, int T);
 int aline_eig_location_history(const float *theta, const float *xi, const float *y, int64_t L1, int B, int T, int K, int D,
                                float noise_scale, float base_signal, float max_signal, float *pce, float *nmc, void *ws,
                                size_t ws_bytes, void *stream);
+/* The same for the CES likelihood (tasks/ces.py:96-115, :169-210; CensoredSigmoidNormal as aline_eig_ces_step): theta [L1, B, 5],
+ * xi [B, T, 6], y [B, T].  ALINE_EUNSUPPORTED when T > 16 or the per-(episode, step) table (96 B T bytes) exceeds 64 KB: use the step
+ * entry points then.  nan_flag as in aline_eig_ces_step. */
+int aline_eig_ces_history(const float *theta, const float *xi, const float *y, int64_t L1, int B, int T, float noise_scale,
+                          float epsilon, float *pce, float *nmc, int32_t *nan_flag, void *ws, size_t ws_bytes, void *stream);
 
 /* --- task samplers (input generators) ---------------------------------------------- */
 /* Batched in-place Cholesky A = U^T U of `batch` symmetric positive-definite [n,n] matrices (upper

@@ -166,6 +166,32 @@ def test_fused_eig_history_equals_the_step_by_step_bounds(B, L, T, K):
     assert maxdiff(p1, ps[:, -1].cpu()) < 2e-4 and maxdiff(n1, ns[:, -1].cpu()) < 2e-4
 
 
+@pytest.mark.parametrize("B,L,T", [(40, 200_000, 10), (20, 100_000, 10), (7, 30_000, 16)])
+def test_fused_ces_eig_history_equals_the_step_by_step_bounds(B, L, T):
+    """`aline_eig_ces_history` (all steps of a CES design history in one pass over the contrastive samples; the per-step arithmetic is
+    `eig_ces_step_table_kernel`'s) against one `EIGStepLoss` step + logsumexp per design on the step kernels, same draw: stepwise sPCE /
+    sNMC of every step (tasks/ces.py:96-115, :169-210; loss/eig.py:174-209; utils/eval.py:64-78).  The outcomes include censored ones
+    (y at eps / 1 - eps: the log-cdf branch).  A history the kernel does not take (T > 16) falls back to the step kernels."""
+    from aline_amd.tasks import CESTask
+    from aline_amd.utils import compute_EIG_from_history
+    torch.manual_seed(B + T)
+    dev = torch.device("cuda")
+    task = CESTask(device=dev)
+    theta0 = task.sample_theta(B)
+    x = 100.0 * torch.rand(B, T, 6, device=dev)
+    y = torch.stack([task.forward(x[:, t], theta0) for t in range(T)], 1)
+    assert bool(((y <= task.epsilon) | (y >= 1 - task.epsilon)).any())          # censored outcomes are in the draw
+    thetas = task.sample_theta((L, B))
+    pf, nf = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=True, thetas=thetas)
+    ps, ns = compute_EIG_from_history(task, theta0, x, y, L=L, batch_size=B, stepwise=True, thetas=thetas, fused=False)
+    assert pf.shape == ps.shape == (B, T)
+    fin = torch.isfinite(ps) & torch.isfinite(ns)
+    assert torch.equal(torch.isfinite(pf) & torch.isfinite(nf), fin)
+    assert fin.float().mean() > 0.5
+    assert float((pf - ps)[fin].abs().max()) < 2e-3 and float((nf - ns)[fin].abs().max()) < 2e-3, (float((pf - ps)[fin].abs().max()), float((nf - ns)[fin].abs().max()))
+    assert task.native_eig_history(thetas[:100], x.repeat(1, 2, 1), y.repeat(1, 2, 1)) is None      # 2 T > 16 steps: not taken
+
+
 def test_range_status_word_survives_graph_replays_with_eager_launches_in_between():
     """The status word of the f16 range guard (first word of the workspace) is cleared by a KERNEL node of the captured rollout
     (aline_hip.hip: clear_words_kernel): a captured hipMemsetAsync was seen to fill its bytes with the arguments of the eager launch
